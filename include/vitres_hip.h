@@ -1,0 +1,169 @@
+/*
+ * vitres_hip.h -- C ABI of libvitres_hip.so, the MI355X (gfx950) kernel library behind the
+ * ViT-Res (super)network hot path of yilunliao/vit-search.
+ *
+ * The reference has NO native code and no FFI: the seam the hot path sits behind is the timm model
+ * registry + nn.Module protocol (reference main.py:329-348).  This header is
+ * therefore the boundary a maintainer of the reference would bind (with ctypes)
+ * to replace the ATen op sequences listed next to each entry point.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain device pointers and sizes; no torch types.
+ *   - The caller owns every buffer (inputs, outputs, workspaces); the library never allocates,
+ *     frees or retains pointers and keeps no global mutable state; re-entrant.
+ *   - All work is enqueued asynchronously on `stream`; no hidden synchronisation.
+ *   - Return value: 0 = ok; > 0 = hipError_t of the launch; < 0 = argument validation
+ *     (VR_EINVAL -1, VR_EALIGN -2, VR_EUNSUPPORTED -3).  No exceptions cross the ABI.
+ *   - dtype codes: VR_F32 = 0 (exact-fp32 parity mode), VR_BF16 = 1 (raw bf16 bits, fast mode).
+ *   - `keep` arrays: int32[B], active channel-prefix length of each sample for that tensor
+ *     (the reference's ChannelDrop prefix masks, nets/channel_drop.py:153-154); NULL = dense.
+ *   - "rows_per_sample": number of consecutive rows (tokens) that belong to one sample.
+ */
+#ifndef VITRES_HIP_H
+#define VITRES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* vr_stream_t; /* == hipStream_t */
+
+#define VR_F32 0
+#define VR_BF16 1
+
+/* library / ABI version (major*1000 + minor) */
+int vr_version(void);
+
+/* row remap of a token-indexed operand: row(m) = (m / rpi) * rps + off + (m % rpi); rpi==0: identity */
+typedef struct vr_rowmap {
+    int32_t rpi, rps, off;
+} vr_rowmap;
+
+/*
+ * Generic fused GEMM:  C[M,N] (+)= epilogue( A[M,K] * B[N,K]^T )
+ * Replaces: nn.Linear forward/backward in nets/supernet_blocks.py:37-52,102-119 (qkv, proj, fc1, fc2),
+ * cls_head/patch_head (nets/vit_sr_supernet.py:440-446), token_transform (:151), the patchify
+ * convolutions expressed as GEMMs (timm PatchEmbed, nets/patch_conv.py:56-58, vit_sr_supernet.py:140),
+ * and the `x * mask` / drop_path / residual adds that follow them (supernet_blocks.py:214-253).
+ *
+ *   a_trans/b_trans = 0: operand stored [rows, K] (K contiguous); 1: stored [K, rows] (rows contiguous).
+ *   forward   y = x W^T      : a_trans 0, b_trans 0
+ *   dgrad     dx = dy W      : a_trans 0, b_trans 1      (B = W viewed as [K_out rows][N_in contraction])
+ *   wgrad     dW = dy^T x    : a_trans 1, b_trans 1, contraction over tokens, split_k > 1, atomic = 1
+ * Epilogue, in this order:  v = acc (+ bias[n]) (+ pos[m % rows_in][n]);
+ *   act==1: C gets the pre-activation u=v, C2 gets gelu(u) (masked by keep_n);   (Mlp.forward)
+ *   dact_u != NULL: v *= gelu'(u[m][n]);                                          (fc2 dgrad -> du)
+ *   keep_n: v = 0 where n >= keep_n[sample(m)];  scale: v *= scale[sample(m)];   (ChannelDrop, DropPath)
+ *   resid != NULL: v += resid[out_row][n] (fp32, ldc layout);  atomic: atomicAdd into fp32 C.
+ */
+typedef struct vr_gemm_args {
+    const void* A;
+    const void* B;
+    void* C;
+    void* C2;            /* second output for act==1 (same dtype/ld as C) or NULL */
+    const float* bias;   /* [N] or NULL */
+    const float* pos;    /* [rows_in, N] or NULL */
+    const float* scale;  /* [batch] or NULL */
+    const int32_t* keep_n; /* [batch] or NULL */
+    const float* resid;  /* fp32 [*, ldc] or NULL (may alias C for in-place accumulate) */
+    const void* dact_u;  /* pre-activation for gelu' (dtype = in_dtype, leading dim ldu) or NULL */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldu;
+    int32_t a_trans, b_trans;
+    int32_t in_dtype;    /* dtype of A and B (and dact_u) */
+    int32_t out_dtype;   /* dtype of C/C2 */
+    int32_t act;         /* 0 none, 1 gelu dual store */
+    int32_t atomic;      /* 1: atomicAdd fp32 */
+    int32_t split_k;     /* >= 1 */
+    int32_t rows_in;     /* rows per sample of the M index (0: single sample) */
+    vr_rowmap a_map;     /* remap of A's token rows (M index if a_trans==0, K index if a_trans==1) */
+    vr_rowmap b_map;     /* remap of B's token rows (only meaningful when b_trans==1 && a_trans==1) */
+    vr_rowmap c_map;     /* remap of output rows */
+} vr_gemm_args;
+
+int vr_gemm(const vr_gemm_args* args, vr_stream_t stream);
+
+/* fp32 -> bf16 (round to nearest even), n elements.  Replaces autocast's per-op weight casts (engine.py:112). */
+int vr_cast_f32_bf16(const float* src, void* dst, int64_t n, vr_stream_t stream);
+
+/*
+ * Masked LayerNorm forward (nets/masked_layer_norm.py:23-50,113-125).  x fp32 [M,C] -> y (dtype) [M,C];
+ * mean/rstd fp32 [M] saved for backward.  keep NULL -> plain LayerNorm (F.layer_norm path :118-122).
+ */
+int vr_ln_fwd(const float* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+              const int32_t* keep, int32_t M, int32_t C, int32_t rows_per_sample, float eps,
+              int32_t out_dtype, vr_stream_t stream);
+
+/*
+ * Masked LayerNorm backward (nets/masked_layer_norm.py:55-88).  dx_out = (dx_in ? dx_in : 0) + dLN/dx;
+ * dw/db (fp32 [C]) are accumulated with atomics (caller zeroes them).  dy has dtype `dy_dtype`.
+ */
+int vr_ln_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+              const int32_t* keep, const float* dx_in, float* dx_out, float* dw, float* db,
+              int32_t M, int32_t C, int32_t rows_per_sample, int32_t dy_dtype, vr_stream_t stream);
+
+/*
+ * Multi-head self-attention core (nets/supernet_blocks.py:105-109): qkv [B,N,3,H,D] -> o [B,N,H*D],
+ * lse fp32 [B,H,N].  Heads h >= keep_hd[b]/D are written as zeros (Attention's ChannelDrop, :111-112).
+ */
+int vr_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* keep_hd, int32_t B, int32_t N,
+                int32_t H, int32_t D, float scale, int32_t dtype, vr_stream_t stream);
+int vr_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta /* [B,H,N] scratch */,
+                void* dqkv, const int32_t* keep_hd, int32_t B, int32_t N, int32_t H, int32_t D, float scale,
+                int32_t dtype, vr_stream_t stream);
+
+/*
+ * Soft-target cross entropy, forward + gradient in one pass (timm SoftTargetCrossEntropy as used by
+ * engine.py:153-157): loss_rows[r] = sum_k -t[r,k] * log_softmax(x[r])[k];
+ * dlogits[r,k] = gscale * (softmax(x[r])[k] * sum_k t[r,k] - t[r,k]).
+ */
+int vr_softce(const float* logits, const float* target, float* loss_rows, float* dlogits, int32_t R,
+              int32_t K, float gscale, vr_stream_t stream);
+
+/* out[n] += sum_m in[map(m), n]  (bias gradients; atomics, caller zeroes out).  in: dtype [*, ld]. */
+int vr_colsum(const void* in, float* out, int32_t M, int32_t N, int32_t ld, int32_t dtype, vr_rowmap map, vr_stream_t stream);
+
+/*
+ * Gradient entering a masked / drop-path'd residual branch (autograd of supernet_blocks.py:243-253 and
+ * drop.py:24-25): out[m,c] = dtype(in[m,c] * scale[sample]) for c < keep[sample], else 0.  in fp32 [M,C].
+ */
+int vr_scale_mask_cast(const float* in, void* out, const float* scale, const int32_t* keep, int32_t M, int32_t C,
+                       int32_t rows_per_sample, int32_t out_dtype, vr_stream_t stream);
+
+/* out[r, c] = sum_b in[b, r, c]   (pos_embed / tokens gradients: sum over the batch). fp32. */
+int vr_batchsum(const float* in, float* out, int32_t B, int64_t inner, vr_stream_t stream);
+
+/*
+ * timm PatchEmbed as a GEMM operand (vit_sr_supernet.py:227,234): image fp32 NCHW [B,Cin,H,W] ->
+ * col (dtype) [B*gh*gw, ldk] with k = (c, i, j), zero padded up to ldk.
+ */
+int vr_im2col_patch(const float* img, void* col, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t P,
+                    int32_t ldk, int32_t dtype, vr_stream_t stream);
+
+/* token row 0 of the embedding: x[b,0,c] = (tokens[c] + pos[0,c]) masked by keep (vit_sr_supernet.py:399-407) */
+int vr_embed_cls(const float* tokens, const float* pos, float* x, const int32_t* keep, int32_t B, int32_t N,
+                 int32_t C, vr_stream_t stream);
+
+/*
+ * SpatialReductionPatchEmbedding pieces (nets/vit_sr_supernet.py:114-172), grid g x g -> g/2 x g/2:
+ *  vr_sr_im2col : y (dtype) [B,1+g*g,C] -> col (dtype) [B*(g/2)^2, 9*C], k = (kh,kw,c), 3x3 stride 2 pad 1
+ *  vr_sr_col2im : dcol -> dy rows 1.. (gather form, no atomics); row 0 left untouched
+ *  vr_sr_resid  : out fp32 [B,1+(g/2)^2,Cout] = zero-padded residual (cls row copy; 2x2 avg-pool of patches)
+ *  vr_sr_resid_bwd : dx[b,0,:C] (+)= dout[b,0,:C]; dx[b,1+p,:C] (+)= 0.25*dout[b,1+p/2..]
+ */
+int vr_sr_im2col(const void* y, void* col, int32_t B, int32_t g, int32_t C, int32_t dtype, vr_stream_t stream);
+int vr_sr_col2im(const void* dcol, void* dy, int32_t B, int32_t g, int32_t C, int32_t dtype, vr_stream_t stream);
+int vr_sr_resid(const float* x, float* out, int32_t B, int32_t g, int32_t Cin, int32_t Cout, vr_stream_t stream);
+int vr_sr_resid_bwd(const float* dout, float* dx, int32_t B, int32_t g, int32_t Cin, int32_t Cout,
+                    int32_t accumulate, vr_stream_t stream);
+
+/* x[m, c] = 0 for c >= keep[sample(m)]  (ChannelDrop.forward `x * mask`, nets/channel_drop.py:82) */
+int vr_mask_rows(float* x, const int32_t* keep, int32_t M, int32_t C, int32_t rows_per_sample, vr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITRES_HIP_H */

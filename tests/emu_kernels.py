@@ -1,0 +1,245 @@
+"""TEST-ONLY torch emulation of the C-ABI kernels (semantics of include/vitres_hip.h), used to validate
+the host-side orchestration (vitres/functional.py, nets/vit_sr_supernet.py) on a machine without a GPU.
+
+Never imported by the product.  `install(monkeypatch)` swaps the functions of vitres.kernels for these;
+the GPU tests compare the real kernels against the same oracle instead.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _rows(n, m):
+    idx = torch.arange(n)
+    if not m or m[0] == 0:
+        return idx
+    rpi, rps, off = m
+    return (idx // rpi) * rps + off + idx % rpi
+
+
+def _flat2d(t, ld):
+    return t.reshape(-1)[: (t.numel() // ld) * ld].view(-1, ld)
+
+
+def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
+         scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
+         a_map=None, b_map=None, c_map=None):
+    A2, B2 = _flat2d(a, lda), _flat2d(b, ldb)
+    if not a_trans:
+        Am = A2[_rows(M, a_map)][:, :K].float()
+    else:
+        Am = A2[_rows(K, a_map)][:, :M].float().t()
+    if not b_trans:
+        Bm = B2[_rows(N, None)][:, :K].float()
+    else:
+        Bm = B2[_rows(K, b_map if a_trans else None)][:, :N].float().t()
+    v = Am @ Bm.t()
+    m_idx = torch.arange(M)
+    sample = (m_idx // rows_in) if rows_in > 0 else torch.zeros(M, dtype=torch.long)
+    mloc = (m_idx % rows_in) if rows_in > 0 else m_idx
+    if bias is not None:
+        v = v + bias.view(1, N)
+    if pos is not None:
+        v = v + _flat2d(pos, N)[mloc]
+    keep = keep_n.long()[sample] if keep_n is not None else torch.full((M,), N)
+    nmask = torch.arange(N)[None, :] < keep[:, None]
+    orow = _rows(M, c_map)
+    C2d = _flat2d(out, ldc)
+    if act == 1:
+        C2d[orow, :N] = v.to(out.dtype)
+        h = torch.where(nmask, F.gelu(v), torch.zeros_like(v))
+        _flat2d(out2, ldc)[orow, :N] = h.to(out.dtype)
+        return out
+    if dact_u is not None:
+        u = _flat2d(dact_u, ldu)[orow, :N].float()
+        cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2.0)))
+        pdf = torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+        v = v * (cdf + u * pdf)
+    v = torch.where(nmask, v, torch.zeros_like(v))
+    if scale is not None:
+        v = v * scale[sample].view(M, 1)
+    if atomic:
+        C2d[orow, :N] += v
+        return out
+    if resid is not None:
+        v = v + _flat2d(resid, ldc)[orow, :N]
+    C2d[orow, :N] = v.to(out.dtype)
+    return out
+
+
+def cast_bf16(src, dst):
+    dst.copy_(src)
+    return dst
+
+
+def _keep_mask(keep, M, C, rps):
+    if keep is None:
+        return torch.ones(M, C, dtype=torch.bool), torch.full((M,), C, dtype=torch.float32)
+    k = keep.long()[torch.arange(M) // rps]
+    return torch.arange(C)[None, :] < k[:, None], k.float()
+
+
+def ln_fwd(x, w, b, keep, rows_per_sample, eps, out_dtype):
+    C = x.shape[-1]
+    X = x.reshape(-1, C).float()
+    M = X.shape[0]
+    mask, kc = _keep_mask(keep, M, C, rows_per_sample)
+    Xm = X * mask
+    mu = Xm.sum(1) / kc
+    if keep is None:
+        var = ((X - mu[:, None]) ** 2).mean(1)
+    else:
+        var = (Xm * Xm).sum(1) / kc - mu * mu
+    rstd = 1.0 / torch.sqrt(var + eps)
+    y = (w * ((Xm - mu[:, None]) * rstd[:, None]) + b) * mask
+    return y.view(x.shape).to(out_dtype), mu, rstd
+
+
+def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db):
+    C = x.shape[-1]
+    X = x.reshape(-1, C).float()
+    G = dy.reshape(-1, C).float()
+    M = X.shape[0]
+    mask, kc = _keep_mask(keep, M, C, rows_per_sample)
+    G = G * mask
+    z = (X - mean[:, None]) * rstd[:, None] * mask
+    dz = G * w
+    s1 = dz.sum(1) / kc
+    s2 = (dz * z).sum(1) / kc
+    dx = (dz - (s1[:, None] + z * s2[:, None])) * rstd[:, None]
+    if dx_in is not None:
+        dx = dx + dx_in.reshape(-1, C)
+    dx = dx * mask
+    dw += (G * z).sum(0)
+    db += G.sum(0)
+    return dx.view(x.shape)
+
+
+def attn_fwd(qkv, keep_hd, B, N, H, D, scale):
+    q, k, v = qkv.float().view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * scale
+    lse = torch.logsumexp(s, dim=-1)
+    o = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, N, H * D)
+    if keep_hd is not None:
+        hm = (torch.arange(H)[None, :] * D) < keep_hd.long()[:, None]
+        o = o * hm.repeat_interleave(D, dim=1)[:, None, :]
+        lse = lse * hm[:, :, None]
+    return o.to(qkv.dtype), lse
+
+
+def attn_bwd(qkv, o, d_o, lse, keep_hd, B, N, H, D, scale):
+    qkv32 = qkv.float().detach().requires_grad_(True)
+    with torch.enable_grad():
+        out, _ = attn_fwd(qkv32, keep_hd, B, N, H, D, scale)
+        g = d_o.float()
+        (dq,) = torch.autograd.grad(out, qkv32, g)
+    if keep_hd is not None:
+        hm = ((torch.arange(H)[None, :] * D) < keep_hd.long()[:, None]).repeat_interleave(D, dim=1)
+        dq = dq.view(B, N, 3, H * D) * hm[:, None, None, :]
+    return dq.reshape(qkv.shape).to(qkv.dtype)
+
+
+def softce(logits, target, gscale, want_grad=True):
+    K = logits.shape[-1]
+    x, t = logits.reshape(-1, K).float(), target.reshape(-1, K).float()
+    lsm = F.log_softmax(x, dim=-1)
+    loss = -(t * lsm).sum(-1)
+    d = None
+    if want_grad:
+        d = (gscale * (lsm.exp() * t.sum(-1, keepdim=True) - t)).view(logits.shape)
+    return loss, d
+
+
+def colsum(x, out, M, N, ld, row_map=None):
+    out += _flat2d(x, ld)[_rows(M, row_map)][:, :N].float().sum(0)
+    return out
+
+
+def scale_mask_cast(x, scale, keep, rows_per_sample, out_dtype):
+    C = x.shape[-1]
+    X = x.reshape(-1, C).float()
+    M = X.shape[0]
+    mask, _ = _keep_mask(keep, M, C, rows_per_sample)
+    if scale is not None:
+        X = X * scale[torch.arange(M) // rows_per_sample].view(M, 1)
+    return (X * mask).view(x.shape).to(out_dtype)
+
+
+def batchsum(x, out):
+    out.copy_(x.sum(0).view(out.shape))
+    return out
+
+
+def im2col_patch(img, P, ldk, out_dtype):
+    B, Cin, H, W = img.shape
+    col = F.unfold(img, kernel_size=P, stride=P).transpose(1, 2).reshape(B * (H // P) * (W // P), Cin * P * P)
+    out = torch.zeros(col.shape[0], ldk, dtype=out_dtype)
+    out[:, :col.shape[1]] = col.to(out_dtype)
+    return out
+
+
+def embed_cls(tokens, pos, x, keep):
+    B, N, C = x.shape
+    row = (tokens.reshape(-1)[:C] + pos.reshape(-1)[:C])[None, :].expand(B, C)
+    if keep is not None:
+        row = row * (torch.arange(C)[None, :] < keep.long()[:, None])
+    x[:, 0, :] = row
+    return x
+
+
+def sr_im2col(y, B, g, C):
+    img = y.view(B, 1 + g * g, C)[:, 1:, :].float().transpose(1, 2).reshape(B, C, g, g)
+    u = F.unfold(img, kernel_size=3, stride=2, padding=1)                    # [B, C*9, go*go], k = (c, kh, kw)
+    go = g // 2
+    u = u.view(B, C, 9, go * go).permute(0, 3, 2, 1).reshape(B * go * go, 9 * C)   # k = (tap, c)
+    return u.to(y.dtype)
+
+
+def sr_col2im(dcol, dy, B, g, C):
+    go = g // 2
+    u = dcol.float().view(B, go * go, 9, C).permute(0, 3, 2, 1).reshape(B, C * 9, go * go)
+    img = F.fold(u, output_size=(g, g), kernel_size=3, stride=2, padding=1)  # [B, C, g, g]
+    dy.view(B, 1 + g * g, C)[:, 1:, :] = img.flatten(2).transpose(1, 2).to(dy.dtype)
+    return dy
+
+
+def sr_resid(x, B, g, cin, cout):
+    go = g // 2
+    out = torch.zeros(B, 1 + go * go, cout)
+    out[:, 0, :cin] = x[:, 0, :]
+    img = x[:, 1:, :].transpose(1, 2).reshape(B, cin, g, g)
+    out[:, 1:, :cin] = F.avg_pool2d(img, 2, 2).flatten(2).transpose(1, 2)
+    return out
+
+
+def sr_resid_bwd(dout, B, g, cin, cout):
+    go = g // 2
+    dx = torch.zeros(B, 1 + g * g, cin)
+    dx[:, 0, :] = dout[:, 0, :cin]
+    gi = dout[:, 1:, :cin].transpose(1, 2).reshape(B, cin, go, go)
+    gi = gi.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) * 0.25
+    dx[:, 1:, :] = gi.flatten(2).transpose(1, 2)
+    return dx
+
+
+def mask_rows(x, keep, rows_per_sample):
+    C = x.shape[-1]
+    X = x.view(-1, C)
+    mask, _ = _keep_mask(keep, X.shape[0], C, rows_per_sample)
+    X.mul_(mask)
+    return x
+
+
+ALL = ["gemm", "cast_bf16", "ln_fwd", "ln_bwd", "attn_fwd", "attn_bwd", "softce", "colsum", "scale_mask_cast",
+       "batchsum", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
+
+
+def install(monkeypatch):
+    import vitres.kernels as K
+    g = globals()
+    for name in ALL:
+        monkeypatch.setattr(K, name, g[name])
+    # the model refuses CPU tensors; tests lift that guard explicitly
+    import vitres.nets.vit_sr_supernet as V
+    monkeypatch.setattr(V, "_REQUIRE_CUDA", False, raising=False)

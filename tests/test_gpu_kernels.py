@@ -1,0 +1,244 @@
+"""Unit parity of every HIP kernel (through the C ABI) against the torch statement of its semantics
+(tests/emu_kernels.py) on seeded inputs.  fp32 kernels: ~1e-5; bf16 kernels: bf16 rounding of the outputs."""
+import numpy as np
+import pytest
+import torch
+
+import emu_kernels as E
+import vitres.kernels as K
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-6))
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1.2e-2
+
+
+def both(fn_name, cpu_args, cpu_kwargs=None, tensor_outs=()):
+    """Run emu on CPU args and the real kernel on .cuda() copies; returns (real, ref)."""
+    cpu_kwargs = cpu_kwargs or {}
+    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+    ref = getattr(E, fn_name)(*[a.clone() if isinstance(a, torch.Tensor) else a for a in cpu_args],
+                              **{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in cpu_kwargs.items()})
+    real = getattr(K, fn_name)(*[to(a) for a in cpu_args], **{k: to(v) for k, v in cpu_kwargs.items()})
+    torch.cuda.synchronize()
+    return real, ref
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K_", [(257 * 3, 576, 192), (130, 1000, 96), (64, 10, 32), (2176, 768, 3072), (8, 24, 40)])
+def test_gemm_forward_epilogues(dtype, M, N, K_):
+    rows_in = 257 if M % 257 == 0 else 0
+    Bn = max(M // rows_in, 1) if rows_in else 1
+    a = rnd(M, K_, seed=1).to(dtype)
+    b = rnd(N, K_, seed=2, scale=K_ ** -0.5).to(dtype)
+    bias = rnd(N, seed=3)
+    keep = torch.randint(1, N + 1, (Bn,), generator=torch.Generator().manual_seed(4)).int()
+    scale = torch.rand(Bn, generator=torch.Generator().manual_seed(5)) + 0.5
+    resid = rnd(M, N, seed=6)
+    for variant in ("plain", "resid", "gelu"):
+        out_dtype = torch.float32 if variant == "resid" else dtype
+        out = torch.zeros(M, N, dtype=out_dtype)
+        kw = dict(M=M, N=N, K=K_, lda=K_, ldb=K_, ldc=N, bias=bias, rows_in=rows_in, keep_n=keep if rows_in else None)
+        if variant == "resid":
+            kw.update(scale=scale if rows_in else None, resid=resid)
+        out2 = None
+        if variant == "gelu":
+            out2 = torch.zeros(M, N, dtype=out_dtype)
+            kw.update(act=1, out2=out2)
+        to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+        ref = E.gemm(a, b, out.clone(), **{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+        kw_d = {k: to(v) for k, v in kw.items()}
+        real = K.gemm(a.to(DEV), b.to(DEV), out.to(DEV), **kw_d)
+        torch.cuda.synchronize()
+        assert relerr(real, ref) < tol(dtype), (variant, relerr(real, ref))
+        if variant == "gelu":
+            ref2 = torch.zeros(M, N, dtype=out_dtype)
+            kw2 = dict(kw); kw2["out2"] = ref2
+            E.gemm(a, b, out.clone(), **kw2)
+            assert relerr(kw_d["out2"], ref2) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_rowmaps_and_pos(dtype):
+    B, P, C, Kd = 3, 16, 64, 592
+    N = P + 1
+    a = rnd(B * P, Kd, seed=1).to(dtype)
+    w = rnd(C, Kd, seed=2, scale=Kd ** -0.5).to(dtype)
+    bias, pos = rnd(C, seed=3), rnd(P, C, seed=4)
+    keep = torch.tensor([64, 40, 17], dtype=torch.int32)
+    out = rnd(B, N, C, seed=9)
+    kw = dict(M=B * P, N=C, K=Kd, lda=Kd, ldb=Kd, ldc=C, bias=bias, pos=pos, keep_n=keep, rows_in=P, c_map=(P, N, 1))
+    ref = E.gemm(a, w, out.clone(), **kw)
+    real = K.gemm(a.to(DEV), w.to(DEV), out.to(DEV), **{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+    assert relerr(real, ref) < tol(dtype)
+    # a_map on the input rows (token 0 of every sample)
+    y = rnd(B, N, C, seed=5).to(dtype)
+    w2 = rnd(24, C, seed=6, scale=0.1).to(dtype)
+    out = torch.zeros(B, 24)
+    kw = dict(M=B, N=24, K=C, lda=C, ldb=C, ldc=24, a_map=(1, N, 0))
+    ref = E.gemm(y, w2, out.clone(), **kw)
+    real = K.gemm(y.to(DEV), w2.to(DEV), out.to(DEV), **kw)
+    assert relerr(real, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K_", [(257 * 2, 192, 576), (65 * 4, 1536, 384), (34, 96, 10)])
+def test_gemm_dgrad(dtype, M, N, K_):
+    """dx[M,N] = dy[M,K_] @ W[K_,N] (b_trans), with gelu' and keep masks."""
+    ldk = (K_ + 7) // 8 * 8
+    dy = torch.zeros(M, ldk, dtype=dtype)
+    dy[:, :K_] = rnd(M, K_, seed=1).to(dtype)
+    w = rnd(K_, N, seed=2, scale=K_ ** -0.5).to(dtype)
+    u = rnd(M, N, seed=3).to(dtype)
+    rows_in = M // 2
+    keep = torch.tensor([N, max(N // 2 - 3, 1)], dtype=torch.int32)
+    for use_u in (False, True):
+        out = torch.zeros(M, N, dtype=dtype)
+        kw = dict(M=M, N=N, K=K_, lda=ldk, ldb=N, ldc=N, b_trans=True, keep_n=keep, rows_in=rows_in)
+        if use_u:
+            kw.update(dact_u=u, ldu=N)
+        ref = E.gemm(dy, w, out.clone(), **kw)
+        real = K.gemm(dy.to(DEV), w.to(DEV), out.to(DEV), **{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+        assert relerr(real, ref) < tol(dtype), (use_u, relerr(real, ref))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T,No,Ki,split", [(257 * 4, 576, 192, 2), (2176, 768, 3072, 4), (1300, 10, 96, 3), (40, 64, 592, 1)])
+def test_gemm_wgrad(dtype, T, No, Ki, split):
+    """dW[No,Ki] += dy[T,No]^T x[T,Ki]  (both contraction-major, split-K atomics)."""
+    dy = rnd(T, No, seed=1).to(dtype)
+    x = rnd(T, Ki, seed=2).to(dtype)
+    out = rnd(No, Ki, seed=3)
+    kw = dict(M=No, N=Ki, K=T, lda=No, ldb=Ki, ldc=Ki, a_trans=True, b_trans=True, atomic=True, split_k=split)
+    ref = E.gemm(dy, x, out.clone(), **kw)
+    real = K.gemm(dy.to(DEV), x.to(DEV), out.to(DEV), **kw)
+    t = 5e-5 if dtype == torch.float32 else 1.2e-2
+    assert relerr(real, ref) < t, relerr(real, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_wgrad_rowmaps(dtype):
+    B, No_, Ni, Co, C = 6, 5, 17, 64, 32
+    gt = rnd(B, No_, Co, seed=1).to(dtype)
+    y = rnd(B, Ni, C, seed=2).to(dtype)
+    out = torch.zeros(Co, C)
+    kw = dict(M=Co, N=C, K=B, lda=Co, ldb=C, ldc=C, a_trans=True, b_trans=True, atomic=True, split_k=1,
+              a_map=(1, No_, 0), b_map=(1, Ni, 0))
+    ref = E.gemm(gt, y, out.clone(), **kw)
+    real = K.gemm(gt.to(DEV), y.to(DEV), out.to(DEV), **kw)
+    assert relerr(real, ref) < tol(dtype)
+    col = rnd(B * 4, 9 * C, seed=3).to(dtype)
+    out = torch.zeros(Co, 9 * C)
+    kw = dict(M=Co, N=9 * C, K=B * 4, lda=Co, ldb=9 * C, ldc=9 * C, a_trans=True, b_trans=True, atomic=True,
+              split_k=2, a_map=(4, No_, 1))
+    ref = E.gemm(gt, col, out.clone(), **kw)
+    real = K.gemm(gt.to(DEV), col.to(DEV), out.to(DEV), **kw)
+    assert relerr(real, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [32, 192, 320, 1280])
+@pytest.mark.parametrize("masked", [False, True])
+def test_layernorm_fwd_bwd(out_dtype, C, masked):
+    B, N = 5, 17
+    keep = torch.tensor([C, C // 2, C - 4, 8, C], dtype=torch.int32) if masked else None
+    x = rnd(B, N, C, seed=1) + 0.3
+    if masked:
+        x = x * (torch.arange(C)[None, None, :] < keep.long()[:, None, None])
+    w, b = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    (y, mean, rstd), (yr, meanr, rstdr) = both("ln_fwd", (x, w, b, keep, N, 1e-6, out_dtype))
+    assert relerr(y, yr) < tol(out_dtype)
+    assert relerr(mean, meanr) < 1e-5 and relerr(rstd, rstdr) < 1e-5
+    dy = rnd(B, N, C, seed=4).to(out_dtype)
+    gin = rnd(B, N, C, seed=5)
+    dwr, dbr = torch.zeros(C), torch.zeros(C)
+    dxr = E.ln_bwd(dy, x, w, meanr, rstdr, keep, N, gin, dwr, dbr)
+    dw, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = K.ln_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, None if keep is None else keep.to(DEV), N, gin.to(DEV), dw, db)
+    assert relerr(dx, dxr) < 3e-5
+    assert relerr(dw, dwr) < 3e-5 and relerr(db, dbr) < 3e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,H,D", [(17, 2, 64), (65, 3, 48), (257, 2, 32), (257, 3, 64), (5, 2, 48), (2, 2, 64)])
+def test_attention_fwd_bwd(dtype, N, H, D):
+    B = 3
+    qkv = rnd(B, N, 3 * H * D, seed=1).to(dtype)
+    keep = torch.tensor([H * D, D, H * D], dtype=torch.int32)
+    scale = D ** -0.5
+    (o, lse), (orf, lser) = both("attn_fwd", (qkv, keep, B, N, H, D, scale))
+    t = 3e-5 if dtype == torch.float32 else 1.5e-2
+    assert relerr(o, orf) < t
+    assert relerr(lse, lser) < 1e-4
+    d_o = rnd(B, N, H * D, seed=2).to(dtype)
+    dq = K.attn_bwd(qkv.to(DEV), o, d_o.to(DEV), lse, keep.to(DEV), B, N, H, D, scale)
+    dqr = E.attn_bwd(qkv, orf, d_o, lser, keep, B, N, H, D, scale)
+    assert relerr(dq, dqr) < (1e-4 if dtype == torch.float32 else 2.5e-2), relerr(dq, dqr)
+
+
+def test_softce():
+    for R, Kc in ((8, 10), (128 * 16, 1000)):
+        x = rnd(R, Kc, seed=1) * 3
+        t = torch.softmax(rnd(R, Kc, seed=2), -1)
+        (l, d), (lr, dr) = both("softce", (x, t, 1.0 / R))
+        assert relerr(l, lr) < 1e-5 and relerr(d, dr) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_small_kernels(dtype):
+    B, N, C = 4, 17, 96
+    x = rnd(B, N, C, seed=1)
+    keep = torch.tensor([96, 40, 8, 77], dtype=torch.int32)
+    scale = torch.tensor([1.25, 0.0, 1.25, 1.0])
+    r, e = both("scale_mask_cast", (x, scale, keep, N, dtype))
+    assert relerr(r, e) < tol(dtype)
+    xt = x.to(dtype)
+    out = torch.zeros(C)
+    ref = E.colsum(xt, out.clone(), B * (N - 1), C, C, (N - 1, N, 1))
+    real = K.colsum(xt.to(DEV), out.to(DEV), B * (N - 1), C, C, (N - 1, N, 1))
+    assert relerr(real, ref) < 1e-4
+    ref = E.batchsum(x, torch.zeros(N, C))
+    real = K.batchsum(x.to(DEV), torch.zeros(N, C, device=DEV))
+    assert relerr(real, ref) < 1e-5
+    img = rnd(2, 3, 56, 56, seed=3)
+    ldk = 592 if dtype == torch.bfloat16 else 588
+    r, e = both("im2col_patch", (img, 14, ldk, dtype))
+    assert relerr(r, e) < tol(dtype) and r.shape == e.shape
+    tokens, pos = rnd(1, 1, C, seed=4), rnd(1, N, C, seed=5)
+    r, e = both("embed_cls", (tokens, pos, x.clone(), keep))
+    assert relerr(r, e) < 1e-6
+    r, e = both("mask_rows", (x.clone(), keep, N))
+    assert relerr(r, e) < 1e-6
+    # spatial-reduction helpers (grid 4 -> 2)
+    g = 4
+    y = rnd(B, 1 + g * g, C, seed=6).to(dtype)
+    r, e = both("sr_im2col", (y, B, g, C))
+    assert relerr(r, e) < 1e-6
+    dcol = rnd(B * 4, 9 * C, seed=7).to(dtype)
+    dyr = torch.zeros(B, 1 + g * g, C, dtype=dtype)
+    E.sr_col2im(dcol, dyr, B, g, C)
+    dy = torch.zeros(B, 1 + g * g, C, dtype=dtype, device=DEV)
+    K.sr_col2im(dcol.to(DEV), dy, B, g, C)
+    assert relerr(dy[:, 1:], dyr[:, 1:]) < tol(dtype)
+    xs = rnd(B, 1 + g * g, 64, seed=8)
+    r, e = both("sr_resid", (xs, B, g, 64, C))
+    assert relerr(r, e) < 1e-6
+    do = rnd(B, 5, C, seed=9)
+    r, e = both("sr_resid_bwd", (do, B, g, 64, C))
+    assert relerr(r, e) < 1e-6
+    src = rnd(1000, seed=10)
+    dst = torch.empty(1000, dtype=torch.bfloat16, device=DEV)
+    K.cast_bf16(src.to(DEV), dst)
+    assert torch.equal(dst.cpu(), src.to(torch.bfloat16))

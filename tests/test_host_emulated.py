@@ -1,0 +1,101 @@
+"""Host-side orchestration of the product model (plan sampling, tape, gradient routing) checked on CPU by
+swapping the HIP kernels for tests/emu_kernels.py.  The real kernels are checked on the GPU (tests/test_gpu_*.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import emu_kernels
+import recipe
+import vitres
+import vitres_oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def build_pair(et, mode, seed):
+    nd = recipe.MICRO_DEFS[et]
+    sup = mode != "plain"
+    kw = {}
+    if sup:
+        kw = dict(num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30,
+                  single_arch=(mode == "single"), hybrid_arch=(mode == "hybrid"))
+    name = "flexible_vit_sr_patch14_224_patch_output" + ("_supernet" if sup else "")
+    prod = vitres.create_model(name, img_size=recipe.MICRO_IMG, num_classes=recipe.MICRO_CLASSES, network_def=nd,
+                               drop_path_rate=0.0, drop_block_rate=None, **kw)
+    orc = O.OracleViTSR(nd, img_size=recipe.MICRO_IMG, num_classes=recipe.MICRO_CLASSES, supernet=sup,
+                        patch_output=True, **kw)
+    shapes = [(k, tuple(v.shape)) for k, v in orc.state_dict().items()]
+    assert shapes == [(k, tuple(v.shape)) for k, v in prod.state_dict().items()]
+    sd = recipe.fill_state_dict(shapes, seed)
+    prod.load_state_dict(sd)
+    orc.load_state_dict(sd)
+    return prod, orc, sd
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-6))
+
+
+@pytest.mark.parametrize("et,mode", [(0, "plain"), (0, "multi"), (0, "single"), (0, "hybrid")])
+def test_emulated_model_matches_oracle_and_golden(monkeypatch, et, mode):
+    emu_kernels.install(monkeypatch)
+    g = np.load(os.path.join(G, "f1_micro_t%d_%s.npz" % (et, mode)))
+    prod, orc, sd = build_pair(et, mode, 100 + et)
+    prod.set_compute_dtype(torch.float32)
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    for e in ([31] if mode == "plain" else [0, 15, 31]):
+        prod.train(); orc.train()
+        if mode != "plain":
+            prod.set_epoch(e); orc.set_epoch(e)
+            prod.load_state_dict(sd); orc.load_state_dict(sd)
+        prod.zero_grad(); orc.zero_grad()
+        torch.manual_seed(555 + e)
+        rng = torch.random.get_rng_state()
+        if mode in ("single", "hybrid"):
+            torch.manual_seed(e * 10000 + 3)
+        cls, pat = prod(x, patch_output_type="seq")
+        torch.random.set_rng_state(rng)
+        tag = "e%d." % e
+        if mode != "plain":
+            keeps = torch.stack(prod.last_keeps).numpy()
+            assert np.array_equal(keeps, g[tag + "keeps"])          # bit-exact masks vs the reference
+        assert rel(cls.detach(), torch.from_numpy(g[tag + "cls"])) < 5e-5
+        assert rel(pat.detach(), torch.from_numpy(g[tag + "pat"])) < 5e-5
+        loss = O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)
+        loss.backward()
+        ocls, opat = orc(x, keeps=prod.last_keeps if mode != "plain" else None, patch_output_type="seq")
+        (O.soft_target_ce(ocls, t) + O.soft_target_ce(opat, pt)).backward()
+        op = dict(orc.named_parameters())
+        for n, p in prod.named_parameters():
+            assert p.grad is not None, n
+            assert rel(p.grad, op[n].grad) < 2e-4, (n, rel(p.grad, op[n].grad))
+    prod.eval()
+    prod.load_state_dict(sd)
+    with torch.no_grad():
+        out = prod(x)
+    assert rel(out, torch.from_numpy(g["eval.cls"])) < 5e-5
+
+
+def test_emulated_second_backward_accumulates(monkeypatch):
+    emu_kernels.install(monkeypatch)
+    prod, orc, sd = build_pair(0, "plain", 100)
+    prod.set_compute_dtype(torch.float32)
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    prod.train()
+    for _ in range(2):
+        cls, pat = prod(x)
+        (O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)).backward()
+    g2 = prod.cls_head.weight.grad.clone()
+    prod.zero_grad()
+    cls, pat = prod(x)
+    (O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)).backward()
+    assert rel(g2, 2 * prod.cls_head.weight.grad) < 1e-5
+
+
+def test_cpu_tensor_is_refused():
+    prod, _, _ = build_pair(0, "plain", 100)
+    with pytest.raises(RuntimeError):
+        prod(torch.zeros(2, 3, 56, 56))

@@ -1,0 +1,80 @@
+// Common device helpers for the vitres HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VR_F32 0
+#define VR_BF16 1
+
+#define VR_OK 0
+#define VR_EINVAL (-1)
+#define VR_EALIGN (-2)
+#define VR_EUNSUPPORTED (-3)
+
+#define VR_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        hipError_t _e = hipGetLastError();                  \
+        if (_e != hipSuccess) return (int)_e;               \
+    } while (0)
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even, NaN-preserving (same rounding as torch's .bfloat16())
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int dtype = VR_F32;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int dtype = VR_BF16;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact (erf) GELU and its derivative, as nn.GELU() default (reference nets/supernet_blocks.py:18)
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float u) {
+    const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * u * u);
+    return cdf + u * pdf;
+}
+
+// token-row remap:  row(m) = (m / rpi) * rps + off + (m % rpi) ; rpi == 0 -> identity
+struct RowMap {
+    int rpi, rps, off;
+};
+__device__ __forceinline__ long long map_row(const RowMap& r, int m) {
+    if (r.rpi == 0) return m;
+    const int s = m / r.rpi;
+    return (long long)s * r.rps + r.off + (m - s * r.rpi);
+}

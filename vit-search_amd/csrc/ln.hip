@@ -1,0 +1,236 @@
+// Masked LayerNorm forward / backward for gfx950 (reference nets/masked_layer_norm.py:23-50,55-88,113-125).
+// One wave64 per token row, float4 loads, shuffle reductions; HBM-bound by design (one read of x, one
+// write of y; backward: read dy,x once, write dx once).  The prefix mask of each sample is an int keep
+// count: statistics and outputs use only channels c < keep (channels beyond are exactly zero upstream).
+#include "common.h"
+#include "../../include/vitres_hip.h"
+
+namespace {
+
+constexpr int MAXV_LIMIT = 8;  // float4 per lane -> C <= 2048 (kernels are templated on the actual count)
+
+template <typename TO, int MAXV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, TO* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     const int* __restrict__ keep, int M, int C, int rps, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int kc = keep ? keep[m / rps] : C;
+    const float* xr = x + (long long)m * C;
+    float4 v[MAXV];
+    float s = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) {
+            v[j] = *reinterpret_cast<const float4*>(xr + c);
+            if (c + 0 >= kc) v[j].x = 0.f;
+            if (c + 1 >= kc) v[j].y = 0.f;
+            if (c + 2 >= kc) v[j].z = 0.f;
+            if (c + 3 >= kc) v[j].w = 0.f;
+            s += v[j].x + v[j].y + v[j].z + v[j].w;
+            s2 += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        }
+    }
+    s = wave_sum(s);
+    const float inv_n = kc > 0 ? 1.0f / (float)kc : 0.f;
+    const float mu = s * inv_n;
+    float var;
+    if (keep) {
+        // masked path: var = E[x^2]/p - mu^2  (masked_layer_norm.py:38-40)
+        s2 = wave_sum(s2);
+        var = s2 * inv_n - mu * mu;
+    } else {
+        // plain F.layer_norm path (:118-122): two-pass variance
+        float d2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < C) {
+                const float a = v[j].x - mu, bb = v[j].y - mu, cc = v[j].z - mu, dd = v[j].w - mu;
+                d2 += a * a + bb * bb + cc * cc + dd * dd;
+            }
+        }
+        var = wave_sum(d2) * inv_n;
+    }
+    const float rs = 1.0f / sqrtf(var + eps);
+    if (lane == 0) {
+        mean[m] = mu;
+        rstd[m] = rs;
+    }
+    TO* yr = y + (long long)m * C;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = (lane + 64 * j) * 4;
+        if (c < C) {
+            const float4 ww = *reinterpret_cast<const float4*>(w + c);
+            const float4 bb = *reinterpret_cast<const float4*>(b + c);
+            float o0 = (c + 0 < kc) ? ww.x * ((v[j].x - mu) * rs) + bb.x : 0.f;
+            float o1 = (c + 1 < kc) ? ww.y * ((v[j].y - mu) * rs) + bb.y : 0.f;
+            float o2 = (c + 2 < kc) ? ww.z * ((v[j].z - mu) * rs) + bb.z : 0.f;
+            float o3 = (c + 3 < kc) ? ww.w * ((v[j].w - mu) * rs) + bb.w : 0.f;
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<float4*>(yr + c) = make_float4(o0, o1, o2, o3);
+            } else {
+                *reinterpret_cast<uint2*>(yr + c) = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
+            }
+        }
+    }
+}
+
+template <typename TI> __device__ __forceinline__ float4 load4(const TI* p);
+template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+constexpr int BWD_ROWS = 32;  // rows per workgroup (8 per wave)
+
+template <typename TI, int MAXV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TI* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const int* __restrict__ keep,
+                                                     const float* __restrict__ dx_in, float* __restrict__ dx_out,
+                                                     float* __restrict__ dw, float* __restrict__ db, int M, int C, int rps) {
+    __shared__ float red[2][4][64 * 4];  // [dw|db][wave][lane*4+e], reused per j
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 gw[MAXV], gb[MAXV], ww[MAXV];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        gw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = (lane + 64 * j) * 4;
+        ww[j] = (c < C) ? *reinterpret_cast<const float4*>(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int mbeg = blockIdx.x * BWD_ROWS;
+    for (int rr = wave; rr < BWD_ROWS; rr += 4) {
+        const int m = mbeg + rr;
+        if (m >= M) break;
+        const int kc = keep ? keep[m / rps] : C;
+        const float mu = mean[m], rs = rstd[m];
+        const float inv_n = kc > 0 ? 1.0f / (float)kc : 0.f;
+        float4 g[MAXV], z[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            z[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C) {
+                float4 gv = load4<TI>(dy + (long long)m * C + c);
+                float4 xv = *reinterpret_cast<const float4*>(x + (long long)m * C + c);
+                if (c + 0 >= kc) { gv.x = 0.f; xv.x = mu; }
+                if (c + 1 >= kc) { gv.y = 0.f; xv.y = mu; }
+                if (c + 2 >= kc) { gv.z = 0.f; xv.z = mu; }
+                if (c + 3 >= kc) { gv.w = 0.f; xv.w = mu; }
+                z[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                gw[j].x += gv.x * z[j].x; gw[j].y += gv.y * z[j].y; gw[j].z += gv.z * z[j].z; gw[j].w += gv.w * z[j].w;
+                gb[j].x += gv.x; gb[j].y += gv.y; gb[j].z += gv.z; gb[j].w += gv.w;
+                g[j] = make_float4(gv.x * ww[j].x, gv.y * ww[j].y, gv.z * ww[j].z, gv.w * ww[j].w);  // dz
+                s1 += g[j].x + g[j].y + g[j].z + g[j].w;
+                s2 += g[j].x * z[j].x + g[j].y * z[j].y + g[j].z * z[j].z + g[j].w * z[j].w;
+            }
+        }
+        s1 = wave_sum(s1) * inv_n;
+        s2 = wave_sum(s2) * inv_n;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < C) {
+                // channels >= keep get exactly 0 (also for the pass-through residual gradient): the reference lets
+                // garbage flow there until the stage's `x * mask` kills it (nets/channel_drop.py:82); same param grads.
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dx_in) r = *reinterpret_cast<const float4*>(dx_in + (long long)m * C + c);
+                float4 o;
+                o.x = (c + 0 < kc) ? (g[j].x - (s1 + z[j].x * s2)) * rs + r.x : 0.f;
+                o.y = (c + 1 < kc) ? (g[j].y - (s1 + z[j].y * s2)) * rs + r.y : 0.f;
+                o.z = (c + 2 < kc) ? (g[j].z - (s1 + z[j].z * s2)) * rs + r.z : 0.f;
+                o.w = (c + 3 < kc) ? (g[j].w - (s1 + z[j].w * s2)) * rs + r.w : 0.f;
+                *reinterpret_cast<float4*>(dx_out + (long long)m * C + c) = o;
+            }
+        }
+    }
+    // cross-wave reduction of dgamma / dbeta, one float4 column group at a time
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        if (64 * 4 * j >= C) break;
+        __syncthreads();
+        *reinterpret_cast<float4*>(&red[0][wave][lane * 4]) = gw[j];
+        *reinterpret_cast<float4*>(&red[1][wave][lane * 4]) = gb[j];
+        __syncthreads();
+        // 256 threads: thread t handles element t of the 256-wide group, for dw; same for db
+        const int e = threadIdx.x;
+        const int c = 64 * 4 * j + e;
+        if (c < C) {
+            const float a = red[0][0][e] + red[0][1][e] + red[0][2][e] + red[0][3][e];
+            const float bsum = red[1][0][e] + red[1][1][e] + red[1][2][e] + red[1][3][e];
+            atomicAdd(dw + c, a);
+            atomicAdd(db + c, bsum);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vr_ln_fwd(const float* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                         const int32_t* keep, int32_t M, int32_t C, int32_t rows_per_sample, float eps,
+                         int32_t out_dtype, vr_stream_t stream) {
+    if (!x || !w || !b || !y || !mean || !rstd || M <= 0 || C <= 0) return VR_EINVAL;
+    if (C % 4 || C > 64 * 4 * MAXV_LIMIT) return VR_EUNSUPPORTED;
+    if (out_dtype != VR_F32 && out_dtype != VR_BF16) return VR_EUNSUPPORTED;
+    if (rows_per_sample <= 0) rows_per_sample = M;
+    dim3 grid((M + 3) / 4);
+    const int nv = (C + 255) / 256;
+#define VR_LN_FWD(NV)                                                                                                  \
+    if (out_dtype == VR_F32)                                                                                           \
+        hipLaunchKernelGGL((ln_fwd_kernel<float, NV>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, (float*)y, mean, \
+                           rstd, keep, M, C, rows_per_sample, eps);                                                    \
+    else                                                                                                               \
+        hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NV>), grid, dim3(256), 0, (hipStream_t)stream, x, w, b, (bf16_t*)y,  \
+                           mean, rstd, keep, M, C, rows_per_sample, eps);
+    switch (nv) {
+        case 1: VR_LN_FWD(1) break;
+        case 2: VR_LN_FWD(2) break;
+        case 3: VR_LN_FWD(3) break;
+        case 4: VR_LN_FWD(4) break;
+        case 5: VR_LN_FWD(5) break;
+        default: VR_LN_FWD(8) break;
+    }
+#undef VR_LN_FWD
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_ln_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                         const int32_t* keep, const float* dx_in, float* dx_out, float* dw, float* db, int32_t M,
+                         int32_t C, int32_t rows_per_sample, int32_t dy_dtype, vr_stream_t stream) {
+    if (!dy || !x || !w || !mean || !rstd || !dx_out || !dw || !db || M <= 0 || C <= 0) return VR_EINVAL;
+    if (C % 4 || C > 64 * 4 * MAXV_LIMIT) return VR_EUNSUPPORTED;
+    if (dy_dtype != VR_F32 && dy_dtype != VR_BF16) return VR_EUNSUPPORTED;
+    if (rows_per_sample <= 0) rows_per_sample = M;
+    dim3 grid((M + BWD_ROWS - 1) / BWD_ROWS);
+    const int nv = (C + 255) / 256;
+#define VR_LN_BWD(NV)                                                                                                  \
+    if (dy_dtype == VR_F32)                                                                                            \
+        hipLaunchKernelGGL((ln_bwd_kernel<float, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, x, w, \
+                           mean, rstd, keep, dx_in, dx_out, dw, db, M, C, rows_per_sample);                            \
+    else                                                                                                               \
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, \
+                           w, mean, rstd, keep, dx_in, dx_out, dw, db, M, C, rows_per_sample);
+    switch (nv) {
+        case 1: VR_LN_BWD(1) break;
+        case 2: VR_LN_BWD(2) break;
+        case 3: VR_LN_BWD(3) break;
+        case 4: VR_LN_BWD(4) break;
+        case 5: VR_LN_BWD(5) break;
+        default: VR_LN_BWD(8) break;
+    }
+#undef VR_LN_BWD
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}

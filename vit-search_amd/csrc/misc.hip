@@ -1,0 +1,353 @@
+// Small HBM-bound kernels around the GEMMs of the ViT-Res hot path (gfx950).
+// Every kernel streams its operands once with 16-byte accesses where the layout allows.
+#include "common.h"
+#include "../../include/vitres_hip.h"
+
+namespace {
+
+// ---- fp32 -> bf16 ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x * 8;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 8 <= n) {
+            const float4 a = *reinterpret_cast<const float4*>(src + i);
+            const float4 b = *reinterpret_cast<const float4*>(src + i + 4);
+            *reinterpret_cast<uint4*>(dst + i) =
+                make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w));
+        } else {
+            for (long long j = i; j < n; ++j) dst[j] = f2bf(src[j]);
+        }
+    }
+}
+
+// ---- soft-target cross entropy: wave per row -----------------------------------------------------------
+__global__ __launch_bounds__(256) void softce_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                     float* __restrict__ loss, float* __restrict__ dx, int R, int K,
+                                                     float gscale) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* xr = x + (long long)r * K;
+    const float* tr = t + (long long)r * K;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, xr[k]);
+    mx = wave_max(mx);
+    float se = 0.f, st = 0.f, stx = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float xv = xr[k], tv = tr[k];
+        se += __expf(xv - mx);
+        st += tv;
+        stx += tv * xv;
+    }
+    se = wave_sum(se);
+    st = wave_sum(st);
+    stx = wave_sum(stx);
+    const float lse = mx + __logf(se);
+    if (lane == 0) loss[r] = lse * st - stx;
+    if (dx) {
+        float* dr = dx + (long long)r * K;
+        const float inv = 1.0f / se;
+        for (int k = lane; k < K; k += 64) dr[k] = gscale * (__expf(xr[k] - mx) * inv * st - tr[k]);
+    }
+}
+
+// ---- column sums (bias gradients) ----------------------------------------------------------------------
+// grid.x over column groups of 256, grid.y over row chunks; thread = one column; atomics at the end.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, float* __restrict__ out, int M, int N,
+                                                     int ld, int rows_per_block, RowMap rm) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int mb = blockIdx.y * rows_per_block;
+    const int me = min(M, mb + rows_per_block);
+    float s = 0.f;
+    for (int m = mb; m < me; ++m) s += Elem<T>::ld(in + map_row(rm, m) * (long long)ld + n);
+    atomicAdd(out + n, s);
+}
+
+// out[m,c] = T(in[m,c] * scale[s]) for c < keep[s], else 0   (gradient entering a masked / drop-path'd branch)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_mask_cast_kernel(const float* __restrict__ in, T* __restrict__ out,
+                                                              const float* __restrict__ scale, const int* __restrict__ keep,
+                                                              int M, int C, int rps) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int s = m / rps;
+    const float sc = scale ? scale[s] : 1.0f;
+    const int kc = keep ? keep[s] : C;
+    const float* src = in + (long long)m * C;
+    T* dst = out + (long long)m * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(src + c);
+        v.x = (c + 0 < kc) ? v.x * sc : 0.f;
+        v.y = (c + 1 < kc) ? v.y * sc : 0.f;
+        v.z = (c + 2 < kc) ? v.z * sc : 0.f;
+        v.w = (c + 3 < kc) ? v.w * sc : 0.f;
+        if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(dst + c) = v;
+        else *reinterpret_cast<uint2*>(dst + c) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    }
+}
+
+__global__ __launch_bounds__(256) void batchsum_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                       long long inner) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= inner) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += in[(long long)b * inner + i];
+    out[i] = s;
+}
+
+// ---- timm PatchEmbed im2col: col[(b,py,px)][(c,i,j)] = img[b,c,py*P+i,px*P+j] ---------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img, T* __restrict__ col, int B,
+                                                           int Cin, int H, int W, int P, int ldk) {
+    const int gw = W / P, gh = H / P;
+    const int row = blockIdx.x;  // (b, py, px)
+    const int px = row % gw, py = (row / gw) % gh, b = row / (gw * gh);
+    const int K = Cin * P * P;
+    T* out = col + (long long)row * ldk;
+    for (int k = threadIdx.x; k < ldk; k += blockDim.x) {
+        float v = 0.f;
+        if (k < K) {
+            const int j = k % P, i = (k / P) % P, c = k / (P * P);
+            v = img[(((long long)b * Cin + c) * H + py * P + i) * W + px * P + j];
+        }
+        Elem<T>::st(out + k, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_cls_kernel(const float* __restrict__ tokens, const float* __restrict__ pos,
+                                                        float* __restrict__ x, const int* __restrict__ keep, int B, int N,
+                                                        int C) {
+    const int b = blockIdx.x;
+    const int kc = keep ? keep[b] : C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+        x[(long long)b * N * C + c] = (c < kc) ? tokens[c] + pos[c] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, const int* __restrict__ keep, int M, int C,
+                                                        int rps) {
+    const int m = blockIdx.x;
+    const int kc = keep[m / rps];
+    for (int c = kc + threadIdx.x; c < C; c += blockDim.x) x[(long long)m * C + c] = 0.f;
+}
+
+// ---- spatial-reduction block pieces (3x3 stride 2 pad 1 conv as GEMM; 2x2 avg-pool residual) ------------
+// col[(b,oh,ow)][(kh,kw,c)] = y[b, 1 + (2oh-1+kh)*g + (2ow-1+kw), c]  (0 outside)
+template <typename T>
+__global__ __launch_bounds__(256) void sr_im2col_kernel(const T* __restrict__ y, T* __restrict__ col, int B, int g, int C) {
+    const int go = g / 2;
+    const int row = blockIdx.x;  // (b, oh, ow)
+    const int tap = blockIdx.y;  // kh*3+kw
+    const int ow = row % go, oh = (row / go) % go, b = row / (go * go);
+    const int ih = 2 * oh - 1 + tap / 3, iw = 2 * ow - 1 + tap % 3;
+    const bool in = ih >= 0 && ih < g && iw >= 0 && iw < g;
+    const T* src = y + ((long long)b * (1 + g * g) + 1 + ih * g + iw) * C;
+    T* dst = col + (long long)row * 9 * C + tap * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) dst[c] = in ? src[c] : (T)0;
+}
+
+// dy[b,1+ih*g+iw,c] = sum over taps (kh,kw) with 2oh-1+kh==ih, 2ow-1+kw==iw of dcol[(b,oh,ow)][(kh,kw,c)]
+template <typename T>
+__global__ __launch_bounds__(256) void sr_col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dy, int B, int g, int C) {
+    const int go = g / 2;
+    const int pix = blockIdx.x;  // (b, ih, iw)
+    const int iw = pix % g, ih = (pix / g) % g, b = pix / (g * g);
+    T* dst = dy + ((long long)b * (1 + g * g) + 1 + ih * g + iw) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = ih + 1 - kh;
+            if (t < 0 || (t & 1)) continue;
+            const int oh = t >> 1;
+            if (oh >= go) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int u = iw + 1 - kw;
+                if (u < 0 || (u & 1)) continue;
+                const int ow = u >> 1;
+                if (ow >= go) continue;
+                s += Elem<T>::ld(dcol + ((long long)(b * go + oh) * go + ow) * 9 * C + (kh * 3 + kw) * C + c);
+            }
+        }
+        Elem<T>::st(dst + c, s);
+    }
+}
+
+// out[b,0,:] = pad(x[b,0,:]); out[b,1+(oh,ow),:] = pad(mean of the 2x2 patch rows)
+__global__ __launch_bounds__(256) void sr_resid_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int g,
+                                                       int Cin, int Cout) {
+    const int go = g / 2, No = 1 + go * go, Ni = 1 + g * g;
+    const int row = blockIdx.x;  // b*No + r
+    const int r = row % No, b = row / No;
+    float* dst = out + (long long)row * Cout;
+    const float* xb = x + (long long)b * Ni * Cin;
+    if (r == 0) {
+        for (int c = threadIdx.x; c < Cout; c += blockDim.x) dst[c] = c < Cin ? xb[c] : 0.f;
+        return;
+    }
+    const int ow = (r - 1) % go, oh = (r - 1) / go;
+    const float* p00 = xb + (long long)(1 + (2 * oh) * g + 2 * ow) * Cin;
+    const float* p01 = p00 + Cin;
+    const float* p10 = p00 + (long long)g * Cin;
+    const float* p11 = p10 + Cin;
+    for (int c = threadIdx.x; c < Cout; c += blockDim.x)
+        dst[c] = c < Cin ? 0.25f * (p00[c] + p01[c] + p10[c] + p11[c]) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void sr_resid_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int B,
+                                                           int g, int Cin, int Cout, int accumulate) {
+    const int go = g / 2, No = 1 + go * go, Ni = 1 + g * g;
+    const int row = blockIdx.x;  // b*Ni + r  (input rows)
+    const int r = row % Ni, b = row / Ni;
+    float* dst = dx + (long long)row * Cin;
+    const float* src;
+    float f;
+    if (r == 0) {
+        src = dout + (long long)b * No * Cout;
+        f = 1.0f;
+    } else {
+        const int iw = (r - 1) % g, ih = (r - 1) / g;
+        src = dout + ((long long)b * No + 1 + (ih / 2) * go + iw / 2) * Cout;
+        f = 0.25f;
+    }
+    for (int c = threadIdx.x; c < Cin; c += blockDim.x) {
+        const float v = f * src[c];
+        dst[c] = accumulate ? dst[c] + v : v;
+    }
+}
+
+}  // namespace
+
+extern "C" int vr_version(void) { return 1000; }
+
+extern "C" int vr_cast_f32_bf16(const float* src, void* dst, int64_t n, vr_stream_t stream) {
+    if (!src || !dst || n <= 0) return VR_EINVAL;
+    if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return VR_EALIGN;
+    long long blocks = (n / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long long)n);
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_softce(const float* logits, const float* target, float* loss_rows, float* dlogits, int32_t R, int32_t K,
+                         float gscale, vr_stream_t stream) {
+    if (!logits || !target || !loss_rows || R <= 0 || K <= 0) return VR_EINVAL;
+    hipLaunchKernelGGL(softce_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, target, loss_rows,
+                       dlogits, R, K, gscale);
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_colsum(const void* in, float* out, int32_t M, int32_t N, int32_t ld, int32_t dtype, vr_rowmap map,
+                         vr_stream_t stream) {
+    if (!in || !out || M <= 0 || N <= 0) return VR_EINVAL;
+    const int rpb = 128;
+    dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
+    const RowMap rm = {map.rpi, map.rps, map.off};
+    if (dtype == VR_F32)
+        hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, out, M, N, ld, rpb, rm);
+    else if (dtype == VR_BF16)
+        hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, out, M, N, ld, rpb, rm);
+    else
+        return VR_EUNSUPPORTED;
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_scale_mask_cast(const float* in, void* out, const float* scale, const int32_t* keep, int32_t M, int32_t C,
+                                  int32_t rows_per_sample, int32_t out_dtype, vr_stream_t stream) {
+    if (!in || !out || M <= 0 || C <= 0 || C % 4) return VR_EINVAL;
+    if (rows_per_sample <= 0) rows_per_sample = M;
+    dim3 grid((M + 3) / 4);
+    if (out_dtype == VR_F32)
+        hipLaunchKernelGGL((scale_mask_cast_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, in, (float*)out, scale, keep, M, C, rows_per_sample);
+    else if (out_dtype == VR_BF16)
+        hipLaunchKernelGGL((scale_mask_cast_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, scale, keep, M, C, rows_per_sample);
+    else
+        return VR_EUNSUPPORTED;
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_batchsum(const float* in, float* out, int32_t B, int64_t inner, vr_stream_t stream) {
+    if (!in || !out || B <= 0 || inner <= 0) return VR_EINVAL;
+    hipLaunchKernelGGL(batchsum_kernel, dim3((unsigned)((inner + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, B,
+                       (long long)inner);
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_im2col_patch(const float* img, void* col, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t P,
+                               int32_t ldk, int32_t dtype, vr_stream_t stream) {
+    if (!img || !col || B <= 0 || P <= 0 || H % P || W % P || ldk < Cin * P * P) return VR_EINVAL;
+    dim3 grid(B * (H / P) * (W / P));
+    if (dtype == VR_F32)
+        hipLaunchKernelGGL((im2col_patch_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, img, (float*)col, B, Cin, H, W, P, ldk);
+    else if (dtype == VR_BF16)
+        hipLaunchKernelGGL((im2col_patch_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)col, B, Cin, H, W, P, ldk);
+    else
+        return VR_EUNSUPPORTED;
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_embed_cls(const float* tokens, const float* pos, float* x, const int32_t* keep, int32_t B, int32_t N,
+                            int32_t C, vr_stream_t stream) {
+    if (!tokens || !pos || !x || B <= 0) return VR_EINVAL;
+    hipLaunchKernelGGL(embed_cls_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, pos, x, keep, B, N, C);
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_mask_rows(float* x, const int32_t* keep, int32_t M, int32_t C, int32_t rows_per_sample, vr_stream_t stream) {
+    if (!x || !keep || M <= 0 || rows_per_sample <= 0) return VR_EINVAL;
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, keep, M, C, rows_per_sample);
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_sr_im2col(const void* y, void* col, int32_t B, int32_t g, int32_t C, int32_t dtype, vr_stream_t stream) {
+    if (!y || !col || B <= 0 || g <= 0 || (g & 1)) return VR_EINVAL;
+    dim3 grid(B * (g / 2) * (g / 2), 9);
+    if (dtype == VR_F32)
+        hipLaunchKernelGGL((sr_im2col_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, (float*)col, B, g, C);
+    else if (dtype == VR_BF16)
+        hipLaunchKernelGGL((sr_im2col_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (bf16_t*)col, B, g, C);
+    else
+        return VR_EUNSUPPORTED;
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_sr_col2im(const void* dcol, void* dy, int32_t B, int32_t g, int32_t C, int32_t dtype, vr_stream_t stream) {
+    if (!dcol || !dy || B <= 0 || g <= 0 || (g & 1)) return VR_EINVAL;
+    dim3 grid(B * g * g);
+    if (dtype == VR_F32)
+        hipLaunchKernelGGL((sr_col2im_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dcol, (float*)dy, B, g, C);
+    else if (dtype == VR_BF16)
+        hipLaunchKernelGGL((sr_col2im_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dcol, (bf16_t*)dy, B, g, C);
+    else
+        return VR_EUNSUPPORTED;
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_sr_resid(const float* x, float* out, int32_t B, int32_t g, int32_t Cin, int32_t Cout, vr_stream_t stream) {
+    if (!x || !out || B <= 0 || g <= 0 || (g & 1) || Cout < Cin) return VR_EINVAL;
+    hipLaunchKernelGGL(sr_resid_kernel, dim3(B * (1 + (g / 2) * (g / 2))), dim3(256), 0, (hipStream_t)stream, x, out, B, g, Cin, Cout);
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_sr_resid_bwd(const float* dout, float* dx, int32_t B, int32_t g, int32_t Cin, int32_t Cout,
+                               int32_t accumulate, vr_stream_t stream) {
+    if (!dout || !dx || B <= 0 || g <= 0 || (g & 1) || Cout < Cin) return VR_EINVAL;
+    hipLaunchKernelGGL(sr_resid_bwd_kernel, dim3(B * (1 + g * g)), dim3(256), 0, (hipStream_t)stream, dout, dx, B, g, Cin, Cout, accumulate);
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}

@@ -1,0 +1,86 @@
+"""ctypes loader for libvitres_hip.so (the C ABI declared in include/vitres_hip.h).
+
+The library is the product: there is no CPU / PyTorch fallback.  Importing this module never fails
+(so that host-side logic can be unit-tested without a GPU), but the first kernel call raises
+RuntimeError when the shared object is missing or does not export a declared symbol.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvitres_hip.so")
+
+VR_F32, VR_BF16 = 0, 1
+
+
+class RowMap(ctypes.Structure):
+    _fields_ = [("rpi", c_int32), ("rps", c_int32), ("off", c_int32)]
+
+
+class GemmArgs(ctypes.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p),
+        ("bias", c_void_p), ("pos", c_void_p), ("scale", c_void_p), ("keep_n", c_void_p),
+        ("resid", c_void_p), ("dact_u", c_void_p),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldu", c_int32),
+        ("a_trans", c_int32), ("b_trans", c_int32),
+        ("in_dtype", c_int32), ("out_dtype", c_int32),
+        ("act", c_int32), ("atomic", c_int32), ("split_k", c_int32), ("rows_in", c_int32),
+        ("a_map", RowMap), ("b_map", RowMap), ("c_map", RowMap),
+    ]
+
+
+# name -> argtypes ; every entry point returns int.  Must list every symbol of include/vitres_hip.h
+SYMBOLS = {
+    "vr_version": [],
+    "vr_gemm": [ctypes.POINTER(GemmArgs), c_void_p],
+    "vr_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
+    "vr_ln_fwd": [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_float, c_int32, c_void_p],
+    "vr_ln_bwd": [c_void_p] * 10 + [c_int32, c_int32, c_int32, c_int32, c_void_p],
+    "vr_attn_fwd": [c_void_p] * 4 + [c_int32] * 4 + [c_float, c_int32, c_void_p],
+    "vr_attn_bwd": [c_void_p] * 7 + [c_int32] * 4 + [c_float, c_int32, c_void_p],
+    "vr_softce": [c_void_p] * 4 + [c_int32, c_int32, c_float, c_void_p],
+    "vr_colsum": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, RowMap, c_void_p],
+    "vr_scale_mask_cast": [c_void_p] * 4 + [c_int32] * 4 + [c_void_p],
+    "vr_batchsum": [c_void_p, c_void_p, c_int32, c_int64, c_void_p],
+    "vr_im2col_patch": [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p],
+    "vr_embed_cls": [c_void_p] * 4 + [c_int32] * 3 + [c_void_p],
+    "vr_sr_im2col": [c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p],
+    "vr_sr_col2im": [c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p],
+    "vr_sr_resid": [c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p],
+    "vr_sr_resid_bwd": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
+    "vr_mask_rows": [c_void_p, c_void_p] + [c_int32] * 3 + [c_void_p],
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the library; raise loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libvitres_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C vit-search_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SYMBOLS.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise RuntimeError("libvitres_hip.so does not export %s" % name) from e
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+_ERR = {-1: "VR_EINVAL (bad argument)", -2: "VR_EALIGN (pointer / leading-dimension alignment)",
+        -3: "VR_EUNSUPPORTED (shape or dtype not supported)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, "hipError_t %d" % rc)))

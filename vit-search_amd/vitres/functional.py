@@ -1,0 +1,232 @@
+"""Forward / backward of the ViT-Res layers as explicit sequences of HIP kernel calls.
+
+Every `*_fwd` returns (output, saved) and every `*_bwd` consumes `saved` and the incoming gradient,
+accumulates parameter gradients into the caller's gradient views and returns the gradient of its input.
+The residual stream (x, and its gradient g) is fp32 [B, N, C]; branch activations are in the compute
+dtype (bf16 fast mode / fp32 parity mode).  Prefix masks are int32 keep-count vectors on the device.
+
+Reference op sequences replaced (file:line in /root/reference):
+  attn_branch : nets/supernet_blocks.py:214-245 (norm1 -> Attention.forward :100-120 -> drop_path -> masks -> +x)
+  mlp_branch  : nets/supernet_blocks.py:247-253 (norm2 -> Mlp.forward :37-52 -> drop_path -> mask -> +x)
+  sr_block    : nets/vit_sr_supernet.py:114-172
+  patch_embed : timm PatchEmbed / nets/patch_conv.py:63-72 + vit_sr_supernet.py:398-407
+  head        : nets/vit_sr_supernet.py:420-428,440-449
+"""
+import torch
+
+from . import kernels as K
+
+
+def _split_k(tokens):
+    """Number of contraction splits for a weight-gradient GEMM over `tokens` rows."""
+    return max(1, min(64, tokens // 512))
+
+
+class Weights:
+    """Per-forward view of one Linear-like parameter pair in the compute dtype."""
+    __slots__ = ("w", "b", "w_c", "ld")
+
+    def __init__(self, w, b, w_c, ld):
+        self.w, self.b, self.w_c, self.ld = w, b, w_c, ld   # fp32 param, fp32 bias, compute-dtype matrix [out, ld]
+
+
+def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None):
+    """dw[N_out, K_in] += dy[M, N_out]^T @ x[M, K_in]  (fp32 atomics, split over tokens)."""
+    K.gemm(dy, x, dw, M=N_out, N=K_in, K=M, lda=lddy, ldb=ldx, ldc=ldw or K_in, a_trans=True, b_trans=True,
+           atomic=True, split_k=_split_k(M), a_map=a_map, b_map=b_map)
+
+
+# --------------------------------------------------------------------------------------------------
+# transformer block halves
+# --------------------------------------------------------------------------------------------------
+def attn_branch_fwd(x, p, cfg, embed_keep, attn_keep, out_keep, scale, save):
+    B, N, C = x.shape
+    M = B * N
+    H, D = cfg["heads"], cfg["head_dim"]
+    HD = H * D
+    dt = cfg["dtype"]
+    y, mean, rstd = K.ln_fwd(x, p["n1w"], p["n1b"], embed_keep, N, cfg["eps"], dt)
+    qkv = torch.empty((B, N, 3 * HD), dtype=dt, device=x.device)
+    K.gemm(y, p["qkv"].w_c, qkv, M=M, N=3 * HD, K=C, lda=C, ldb=p["qkv"].ld, ldc=3 * HD, bias=p["qkv"].b, rows_in=N)
+    o, lse = K.attn_fwd(qkv, attn_keep, B, N, H, D, cfg["scale"])
+    x1 = torch.empty_like(x)
+    K.gemm(o, p["proj"].w_c, x1, M=M, N=C, K=HD, lda=HD, ldb=p["proj"].ld, ldc=C, bias=p["proj"].b, scale=scale,
+           keep_n=out_keep, resid=x, rows_in=N)
+    saved = (x, mean, rstd, y, qkv, o, lse) if save else None
+    return x1, saved
+
+
+def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, scale):
+    x, mean, rstd, y, qkv, o, lse = saved
+    B, N, C = x.shape
+    M = B * N
+    H, D = cfg["heads"], cfg["head_dim"]
+    HD = H * D
+    dt = cfg["dtype"]
+    gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                       # d(branch output), compute dtype
+    K.colsum(gt, grads["proj.b"], M, C, C)
+    linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD)
+    d_o = torch.empty((B, N, HD), dtype=dt, device=x.device)
+    K.gemm(gt, p["proj"].w_c, d_o, M=M, N=HD, K=C, lda=C, ldb=p["proj"].ld, ldc=HD, b_trans=True, keep_n=attn_keep,
+           rows_in=N)
+    dqkv = K.attn_bwd(qkv, o, d_o, lse, attn_keep, B, N, H, D, cfg["scale"])
+    K.colsum(dqkv, grads["qkv.b"], M, 3 * HD, 3 * HD)
+    linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C)
+    dy = torch.empty((B, N, C), dtype=dt, device=x.device)
+    K.gemm(dqkv, p["qkv"].w_c, dy, M=M, N=C, K=3 * HD, lda=3 * HD, ldb=p["qkv"].ld, ldc=C, b_trans=True, rows_in=N)
+    return K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, grads["n1w"], grads["n1b"])
+
+
+def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save):
+    B, N, C = x.shape
+    M = B * N
+    F = cfg["hidden"]
+    dt = cfg["dtype"]
+    y, mean, rstd = K.ln_fwd(x, p["n2w"], p["n2b"], embed_keep, N, cfg["eps"], dt)
+    u = torch.empty((B, N, F), dtype=dt, device=x.device)
+    h = torch.empty((B, N, F), dtype=dt, device=x.device)
+    K.gemm(y, p["fc1"].w_c, u, out2=h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b, act=1,
+           keep_n=mlp_keep, rows_in=N)
+    x2 = torch.empty_like(x)
+    K.gemm(h, p["fc2"].w_c, x2, M=M, N=C, K=F, lda=F, ldb=p["fc2"].ld, ldc=C, bias=p["fc2"].b, scale=scale,
+           keep_n=out_keep, resid=x, rows_in=N)
+    saved = (x, mean, rstd, y, u, h) if save else None
+    return x2, saved
+
+
+def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scale):
+    x, mean, rstd, y, u, h = saved
+    B, N, C = x.shape
+    M = B * N
+    F = cfg["hidden"]
+    dt = cfg["dtype"]
+    gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
+    K.colsum(gt, grads["fc2.b"], M, C, C)
+    linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F)
+    du = torch.empty((B, N, F), dtype=dt, device=x.device)
+    K.gemm(gt, p["fc2"].w_c, du, M=M, N=F, K=C, lda=C, ldb=p["fc2"].ld, ldc=F, b_trans=True, dact_u=u, ldu=F,
+           keep_n=mlp_keep, rows_in=N)
+    K.colsum(du, grads["fc1.b"], M, F, F)
+    linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C)
+    dy = torch.empty((B, N, C), dtype=dt, device=x.device)
+    K.gemm(du, p["fc1"].w_c, dy, M=M, N=C, K=F, lda=F, ldb=p["fc1"].ld, ldc=C, b_trans=True, rows_in=N)
+    return K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"])
+
+
+# --------------------------------------------------------------------------------------------------
+# spatial-reduction block
+# --------------------------------------------------------------------------------------------------
+def sr_fwd(x, p, cfg, embed_keep, new_keep, save):
+    B, Ni, C = x.shape
+    g = cfg["grid"]
+    go = g // 2
+    No = 1 + go * go
+    Co = cfg["cout"]
+    dt = cfg["dtype"]
+    y, mean, rstd = K.ln_fwd(x, p["nw"], p["nb"], embed_keep, Ni, cfg["eps"], dt)
+    out = K.sr_resid(x, B, g, C, Co)
+    col = K.sr_im2col(y, B, g, C)
+    K.gemm(col, p["reduce"].w_c, out, M=B * go * go, N=Co, K=9 * C, lda=9 * C, ldb=p["reduce"].ld, ldc=Co,
+           bias=p["reduce"].b, pos=p["pos"], resid=out, rows_in=go * go, c_map=(go * go, No, 1))
+    K.gemm(y, p["token"].w_c, out, M=B, N=Co, K=C, lda=C, ldb=p["token"].ld, ldc=Co, bias=p["token"].b, resid=out,
+           rows_in=1, a_map=(1, Ni, 0), c_map=(1, No, 0))
+    if new_keep is not None:
+        K.mask_rows(out, new_keep, No)
+    saved = (x, mean, rstd, y, col) if save else None
+    return out, saved
+
+
+def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep):
+    x, mean, rstd, y, col = saved
+    B, Ni, C = x.shape
+    g = cfg["grid"]
+    go = g // 2
+    P = go * go
+    No = 1 + P
+    Co = cfg["cout"]
+    dt = cfg["dtype"]
+    gt = K.scale_mask_cast(gout, None, new_keep, No, dt)                    # [B, No, Co]
+    # token_transform (row 0 of every sample)
+    K.colsum(gt, grads["token.b"], B, Co, Co, row_map=(1, No, 0))
+    linear_wgrad(gt, y, grads["token.w"], B, Co, C, Co, C, a_map=(1, No, 0), b_map=(1, Ni, 0))
+    # patch_reduce (rows 1..)
+    K.colsum(gt, grads["reduce.b"], B * P, Co, Co, row_map=(P, No, 1))
+    K.batchsum(gout, grads["pos_sum"])                                      # [No, Co]; rows 1.. are d pos_embed
+    linear_wgrad(gt, col, grads["reduce.w"], B * P, Co, 9 * C, Co, 9 * C, a_map=(P, No, 1))
+    dcol = torch.empty((B * P, 9 * C), dtype=dt, device=x.device)
+    K.gemm(gt, p["reduce"].w_c, dcol, M=B * P, N=9 * C, K=Co, lda=Co, ldb=p["reduce"].ld, ldc=9 * C, b_trans=True,
+           a_map=(P, No, 1), rows_in=P)
+    dy = torch.empty((B, Ni, C), dtype=dt, device=x.device)
+    K.sr_col2im(dcol, dy, B, g, C)
+    K.gemm(gt, p["token"].w_c, dy, M=B, N=C, K=Co, lda=Co, ldb=p["token"].ld, ldc=C, b_trans=True, a_map=(1, No, 0),
+           c_map=(1, Ni, 0), rows_in=1)
+    gres = K.sr_resid_bwd(gout, B, g, C, Co)
+    return K.ln_bwd(dy, x, p["nw"], mean, rstd, embed_keep, Ni, gres, grads["nw"], grads["nb"])
+
+
+# --------------------------------------------------------------------------------------------------
+# patch embedding (type 0: timm PatchEmbed == one patchify GEMM)
+# --------------------------------------------------------------------------------------------------
+def embed0_fwd(img, p, cfg, keep, save):
+    B = img.shape[0]
+    P, C, N = cfg["patches"], cfg["dim"], cfg["patches"] + 1
+    dt = cfg["dtype"]
+    ldk = p["proj"].ld
+    col = K.im2col_patch(img, cfg["patch"], ldk, dt)
+    x = torch.empty((B, N, C), dtype=torch.float32, device=img.device)
+    K.gemm(col, p["proj"].w_c, x, M=B * P, N=C, K=ldk, lda=ldk, ldb=ldk, ldc=C, bias=p["proj"].b, pos=p["pos"][0, 1:],
+           keep_n=keep, rows_in=P, c_map=(P, N, 1))
+    K.embed_cls(p["tokens"], p["pos"], x, keep)
+    return x, ((col,) if save else None)
+
+
+def embed0_bwd(g, saved, p, grads, cfg, keep):
+    (col,) = saved
+    B, N, C = g.shape
+    P = N - 1
+    dt = cfg["dtype"]
+    ldk = p["proj"].ld
+    gt = K.scale_mask_cast(g, None, keep, N, dt)
+    K.colsum(gt, grads["proj.b"], B * P, C, C, row_map=(P, N, 1))
+    linear_wgrad(gt, col, grads["proj.w"], B * P, C, ldk, C, ldk, a_map=(P, N, 1))
+    K.batchsum(g, grads["pos"])                                             # d pos_embed [N, C] (row 0 also = d tokens)
+
+
+# --------------------------------------------------------------------------------------------------
+# final norm + heads
+# --------------------------------------------------------------------------------------------------
+def head_fwd(x, p, cfg, keep, with_patch, save):
+    B, N, C = x.shape
+    dt = cfg["dtype"]
+    nc = cfg["classes"]
+    y, mean, rstd = K.ln_fwd(x, p["nw"], p["nb"], keep, N, cfg["eps"], dt)
+    cls = torch.empty((B, nc), dtype=torch.float32, device=x.device)
+    K.gemm(y, p["cls"].w_c, cls, M=B, N=nc, K=C, lda=C, ldb=p["cls"].ld, ldc=nc, bias=p["cls"].b, a_map=(1, N, 0))
+    pat = None
+    if with_patch:
+        pat = torch.empty((B, N - 1, nc), dtype=torch.float32, device=x.device)
+        K.gemm(y, p["patch"].w_c, pat, M=B * (N - 1), N=nc, K=C, lda=C, ldb=p["patch"].ld, ldc=nc, bias=p["patch"].b,
+               a_map=(N - 1, N, 1))
+    saved = (x, mean, rstd, y) if save else None
+    return cls, pat, saved
+
+
+def head_bwd(dcls, dpat, saved, p, grads, cfg, keep):
+    x, mean, rstd, y = saved
+    B, N, C = x.shape
+    dt = cfg["dtype"]
+    nc = cfg["classes"]
+    dy = torch.zeros((B, N, C), dtype=dt, device=x.device)
+    if dcls is not None:
+        gc = K.scale_mask_cast(dcls.contiguous(), None, None, 1, dt)
+        K.colsum(gc, grads["cls.b"], B, nc, nc)
+        linear_wgrad(gc, y, grads["cls.w"], B, nc, C, nc, C, b_map=(1, N, 0))
+        K.gemm(gc, p["cls"].w_c, dy, M=B, N=C, K=nc, lda=nc, ldb=p["cls"].ld, ldc=C, b_trans=True, c_map=(1, N, 0))
+    if dpat is not None:
+        R = B * (N - 1)
+        gp = K.scale_mask_cast(dpat.contiguous(), None, None, 1, dt)
+        K.colsum(gp, grads["patch.b"], R, nc, nc)
+        linear_wgrad(gp, y, grads["patch.w"], R, nc, C, nc, C, b_map=(N - 1, N, 1))
+        K.gemm(gp, p["patch"].w_c, dy, M=R, N=C, K=nc, lda=nc, ldb=p["patch"].ld, ldc=C, b_trans=True,
+               c_map=(N - 1, N, 1))
+    return K.ln_bwd(dy, x, p["nw"], mean, rstd, keep, N, None, grads["nw"], grads["nb"])

@@ -1,0 +1,175 @@
+"""Tensor-level wrappers over the C ABI (include/vitres_hip.h).
+
+Each function takes torch CUDA tensors, passes raw device pointers + sizes to libvitres_hip.so on
+torch's current stream, and returns torch tensors it allocated for the outputs.  PyTorch is used
+for device memory and streams only.  Non-CUDA tensors raise: there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, RowMap, VR_BF16, VR_F32
+
+IDENT = (0, 0, 0)
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return VR_F32
+    if t.dtype == torch.bfloat16:
+        return VR_BF16
+    raise TypeError("unsupported dtype %s" % t.dtype)
+
+
+def _dtcode(dtype):
+    return VR_F32 if dtype == torch.float32 else VR_BF16
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("vitres kernels need CUDA/HIP tensors (got %s); there is no CPU fallback" % t.device)
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rm(m):
+    return RowMap(*(m or IDENT))
+
+
+def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
+         scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
+         a_map=None, b_map=None, c_map=None):
+    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T) -- see vr_gemm in include/vitres_hip.h."""
+    args = GemmArgs()
+    args.A, args.B, args.C, args.C2 = _p(a), _p(b), _p(out), _p(out2)
+    args.bias, args.pos, args.scale, args.keep_n = _p(bias), _p(pos), _p(scale), _p(keep_n)
+    args.resid, args.dact_u = _p(resid), _p(dact_u)
+    args.M, args.N, args.K = M, N, K
+    args.lda, args.ldb, args.ldc, args.ldu = lda, ldb, ldc, ldu
+    args.a_trans, args.b_trans = int(a_trans), int(b_trans)
+    args.in_dtype, args.out_dtype = _dt(a), _dt(out)
+    assert b.dtype == a.dtype, "A and B must share a dtype"
+    args.act, args.atomic, args.split_k, args.rows_in = act, int(atomic), split_k, rows_in
+    args.a_map, args.b_map, args.c_map = _rm(a_map), _rm(b_map), _rm(c_map)
+    _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
+    return out
+
+
+def cast_bf16(src, dst):
+    _lib.check(_lib.lib().vr_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "vr_cast_f32_bf16")
+    return dst
+
+
+def ln_fwd(x, w, b, keep, rows_per_sample, eps, out_dtype):
+    M, C = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().vr_ln_fwd(_p(x), _p(w), _p(b), _p(y), _p(mean), _p(rstd), _p(keep), M, C, rows_per_sample,
+                                    eps, _dtcode(out_dtype), _stream()), "vr_ln_fwd")
+    return y, mean, rstd
+
+
+def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db):
+    M, C = x.numel() // x.shape[-1], x.shape[-1]
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().vr_ln_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(keep), _p(dx_in), _p(dx), _p(dw), _p(db),
+                                    M, C, rows_per_sample, _dt(dy), _stream()), "vr_ln_bwd")
+    return dx
+
+
+def attn_fwd(qkv, keep_hd, B, N, H, D, scale):
+    o = torch.empty((B, N, H * D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().vr_attn_fwd(_p(qkv), _p(o), _p(lse), _p(keep_hd), B, N, H, D, scale, _dt(qkv), _stream()),
+               "vr_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(qkv, o, d_o, lse, keep_hd, B, N, H, D, scale):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().vr_attn_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), _p(delta), _p(dqkv), _p(keep_hd), B, N, H, D,
+                                      scale, _dt(qkv), _stream()), "vr_attn_bwd")
+    return dqkv
+
+
+def softce(logits, target, gscale, want_grad=True):
+    K = logits.shape[-1]
+    R = logits.numel() // K
+    loss_rows = torch.empty(R, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    _lib.check(_lib.lib().vr_softce(_p(logits), _p(target), _p(loss_rows), _p(dlogits), R, K, gscale, _stream()),
+               "vr_softce")
+    return loss_rows, dlogits
+
+
+def colsum(x, out, M, N, ld, row_map=None):
+    _lib.check(_lib.lib().vr_colsum(_p(x), _p(out), M, N, ld, _dt(x), _rm(row_map), _stream()), "vr_colsum")
+    return out
+
+
+def scale_mask_cast(x, scale, keep, rows_per_sample, out_dtype):
+    C = x.shape[-1]
+    M = x.numel() // C
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _lib.check(_lib.lib().vr_scale_mask_cast(_p(x), _p(out), _p(scale), _p(keep), M, C, rows_per_sample,
+                                             _dtcode(out_dtype), _stream()), "vr_scale_mask_cast")
+    return out
+
+
+def batchsum(x, out):
+    B = x.shape[0]
+    inner = x.numel() // B
+    _lib.check(_lib.lib().vr_batchsum(_p(x), _p(out), B, inner, _stream()), "vr_batchsum")
+    return out
+
+
+def im2col_patch(img, P, ldk, out_dtype):
+    B, Cin, H, W = img.shape
+    col = torch.empty((B * (H // P) * (W // P), ldk), dtype=out_dtype, device=img.device)
+    _lib.check(_lib.lib().vr_im2col_patch(_p(img), _p(col), B, Cin, H, W, P, ldk, _dtcode(out_dtype), _stream()),
+               "vr_im2col_patch")
+    return col
+
+
+def embed_cls(tokens, pos, x, keep):
+    B, N, C = x.shape
+    _lib.check(_lib.lib().vr_embed_cls(_p(tokens), _p(pos), _p(x), _p(keep), B, N, C, _stream()), "vr_embed_cls")
+    return x
+
+
+def sr_im2col(y, B, g, C):
+    col = torch.empty((B * (g // 2) ** 2, 9 * C), dtype=y.dtype, device=y.device)
+    _lib.check(_lib.lib().vr_sr_im2col(_p(y), _p(col), B, g, C, _dt(y), _stream()), "vr_sr_im2col")
+    return col
+
+
+def sr_col2im(dcol, dy, B, g, C):
+    _lib.check(_lib.lib().vr_sr_col2im(_p(dcol), _p(dy), B, g, C, _dt(dcol), _stream()), "vr_sr_col2im")
+    return dy
+
+
+def sr_resid(x, B, g, cin, cout):
+    out = torch.empty((B, 1 + (g // 2) ** 2, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().vr_sr_resid(_p(x), _p(out), B, g, cin, cout, _stream()), "vr_sr_resid")
+    return out
+
+
+def sr_resid_bwd(dout, B, g, cin, cout):
+    dx = torch.empty((B, 1 + g * g, cin), dtype=torch.float32, device=dout.device)
+    _lib.check(_lib.lib().vr_sr_resid_bwd(_p(dout), _p(dx), B, g, cin, cout, 0, _stream()), "vr_sr_resid_bwd")
+    return dx
+
+
+def mask_rows(x, keep, rows_per_sample):
+    C = x.shape[-1]
+    M = x.numel() // C
+    _lib.check(_lib.lib().vr_mask_rows(_p(x), _p(keep), M, C, rows_per_sample, _stream()), "vr_mask_rows")
+    return x

@@ -1,0 +1,606 @@
+"""ViT-Res / ViT-ResNAS (super)network on MI355X: same nn.Module surface as the reference
+(nets/vit_sr_supernet.py:185-577: constructor arguments, `network_def` grammar, state_dict keys,
+`forward(x, patch_output_type)`, `set_epoch`, `no_weight_decay`, registry factories), executed by
+hand-written HIP kernels through the C ABI in include/vitres_hip.h.
+
+Execution model
+  * parameters live in one flat fp32 arena (nn.Parameters are views); a bf16 shadow of the arena is
+    refreshed by one cast kernel per forward (fast mode) -- fp32 parity mode uses the arena directly;
+  * one forward = one autograd node: the layer sequence runs as explicit kernel launches and keeps a
+    tape; backward replays the tape in reverse and writes parameter gradients into a flat gradient
+    arena (returned to autograd as views, so torch optimizers and DDP see ordinary .grad tensors);
+  * all ChannelDrop prefix masks of a forward are sampled on the host first (bit-exact reference RNG
+    protocol), shipped as one int32 [n_masks, B] tensor and consumed by kernel epilogues.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .. import kernels as K
+from ..registry import register_model
+from .channel_drop import ChannelDrop
+from .masked_layer_norm import MaskedLayerNorm
+from .patch_conv import PatchConvEmbed, PatchEmbed
+from .supernet_blocks import Block
+
+# network_def grammar (reference :20-47)
+_BLOCK_EMBED_INDEX = 0
+_EMBED_CHANNEL = 1
+_EMBED_CONV_MID_CHANNELS = 2
+_BLOCK_HEAD_INDEX = -1
+_HEAD_OUT_CHANNEL = 2
+_HEAD_IN_CHANNEL = 1
+_BLOCK_TYPE = 0
+_TYPE_IS_EMBED = 0
+_TYPE_IS_TRANS = 1
+_TYPE_IS_HEAD = 2
+_TYPE_IS_SR = 3
+_TYPE_IS_CONV_EMBED = 4
+_TYPE_IS_FLEXIBLE_CONV_EMBED = 5
+_BLOCK_ATTN_IDX = 1
+_BLOCK_FFN_IDX = 2
+_BLOCK_EXISTS_IDX = 3
+_NUM_WARMUP_EPOCHS = 15
+_REQUIRE_CUDA = True   # tests that emulate the kernels on CPU lift this guard; the kernels themselves never accept CPU tensors
+
+
+def _cfg(url='', **kwargs):
+    return {'url': url, 'num_classes': 1000, 'input_size': (3, 224, 224), 'pool_size': None, 'crop_pct': .9,
+            'interpolation': 'bicubic', 'mean': (0.485, 0.456, 0.406), 'std': (0.229, 0.224, 0.225),
+            'first_conv': 'patch_embed.proj', 'classifier': 'head', **kwargs}
+
+
+def trunc_normal_(t, std):
+    return nn.init.trunc_normal_(t, mean=0., std=std, a=-2., b=2.)
+
+
+class BypassBlock(nn.Module):
+    """Removed transformer block (exists == 0): identity, resets the layer mask (reference :50-56)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+
+class SpatialReductionPatchEmbedding(nn.Module):
+    """Stage transition g x g -> g/2 x g/2 tokens, C -> C' channels (reference :59-182)."""
+
+    def __init__(self, img_size, in_features, out_features, patch_size=2, distill_token=True,
+                 num_channels_to_keep=None, num_warmup_epochs=_NUM_WARMUP_EPOCHS, example_per_arch=None,
+                 single_arch=False):
+        super().__init__()
+        assert patch_size == 2
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.num_patches = (img_size // patch_size) ** 2
+        self.distill_token = distill_token
+        self.num_tokens = 2 if distill_token else 1
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches, out_features))
+        self.norm = MaskedLayerNorm(num_channels=in_features)
+        self.patch_reduce = nn.Conv2d(in_features, out_features, kernel_size=patch_size + 1, stride=patch_size,
+                                      padding=patch_size // 2)
+        assert out_features >= in_features
+        self.token_transform = nn.Linear(in_features, out_features)
+        trunc_normal_(self.pos_embed, std=.02)
+        self.channel_drop = None
+        if num_channels_to_keep is not None:
+            self.channel_drop = ChannelDrop(num_channels_to_keep=num_channels_to_keep,
+                                            num_warmup_epochs=num_warmup_epochs,
+                                            example_per_arch=example_per_arch, single_arch=single_arch)
+
+    def extra_repr(self):
+        return 'num_patches={}, distill_token={}, pos_embed: {}'.format(self.num_patches, self.distill_token,
+                                                                      tuple(self.pos_embed.shape))
+
+
+class _Plan:
+    """Host-side description of one forward: which keep vector / drop-path scale each layer uses."""
+    __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch")
+
+    def __init__(self):
+        self.rows, self.layers, self.keep_dev, self.head, self.scales, self.batch = [], [], None, None, None, 0
+
+    def add(self, keep):
+        if keep is None:
+            return None
+        self.rows.append(keep)
+        return len(self.rows) - 1
+
+    def k(self, idx):
+        return None if idx is None else self.keep_dev[idx]
+
+
+class _ViTResFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, plan, with_patch, *params):
+        save = any(ctx.needs_input_grad[4:])
+        cls, pat, tape = model._run_forward(x, plan, with_patch, save)
+        ctx.model, ctx.plan, ctx.tape, ctx.with_patch = model, plan, tape, with_patch
+        ctx.set_materialize_grads(False)
+        if with_patch:
+            return cls, pat
+        return cls
+
+    @staticmethod
+    def backward(ctx, dcls, dpat=None):
+        if ctx.tape is None:
+            raise RuntimeError('backward called on a forward that saved no tape')
+        grads = ctx.model._run_backward(ctx.tape, ctx.plan, dcls, dpat)
+        ctx.tape = None
+        return (None, None, None, None) + tuple(grads)
+
+
+class FlexibleDistillVisionTransformerSR(nn.Module):
+    def __init__(self, img_size=224, patch_size=14, in_chans=3, num_classes=1000, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., norm_layer=MaskedLayerNorm, distill_token=True, network_def=None,
+                 supernet=False, num_channels_to_keep=None, example_per_arch=None,
+                 num_warmup_epochs=_NUM_WARMUP_EPOCHS, single_arch=False, hybrid_arch=False, patch_output=False):
+        super().__init__()
+        assert patch_size == 14
+        if distill_token:
+            raise NotImplementedError('the HIP path implements the non-distillation (1 token) variants only '
+                                      '(reference factories *_patch14_224[_patch_output][_supernet]); the KD teacher '
+                                      'path is out of scope (SURVEY.md section 2 item 18)')
+        if drop_rate != 0. or attn_drop_rate != 0.:
+            raise NotImplementedError('drop_rate / attn_drop_rate must be 0 (every shipped recipe uses 0)')
+        self.network_def = network_def
+        self.num_classes = num_classes
+        assert network_def[_BLOCK_HEAD_INDEX][_HEAD_OUT_CHANNEL] == num_classes
+        embed_dim = network_def[_BLOCK_EMBED_INDEX][_EMBED_CHANNEL]
+        self.num_features = self.embed_dim = embed_dim
+        self.img_size, self.patch_size, self.in_chans = img_size, patch_size, in_chans
+
+        etype = network_def[_BLOCK_EMBED_INDEX][_BLOCK_TYPE]
+        self.embed_type = etype
+        if etype == _TYPE_IS_FLEXIBLE_CONV_EMBED:
+            self.patch_embed = PatchConvEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                              embed_dim=embed_dim,
+                                              mid_chans=network_def[_BLOCK_EMBED_INDEX][_EMBED_CONV_MID_CHANNELS])
+        elif etype == _TYPE_IS_CONV_EMBED:
+            self.patch_embed = PatchConvEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                              embed_dim=embed_dim)
+        else:
+            self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                          embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        grid = img_size // patch_size
+
+        self.distill_token = distill_token
+        self.num_tokens = 1
+        self.tokens = nn.Parameter(torch.zeros(1, self.num_tokens, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + self.num_tokens, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.patch_output = patch_output
+
+        self.embed_channel_drop = None
+        if supernet:
+            assert num_channels_to_keep is not None, 'Super-network numbers of channels to keep error'
+            assert (example_per_arch is not None) or single_arch, 'Super-network forward-backward architecture error'
+            assert isinstance(num_channels_to_keep, list), 'Num of channels to keep type error'
+            assert len(num_channels_to_keep) == len(network_def), \
+                'Lengths of num_channels_to_keep and network_def are not the same'
+            self.embed_channel_drop = ChannelDrop(num_channels_to_keep=num_channels_to_keep[0],
+                                                  num_warmup_epochs=num_warmup_epochs,
+                                                  example_per_arch=example_per_arch,
+                                                  single_arch=(single_arch or hybrid_arch))
+
+        depth = sum(1 for b in network_def if b[_BLOCK_TYPE] == _TYPE_IS_TRANS)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth, device='cpu')]
+        blocks, depth = [], 0
+        for i, block_def in enumerate(network_def):
+            btype = block_def[_BLOCK_TYPE]
+            if btype not in (_TYPE_IS_SR, _TYPE_IS_TRANS):
+                continue
+            keep_blk = keep_attn = keep_mlp = keep_layer = None
+            if supernet:
+                keep_blk = num_channels_to_keep[i]
+                if btype == _TYPE_IS_TRANS:
+                    assert isinstance(keep_blk, dict)
+                    keep_attn, keep_mlp, keep_layer = keep_blk['attn'], keep_blk['mlp'], keep_blk['layer']
+                else:
+                    assert isinstance(keep_blk, np.ndarray)
+            if btype == _TYPE_IS_TRANS:
+                attn_def, ffn_def = block_def[_BLOCK_ATTN_IDX], block_def[_BLOCK_FFN_IDX]
+                assert attn_def[0] == ffn_def[0], 'Block {}: embedding dim mismatch'.format(depth)
+                assert attn_def[0] == embed_dim, \
+                    'Block {}: embedding dim is not consistent with patch embedding'.format(depth)
+                cls_ = Block if block_def[_BLOCK_EXISTS_IDX] else BypassBlock
+                blocks.append(cls_(dim=embed_dim, num_heads=attn_def[1], head_dim=attn_def[2],
+                                   mlp_features=ffn_def[1], drop_path=dpr[depth],
+                                   num_chs_to_keep_attn=keep_attn, num_chs_to_keep_mlp=keep_mlp,
+                                   num_chs_to_keep_block=keep_layer, num_warmup_epochs=num_warmup_epochs,
+                                   example_per_arch=example_per_arch, single_arch=single_arch))
+                depth += 1
+            else:
+                assert block_def[1] == embed_dim, 'Block {}: SR input embedding size error'.format(i)
+                blocks.append(SpatialReductionPatchEmbedding(
+                    img_size=grid, in_features=block_def[1], out_features=block_def[2],
+                    num_channels_to_keep=keep_blk, num_warmup_epochs=num_warmup_epochs,
+                    example_per_arch=example_per_arch, single_arch=(single_arch or hybrid_arch),
+                    distill_token=distill_token))
+                embed_dim = block_def[2]
+                grid = grid // 2
+        self.blocks = nn.ModuleList(blocks)
+        self.norm = norm_layer(embed_dim)
+        assert embed_dim == network_def[_BLOCK_HEAD_INDEX][_HEAD_IN_CHANNEL]
+        self.cls_head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        self.dst_head = None
+        self.patch_head = nn.Linear(embed_dim, num_classes) if patch_output else None
+
+        trunc_normal_(self.pos_embed, std=.02)
+        trunc_normal_(self.tokens, std=.02)
+        self.apply(self._init_weights)
+
+        self.num_warmup_epochs = num_warmup_epochs
+        self.epoch_now = None
+        self.is_supernet = supernet
+        self.compute_dtype = torch.bfloat16          # fast mode; torch.float32 = exact parity mode
+        self._arena = None
+        self.last_keeps = None                       # keep vectors of the last forward (call order), for tests
+
+    # ---- reference API -----------------------------------------------------------------------
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, (nn.LayerNorm, MaskedLayerNorm)):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        out = ['tokens']
+        for name, _ in self.blocks.named_parameters():
+            if name.endswith(tuple(out)):
+                out.append(name)
+        return set(out)
+
+    def get_classifier(self):
+        return self.cls_head
+
+    def reset_classifier(self, num_classes, global_pool=''):
+        self.num_classes = num_classes
+        self.cls_head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        self._arena = None
+
+    def set_epoch(self, epoch):
+        self.epoch_now = epoch
+        for m in self.modules():
+            if isinstance(m, ChannelDrop):
+                m.set_epoch(epoch)
+        if self.is_supernet and self.num_warmup_epochs >= self.epoch_now:
+            for m in self.modules():
+                if isinstance(m, Block):
+                    m.rewiring()
+
+    def set_compute_dtype(self, dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dtype
+        return self
+
+    def channel_drops_in_call_order(self):
+        out = [self.embed_channel_drop] if self.embed_channel_drop is not None else []
+        for blk in self.blocks:
+            if isinstance(blk, Block):
+                out += [d for d in (blk.attn.channel_drop_layer, blk.layer_drop, blk.mlp.channel_drop_layer)
+                        if d is not None]
+            elif isinstance(blk, SpatialReductionPatchEmbedding) and blk.channel_drop is not None:
+                out.append(blk.channel_drop)
+        return out
+
+    # ---- flat parameter arena ------------------------------------------------------------------
+    def _ensure_arena(self, device):
+        params = list(self.parameters())
+        a = self._arena
+        if a is not None and a["flat"].device == device and len(a["params"]) == len(params) and all(
+                p.data_ptr() == a["flat"].data_ptr() + 4 * off for p, (off, _) in zip(params, a["offsets"])):
+            return a
+        offsets, total = [], 0
+        for p in params:
+            offsets.append((total, p.numel()))
+            total += (p.numel() + 7) // 8 * 8                 # 32-byte aligned fp32 / 16-byte aligned bf16 views
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p, (off, n) in zip(params, offsets):
+                flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + n].view(p.shape)
+        a = {"flat": flat, "params": params, "offsets": offsets, "index": {id(p): i for i, p in enumerate(params)},
+             "shadow": torch.empty(total, dtype=torch.bfloat16, device=device), "gflat": None}
+        self._arena = a
+        return a
+
+    def _wc(self, p, rows=None):
+        """Compute-dtype 2-D view [out, in] of parameter p."""
+        a = self._arena
+        rows = p.shape[0] if rows is None else rows
+        if self.compute_dtype == torch.float32:
+            return p.detach().view(rows, -1)
+        off, n = a["offsets"][a["index"][id(p)]]
+        return a["shadow"][off:off + n].view(rows, -1)
+
+    def _lin(self, m, wkey=None):
+        w = self._wc(m.weight)
+        return Fn.Weights(m.weight, m.bias.detach() if m.bias is not None else None, w, w.shape[1])
+
+    def _gview(self, p):
+        a = self._arena
+        off, n = a["offsets"][a["index"][id(p)]]
+        return a["gcur"][off:off + n].view(p.shape)
+
+    # ---- host-side mask plan -----------------------------------------------------------------------
+    def _make_plan(self, B, device):
+        plan = _Plan()
+        plan.batch = B
+        tr = self.training
+        log = []
+
+        def samp(cd, ch):
+            if cd is None:
+                return None
+            k = cd.sample_keep(B, ch, tr)
+            log.append(k)
+            return k
+        embed_keep = samp(self.embed_channel_drop, self.embed_dim)
+        layer_keep = None
+        e_idx = plan.add(embed_keep)
+        plan.layers.append({"embed": e_idx})
+        n_dp = 0
+        for blk in self.blocks:
+            if isinstance(blk, Block):
+                hd = blk.attn.num_heads * blk.attn.head_dim
+                ka = samp(blk.attn.channel_drop_layer, hd)
+                cur = None
+                if blk.layer_drop is not None:
+                    cur = samp(blk.layer_drop, blk.norm1.num_channels)
+                    if layer_keep is not None:
+                        cur = torch.minimum(cur, layer_keep)
+                if embed_keep is not None:
+                    cur = embed_keep if cur is None else torch.minimum(cur, embed_keep)
+                km = samp(blk.mlp.channel_drop_layer, blk.mlp.fc1.out_features)
+                dp = tr and not isinstance(blk.drop_path, nn.Identity) and blk.drop_path.drop_prob > 0
+                plan.layers.append({"embed": e_idx, "attn": plan.add(ka), "mlp": plan.add(km), "out": plan.add(cur),
+                                    "dp": (n_dp if dp else None)})
+                n_dp += 2 if dp else 0
+                layer_keep = cur
+            elif isinstance(blk, SpatialReductionPatchEmbedding):
+                nk = samp(blk.channel_drop, blk.token_transform.out_features)
+                n_idx = plan.add(nk)
+                plan.layers.append({"embed": e_idx, "new": n_idx})
+                embed_keep, e_idx, layer_keep = nk, n_idx, None
+            else:
+                plan.layers.append(None)
+                layer_keep = None
+        plan.head = e_idx
+        if plan.rows:
+            host = torch.stack(plan.rows).to(torch.int32)
+            plan.keep_dev = host.to(device, non_blocking=True)
+        if n_dp:
+            kp = []
+            for blk in self.blocks:
+                if isinstance(blk, Block) and not isinstance(blk.drop_path, nn.Identity) and blk.drop_path.drop_prob > 0:
+                    kp += [1.0 - blk.drop_path.drop_prob] * 2
+            kp = torch.tensor(kp, dtype=torch.float32, device=device).unsqueeze(1)
+            plan.scales = torch.floor(kp + torch.rand(n_dp, B, device=device)) / kp
+        self.last_keeps = log
+        return plan
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, x, patch_output_type=None):
+        if _REQUIRE_CUDA and not x.is_cuda:
+            raise RuntimeError('vitres runs on MI355X through libvitres_hip.so only; got a %s tensor '
+                               '(the CPU restatement lives in oracle/ and is test infrastructure)' % x.device)
+        if patch_output_type not in (None, 'seq'):
+            if patch_output_type == 'avg':
+                raise NotImplementedError("patch_output_type='avg' is not implemented in the HIP path (the "
+                                          "reference's SwitchTokenMix always returns 'seq', token_mixup.py:150)")
+            raise ValueError()
+        self._ensure_arena(x.device)
+        with_patch = bool(self.patch_output and self.training)
+        plan = self._make_plan(x.shape[0], x.device)
+        params = self._arena["params"]
+        out = _ViTResFn.apply(self, x.contiguous().float(), plan, with_patch, *params)
+        return out
+
+    def _layer_params(self, blk):
+        if isinstance(blk, Block):
+            return {"n1w": blk.norm1.weight.detach(), "n1b": blk.norm1.bias.detach(),
+                    "n2w": blk.norm2.weight.detach(), "n2b": blk.norm2.bias.detach(),
+                    "qkv": self._lin(blk.attn.qkv), "proj": self._lin(blk.attn.proj),
+                    "fc1": self._lin(blk.mlp.fc1), "fc2": self._lin(blk.mlp.fc2)}
+        if isinstance(blk, SpatialReductionPatchEmbedding):
+            w = blk.patch_reduce.weight
+            wperm = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(self.compute_dtype).contiguous()
+            return {"nw": blk.norm.weight.detach(), "nb": blk.norm.bias.detach(),
+                    "reduce": Fn.Weights(w, blk.patch_reduce.bias.detach(), wperm, wperm.shape[1]),
+                    "token": self._lin(blk.token_transform), "pos": blk.pos_embed.detach()[0]}
+        return None
+
+    def _layer_cfg(self, blk, grid):
+        base = {"dtype": self.compute_dtype, "eps": 1e-6}
+        if isinstance(blk, Block):
+            base.update(heads=blk.attn.num_heads, head_dim=blk.attn.head_dim, scale=float(blk.attn.scale),
+                        hidden=blk.mlp.fc1.out_features)
+        elif isinstance(blk, SpatialReductionPatchEmbedding):
+            base.update(grid=grid, cout=blk.token_transform.out_features)
+        return base
+
+    def _embed_params(self):
+        pe = self.patch_embed
+        if self.embed_type == _TYPE_IS_EMBED:
+            w = pe.proj.weight
+            k = w.shape[1] * w.shape[2] * w.shape[3]
+            if self.compute_dtype == torch.float32:
+                wc, ld = w.detach().view(w.shape[0], k), k
+            else:
+                ld = (k + 7) // 8 * 8
+                wc = torch.zeros((w.shape[0], ld), dtype=torch.bfloat16, device=w.device)
+                wc[:, :k].copy_(w.detach().view(w.shape[0], k))
+            return {"proj": Fn.Weights(w, pe.proj.bias.detach(), wc, ld), "pos": self.pos_embed.detach(),
+                    "tokens": self.tokens.detach()}
+        from .. import stem
+        return stem.embed_params(self)
+
+    def _run_forward(self, x, plan, with_patch, save):
+        a = self._arena
+        if self.compute_dtype == torch.bfloat16:
+            K.cast_bf16(a["flat"], a["shadow"])
+        B = x.shape[0]
+        tape = [] if save else None
+        ecfg = {"dtype": self.compute_dtype, "patch": self.patch_size, "patches": self.patch_embed.num_patches,
+                "dim": self.embed_dim}
+        ep = self._embed_params()
+        ekeep = plan.k(plan.layers[0]["embed"])
+        if self.embed_type == _TYPE_IS_EMBED:
+            h, sv = Fn.embed0_fwd(x, ep, ecfg, ekeep, save)
+        else:
+            from .. import stem
+            h, sv = stem.embed_conv_fwd(self, x, ep, ecfg, ekeep, save)
+        if save:
+            tape.append(("embed", ep, ecfg, sv))
+        grid = self.img_size // self.patch_size
+        for blk, L in zip(self.blocks, plan.layers[1:]):
+            if L is None:
+                continue
+            p, cfg = self._layer_params(blk), self._layer_cfg(blk, grid)
+            if isinstance(blk, Block):
+                s1 = s2 = None
+                if L["dp"] is not None:
+                    s1, s2 = plan.scales[L["dp"]], plan.scales[L["dp"] + 1]
+                ek, ka, km, ko = plan.k(L["embed"]), plan.k(L["attn"]), plan.k(L["mlp"]), plan.k(L["out"])
+                h, sa = Fn.attn_branch_fwd(h, p, cfg, ek, ka, ko, s1, save)
+                h, sm = Fn.mlp_branch_fwd(h, p, cfg, ek, km, ko, s2, save)
+                if save:
+                    tape.append(("block", blk, p, cfg, (ek, ka, km, ko, s1, s2), sa, sm))
+            else:
+                ek, nk = plan.k(L["embed"]), plan.k(L["new"])
+                h, sv = Fn.sr_fwd(h, p, cfg, ek, nk, save)
+                if save:
+                    tape.append(("sr", blk, p, cfg, (ek, nk), sv))
+                grid //= 2
+        hp = {"nw": self.norm.weight.detach(), "nb": self.norm.bias.detach(), "cls": self._lin(self.cls_head)}
+        if with_patch:
+            hp["patch"] = self._lin(self.patch_head)
+        hcfg = {"dtype": self.compute_dtype, "eps": 1e-6, "classes": self.num_classes}
+        hk = plan.k(plan.head)
+        cls, pat, sv = Fn.head_fwd(h, hp, hcfg, hk, with_patch, save)
+        if save:
+            tape.append(("head", hp, hcfg, hk, sv))
+        return cls, pat, tape
+
+    # ---- backward ----------------------------------------------------------------------------------
+    def _run_backward(self, tape, plan, dcls, dpat):
+        a = self._arena
+        params = a["params"]
+        fresh = all(p.grad is None for p in params)
+        if a["gflat"] is None:
+            a["gflat"] = torch.zeros_like(a["flat"])
+        # grads already live in the arena (no zero_grad since the last backward): use a scratch arena so that
+        # autograd's accumulation adds a separate buffer
+        a["gcur"] = a["gflat"] if fresh else torch.zeros_like(a["flat"])
+        if fresh:
+            a["gcur"].zero_()
+        gv = self._gview
+        dev = a["flat"].device
+        g = None
+        for entry in reversed(tape):
+            kind = entry[0]
+            if kind == "head":
+                _, hp, hcfg, hk, sv = entry
+                grads = {"nw": gv(self.norm.weight), "nb": gv(self.norm.bias), "cls.w": gv(self.cls_head.weight),
+                         "cls.b": gv(self.cls_head.bias)}
+                if self.patch_head is not None:
+                    grads["patch.w"], grads["patch.b"] = gv(self.patch_head.weight), gv(self.patch_head.bias)
+                g = Fn.head_bwd(dcls, dpat, sv, hp, grads, hcfg, hk)
+            elif kind == "block":
+                _, blk, p, cfg, (ek, ka, km, ko, s1, s2), sa, sm = entry
+                grads = {"n1w": gv(blk.norm1.weight), "n1b": gv(blk.norm1.bias), "n2w": gv(blk.norm2.weight),
+                         "n2b": gv(blk.norm2.bias), "qkv.w": gv(blk.attn.qkv.weight), "qkv.b": gv(blk.attn.qkv.bias),
+                         "proj.w": gv(blk.attn.proj.weight), "proj.b": gv(blk.attn.proj.bias),
+                         "fc1.w": gv(blk.mlp.fc1.weight), "fc1.b": gv(blk.mlp.fc1.bias),
+                         "fc2.w": gv(blk.mlp.fc2.weight), "fc2.b": gv(blk.mlp.fc2.bias)}
+                g = Fn.mlp_branch_bwd(g, sm, p, grads, cfg, ek, km, ko, s2)
+                g = Fn.attn_branch_bwd(g, sa, p, grads, cfg, ek, ka, ko, s1)
+            elif kind == "sr":
+                _, blk, p, cfg, (ek, nk), sv = entry
+                co, ci = blk.patch_reduce.weight.shape[0], blk.patch_reduce.weight.shape[1]
+                wtmp = torch.zeros((co, 9 * ci), dtype=torch.float32, device=dev)
+                ptmp = torch.empty((1 + blk.num_patches, co), dtype=torch.float32, device=dev)
+                grads = {"nw": gv(blk.norm.weight), "nb": gv(blk.norm.bias), "token.w": gv(blk.token_transform.weight),
+                         "token.b": gv(blk.token_transform.bias), "reduce.b": gv(blk.patch_reduce.bias),
+                         "reduce.w": wtmp, "pos_sum": ptmp}
+                g = Fn.sr_bwd(g, sv, p, grads, cfg, ek, nk)
+                gv(blk.patch_reduce.weight).copy_(wtmp.view(co, 3, 3, ci).permute(0, 3, 1, 2))
+                gv(blk.pos_embed).copy_(ptmp[1:].unsqueeze(0))
+            elif kind == "embed":
+                _, ep, ecfg, sv = entry
+                ekeep = plan.k(plan.layers[0]["embed"])
+                if self.embed_type == _TYPE_IS_EMBED:
+                    w = self.patch_embed.proj.weight
+                    ld = ep["proj"].ld
+                    k = w.numel() // w.shape[0]
+                    wt = gv(w).view(w.shape[0], k) if ld == k else torch.zeros((w.shape[0], ld), dtype=torch.float32,
+                                                                              device=dev)
+                    grads = {"proj.w": wt, "proj.b": gv(self.patch_embed.proj.bias), "pos": gv(self.pos_embed)}
+                    Fn.embed0_bwd(g, sv, ep, grads, ecfg, ekeep)
+                    if ld != k:
+                        gv(w).view(w.shape[0], k).copy_(wt[:, :k])
+                else:
+                    from .. import stem
+                    stem.embed_conv_bwd(self, g, sv, ep, ecfg, ekeep, gv)
+                gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:1, :])
+        return [gv(p) for p in params]
+
+
+# ---- registry factories (reference :480-577) -------------------------------------------------------
+def _factory(**fixed):
+    def make(pretrained=False, **kwargs):
+        model = FlexibleDistillVisionTransformerSR(patch_size=14, **fixed, **kwargs)
+        model.default_cfg = _cfg()
+        return model
+    return make
+
+
+@register_model
+def flexible_vit_sr_distill_patch14_224(pretrained=False, **kwargs):
+    return _factory(distill_token=True)(pretrained, **kwargs)
+
+
+@register_model
+def flexible_vit_sr_patch14_224(pretrained=False, **kwargs):
+    return _factory(distill_token=False)(pretrained, **kwargs)
+
+
+@register_model
+def flexible_vit_sr_distill_patch14_224_supernet(pretrained=False, **kwargs):
+    return _factory(distill_token=True, supernet=True)(pretrained, **kwargs)
+
+
+@register_model
+def flexible_vit_sr_patch14_224_supernet(pretrained=False, **kwargs):
+    return _factory(distill_token=False, supernet=True)(pretrained, **kwargs)
+
+
+@register_model
+def flexible_vit_sr_patch14_224_patch_output(pretrained=False, **kwargs):
+    return _factory(distill_token=False, patch_output=True)(pretrained, **kwargs)
+
+
+@register_model
+def flexible_vit_sr_patch14_224_patch_output_supernet(pretrained=False, **kwargs):
+    return _factory(distill_token=False, supernet=True, patch_output=True)(pretrained, **kwargs)
+
+
+@register_model
+def flexible_vit_sr_patch14_280_patch_output(pretrained=False, **kwargs):
+    return _factory(img_size=280, distill_token=False, patch_output=True)(pretrained, **kwargs)
+
+
+@register_model
+def flexible_vit_sr_patch14_336_patch_output(pretrained=False, **kwargs):
+    return _factory(img_size=336, distill_token=False, patch_output=True)(pretrained, **kwargs)
+
+
+@register_model
+def flexible_vit_sr_patch14_392_patch_output(pretrained=False, **kwargs):
+    return _factory(img_size=392, distill_token=False, patch_output=True)(pretrained, **kwargs)
