@@ -217,16 +217,22 @@ def head_bwd(dcls, dpat, saved, p, grads, cfg, keep):
     dt = cfg["dtype"]
     nc = cfg["classes"]
     dy = torch.zeros((B, N, C), dtype=dt, device=x.device)
+    ldp = (nc + 7) // 8 * 8                                                 # logits-gradient rows zero-padded to 16 B
+
+    def padded(d2):                                                         # tiny [rows, classes] tensors: torch glue
+        out = torch.zeros((d2.shape[0], ldp), dtype=dt, device=x.device)
+        out[:, :nc] = d2
+        return out
     if dcls is not None:
-        gc = K.scale_mask_cast(dcls.contiguous(), None, None, 1, dt)
-        K.colsum(gc, grads["cls.b"], B, nc, nc)
-        linear_wgrad(gc, y, grads["cls.w"], B, nc, C, nc, C, b_map=(1, N, 0))
-        K.gemm(gc, p["cls"].w_c, dy, M=B, N=C, K=nc, lda=nc, ldb=p["cls"].ld, ldc=C, b_trans=True, c_map=(1, N, 0))
+        gc = padded(dcls.reshape(B, nc))
+        K.colsum(gc, grads["cls.b"], B, nc, ldp)
+        linear_wgrad(gc, y, grads["cls.w"], B, nc, C, ldp, C, b_map=(1, N, 0))
+        K.gemm(gc, p["cls"].w_c, dy, M=B, N=C, K=nc, lda=ldp, ldb=p["cls"].ld, ldc=C, b_trans=True, c_map=(1, N, 0))
     if dpat is not None:
         R = B * (N - 1)
-        gp = K.scale_mask_cast(dpat.contiguous(), None, None, 1, dt)
-        K.colsum(gp, grads["patch.b"], R, nc, nc)
-        linear_wgrad(gp, y, grads["patch.w"], R, nc, C, nc, C, b_map=(N - 1, N, 1))
-        K.gemm(gp, p["patch"].w_c, dy, M=R, N=C, K=nc, lda=nc, ldb=p["patch"].ld, ldc=C, b_trans=True,
+        gp = padded(dpat.reshape(R, nc))
+        K.colsum(gp, grads["patch.b"], R, nc, ldp)
+        linear_wgrad(gp, y, grads["patch.w"], R, nc, C, ldp, C, b_map=(N - 1, N, 1))
+        K.gemm(gp, p["patch"].w_c, dy, M=R, N=C, K=nc, lda=ldp, ldb=p["patch"].ld, ldc=C, b_trans=True,
                c_map=(N - 1, N, 1))
     return K.ln_bwd(dy, x, p["nw"], mean, rstd, keep, N, None, grads["nw"], grads["nb"])
