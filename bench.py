@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the ViT-ResNAS-Tiny supernet training step (BASELINE.json `metric`),
+one process per GPU, gradients all-reduced over RCCL.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One step = forward + loss + backward + gradient exchange + AdamW on one synthetic batch (B=128/GPU, resident in
+HBM before the timed region).  Prints ONE JSON line (rank 0) with the driver's contract fields plus
+`roofline` (dominant kernel, measured with HIP events around its launches) and `cpu_baseline`
+(the CPU oracle timed on this box's host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "vit-search_amd"),):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[2] / `metric`: sr_tiny supernet (supernet_config/sr_tiny.py), multi-arch sampling
+    "sr_tiny_supernet": dict(space="sr_tiny", batch=128, epa=64, drop_path=0.2),
+    # configs[2'] the README's ViT-ResNAS-Tiny recipe (conv patch embedding)
+    "sr_tiny_mh_supernet": dict(space="sr_tiny_mh", batch=128, epa=64, drop_path=0.2),
+    # configs[3]
+    "sr_small_supernet": dict(space="sr_small", batch=64, epa=32, drop_path=0.3),
+    # configs[1]: ViT-Res-Tiny reference net
+    "ref_tiny": dict(space=None, batch=128, epa=None, drop_path=0.2),
+}
+REF_TINY_DEF = ((4, 192),) + ((1, (192, 3, 64), (192, 768), 1),) * 4 + ((3, 192, 384),) + \
+    ((1, (384, 6, 64), (384, 1536), 1),) * 4 + ((3, 384, 768),) + \
+    ((1, (768, 12, 64), (768, 3072), 1),) * 4 + ((2, 768, 1000),)
+MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}      # dense TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_model(name, dtype, device):
+    import vitres
+    from vitres import supernet_config
+    w = WORKLOADS[name]
+    if w["space"]:
+        sp = getattr(supernet_config, w["space"])
+        model = vitres.create_model("flexible_vit_sr_patch14_224_patch_output_supernet", num_classes=1000,
+                                    network_def=sp.network_def, drop_path_rate=w["drop_path"],
+                                    num_channels_to_keep=sp.num_channels_to_keep, example_per_arch=w["epa"],
+                                    num_warmup_epochs=30, single_arch=False)
+        nd = sp.network_def
+    else:
+        model = vitres.create_model("flexible_vit_sr_patch14_224_patch_output", num_classes=1000,
+                                    network_def=REF_TINY_DEF, drop_path_rate=w["drop_path"])
+        nd = REF_TINY_DEF
+    model = model.to(device).set_compute_dtype(dtype)
+    return model, nd
+
+
+def synthetic_batch(batch, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(batch, 3, 224, 224, generator=g)
+    t = torch.softmax(torch.randn(batch, 1000, generator=g), -1)
+    pt = torch.softmax(torch.randn(batch, 16, 1000, generator=g), -1)
+    return x.to(device), t.to(device), pt.to(device)
+
+
+def effective_macs(model, nd, keeps):
+    """MACs per image actually kept by the sampled sub-networks (masked work is never counted)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    return None
+
+
+def cpu_baseline(name, seconds_budget=25.0):
+    """The CPU oracle (oracle/vitres_oracle.py, pinned to the reference by golden vectors) on the host cores:
+    full training step (fwd + bwd + AdamW), same network, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vitres_oracle as O
+    from vitres import supernet_config
+    w = WORKLOADS[name]
+    cores = min(os.cpu_count() or 1, 32)       # more threads than this only adds fork/join overhead at batch 8
+    torch.set_num_threads(cores)
+    B = 8
+    if w["space"]:
+        sp = getattr(supernet_config, w["space"])
+        m = O.OracleViTSR(sp.network_def, num_classes=1000, drop_path_rate=w["drop_path"], supernet=True,
+                          num_channels_to_keep=sp.num_channels_to_keep, example_per_arch=B // 2,
+                          num_warmup_epochs=30, patch_output=True)
+        m.set_epoch(31)
+    else:
+        m = O.OracleViTSR(REF_TINY_DEF, num_classes=1000, drop_path_rate=w["drop_path"], patch_output=True)
+    opt = torch.optim.AdamW(O.param_groups_weight_decay(m, 0.05), lr=1e-4)
+    x, t, pt = synthetic_batch(B, "cpu", 0)
+    n, t0 = 0, time.time()
+    while True:                                   # no separate warm-up: bounded to ~seconds_budget of CPU work
+        O.train_step(m, opt, x, t, pt, 31, n + 1, arch_sample=("multi" if w["space"] else None))
+        n += 1
+        dt = time.time() - t0
+        if dt + dt / n > seconds_budget or n >= 8:
+            break
+    return {"value": round(B * n / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d train steps (fwd+bwd+AdamW) of the %s CPU oracle, batch %d, fp32, torch %d threads"
+                      % (n, name, B, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="sr_tiny_supernet", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from vitres import engine, kernels as K
+    from vitres.losses import SoftTargetCrossEntropy
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    w = WORKLOADS[args.workload]
+    B = args.batch or w["batch"]
+    torch.manual_seed(0 + rank)                                    # reference: seed + rank (main.py:261-267)
+    model, nd = build_model(args.workload, dtype, device)
+    sync = engine.GradSync(model)
+    x, t, pt = synthetic_batch(B, device, 1000 + rank)
+    model.train()
+    if w["space"]:
+        model.set_epoch(31)                                        # past warm-up: every width choice active
+    model._ensure_arena(device)
+    sync.broadcast_parameters()
+    lr = 5e-4 * B * world / 512.0
+    opt = torch.optim.AdamW(engine.param_groups_weight_decay(model, 0.05), lr=lr, fused=True)
+    crit = SoftTargetCrossEntropy()
+    arch = "multi" if w["space"] else None
+
+    def step(i):
+        return engine.train_step(model, crit, opt, x, t, pt, "seq", epoch=31, train_iter=i, arch_sample=arch,
+                                 grad_sync=sync)
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = []
+    for i in range(args.steps):
+        losses.append(step(args.warmup + i))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    lossv = torch.stack(losses).tolist()
+    assert all(v == v and abs(v) != float("inf") for v in lossv), "non-finite loss"
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- dominant-kernel roofline: HIP events around every vr_gemm launch (same stream), extra steps ------
+    roof = None
+    if args.profile_steps > 0:
+        K.PROFILE = []
+        for i in range(args.profile_steps):
+            step(10_000 + i)
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, fl, by, e0, e1 in K.PROFILE:
+            a = agg.setdefault(kind, [0.0, 0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += fl
+            a[2] += by
+            a[3] += 1
+        K.PROFILE = None
+        names = {(0, 0): "gemm_kernel<T,false,false> (forward NT)", (0, 1): "gemm_kernel<T,false,true> (dgrad)",
+                 (1, 1): "gemm_kernel<T,true,true> (wgrad)", (1, 0): "gemm_kernel<T,true,false>"}
+        kind, (sec, fl, by, n) = max(agg.items(), key=lambda kv: kv[1][0])
+        peak = MFMA_PEAK[kind[0]]
+        ach = fl / sec / 1e12
+        roof = {"bound": "mfma", "kernel": names[(kind[1], kind[2])].replace("T", kind[0]), "achieved": round(ach, 2),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "launches_per_step": n // args.profile_steps, "avg_launch_us": round(sec / n * 1e6, 2),
+                "flops_per_launch": fl / n, "algorithmic_bytes_per_launch": by / n,
+                "gemm_time_share_of_step": round(sum(v[0] for v in agg.values()) / args.profile_steps
+                                                 / (elapsed / args.steps), 3),
+                "all_gemm_kinds": {names[(k[1], k[2])].split(" ")[-1].strip("()"): {
+                    "tflops": round(v[1] / v[0] / 1e12, 2), "ms_per_step": round(v[0] / args.profile_steps * 1e3, 3)}
+                    for k, v in agg.items()}}
+    cpu = None if args.no_cpu_baseline else cpu_baseline(args.workload)
+    out = {
+        "metric": "images/sec/node ViT-ResNAS-Tiny supernet train, bs128/GPU, 1/2/4/8 MI355X",
+        "value": round(B * world * args.steps / elapsed, 2), "unit": "images/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": args.workload, "global_batch": B * world, "per_gpu_batch": B,
+                   "example_per_arch": w["epa"], "epoch": 31, "drop_path": w["drop_path"], "parallelism": "dp%d" % world,
+                   "optimizer": "AdamW(torch fused)", "final_loss": round(lossv[-1], 4)},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,216 @@
+"""Train / eval loops: the build's counterpart of reference engine.py (train_one_epoch :57-190,
+evaluate :194-261), same call signature and per-iteration protocol:
+
+  (patch-)mixup -> save CPU RNG -> [manual_seed(epoch*10000+iter) if single/hybrid] -> forward ->
+  loss = CE(cls) + CE(patch) -> restore CPU RNG -> finite check -> zero_grad -> backward (+ gradient
+  exchange over RCCL) -> optimizer step -> meters.
+
+Differences, all deliberate: bf16 compute needs no GradScaler (loss_scaler may be None); gradients of all
+ranks are averaged by one flat all-reduce (GradSync) instead of DDP buckets; the non-finite-loss check is
+done on the device and read back every `sync_every` iterations (reference: every iteration).
+"""
+import math
+import sys
+import time
+from collections import defaultdict
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+class Meter:
+    """Running sum / count with cross-process reduction (reference utils.SmoothedValue :24-88)."""
+
+    def __init__(self):
+        self.total, self.count = 0.0, 0
+
+    def update(self, value, n=1):
+        self.total += float(value) * n
+        self.count += n
+
+    def synchronize_between_processes(self):
+        if not is_dist():
+            return
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        dist.barrier()
+        dist.all_reduce(t)
+        t = t.tolist()
+        self.count, self.total = int(t[0]), t[1]
+
+    @property
+    def global_avg(self):
+        return self.total / max(self.count, 1)
+
+
+class GradSync:
+    """Data-parallel gradient exchange for a vitres model: parameters are broadcast once from rank 0
+    (reference DDP constructor, main.py:367) and, every step, the flat gradient arena is all-reduced
+    (sum) and scaled by 1/world -- one RCCL call over xGMI instead of DDP's 25 MB buckets."""
+
+    def __init__(self, model):
+        self.model = model
+        self.world = world_size()
+
+    def broadcast_parameters(self):
+        if self.world == 1:
+            return
+        arena = self.model._arena
+        if arena is not None:
+            dist.broadcast(arena["flat"], src=0)
+        else:
+            for p in self.model.parameters():
+                dist.broadcast(p.data, src=0)
+        for b in self.model.buffers():
+            dist.broadcast(b, src=0)
+
+    def all_reduce_grads(self):
+        if self.world == 1:
+            return
+        a = self.model._arena
+        g = a.get("gcur") if a is not None else None
+        p0 = a["params"][0] if a is not None else None
+        if g is not None and p0.grad is not None and p0.grad.data_ptr() == g.data_ptr() + 4 * a["offsets"][0][0]:
+            dist.all_reduce(g)                                    # .grad tensors are views of the flat arena
+            g.mul_(1.0 / self.world)
+            return
+        for p in self.model.parameters():                         # autograd cloned the views: per-tensor fallback
+            if p.grad is not None:
+                dist.all_reduce(p.grad)
+                p.grad.mul_(1.0 / self.world)
+
+
+def train_step(model, criterion, optimizer, samples, targets, patch_targets=None, patch_output_type=None, epoch=0,
+               train_iter=0, arch_sample=None, grad_sync=None, loss_scaler=None, max_norm=None):
+    """One optimisation step; returns the loss tensor (on device, not synchronised)."""
+    rng = None
+    if arch_sample is not None:                                   # engine.py:119-131
+        rng = torch.random.get_rng_state()
+        if arch_sample in ('single', 'hybrid'):
+            torch.manual_seed(epoch * 10000 + train_iter)
+        elif arch_sample != 'multi':
+            raise ValueError('arch_sample has invalid value {}.'.format(arch_sample))
+    if patch_targets is None:
+        outputs = model(samples)
+        output_cls = outputs[0] if isinstance(outputs, tuple) else outputs
+        loss = criterion(output_cls, targets)
+    else:
+        cls_pred, patch_pred = model(samples, patch_output_type=patch_output_type)
+        loss = criterion(cls_pred, targets)
+        if patch_output_type == 'seq':
+            loss = loss + criterion(patch_pred, patch_targets)
+        elif patch_output_type == 'avg':
+            loss = loss + criterion(patch_pred, targets)
+        else:
+            raise ValueError()
+    if rng is not None:
+        torch.random.set_rng_state(rng)                           # engine.py:164-165
+    optimizer.zero_grad(set_to_none=True)
+    if loss_scaler is not None:
+        loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=False)
+    else:
+        loss.backward()
+        if grad_sync is not None:
+            grad_sync.all_reduce_grads()
+        if max_norm:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        optimizer.step()
+    return loss.detach()
+
+
+def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler=None, max_norm=0,
+                    model_ema=None, mixup_fn=None, print_freq=100, teacher_model=None, hard_distill=True, alpha=0.5,
+                    logger=None, arch_sample=False, patch_mixup_fn=None, grad_sync=None, sync_every=1):
+    if teacher_model is not None:
+        raise NotImplementedError('knowledge distillation is out of scope of the HIP hot path (SURVEY.md section 2 item 18)')
+    model.train()
+    criterion.train()
+    print_out = logger.info if logger else print
+    meters = defaultdict(Meter)
+    arch_sample = arch_sample or None
+    pending = []
+    t0 = time.time()
+    for train_iter, (samples, targets) in enumerate(data_loader):
+        samples = samples.to(device, non_blocking=True)
+        targets = targets.to(device, non_blocking=True)
+        patch_targets, patch_output_type = None, None
+        if mixup_fn is not None:
+            samples, targets = mixup_fn(samples, targets)
+            assert patch_mixup_fn is None
+        if patch_mixup_fn is not None:
+            samples, targets, patch_targets, patch_output_type = patch_mixup_fn(samples, targets)
+        loss = train_step(model, criterion, optimizer, samples, targets, patch_targets, patch_output_type, epoch,
+                          train_iter, arch_sample, grad_sync, loss_scaler, max_norm)
+        pending.append(loss)
+        if model_ema is not None:
+            model_ema.update(model)
+        if len(pending) >= sync_every:
+            for v in torch.stack(pending).tolist():               # device -> host sync (reference: every iteration)
+                if not math.isfinite(v):
+                    print_out('Loss is {}, stopping training'.format(v))
+                    sys.exit(1)
+                meters['loss'].update(v)
+            pending = []
+        meters['lr'].update(optimizer.param_groups[0]['lr'])
+        if print_freq and train_iter % print_freq == 0:
+            print_out('Epoch: [{}] [{}] loss: {:.4f} time: {:.1f}s'.format(epoch, train_iter, meters['loss'].global_avg,
+                                                                          time.time() - t0))
+    for v in (torch.stack(pending).tolist() if pending else []):
+        meters['loss'].update(v)
+    for m in meters.values():
+        m.synchronize_between_processes()
+    print_out('Averaged stats: ' + '  '.join('{}: {:.6f}'.format(k, m.global_avg) for k, m in meters.items()))
+    return {k: m.global_avg for k, m in meters.items()}
+
+
+def accuracy(output, target, topk=(1,)):
+    """timm.utils.accuracy: top-k accuracy in percent."""
+    maxk = max(topk)
+    pred = output.topk(maxk, 1, True, True)[1].t()
+    correct = pred.eq(target.reshape(1, -1).expand_as(pred))
+    return [correct[:k].reshape(-1).float().sum(0) * 100.0 / target.size(0) for k in topk]
+
+
+@torch.no_grad()
+def evaluate(data_loader, model, device, print_freq=100, logger=None):
+    """engine.evaluate (:194-261): eval forward, CE, top-1/5 weighted by batch size, global averages."""
+    criterion = torch.nn.CrossEntropyLoss()
+    print_out = logger.info if logger else print
+    meters = defaultdict(Meter)
+    model.eval()
+    for images, target in data_loader:
+        images = images.to(device, non_blocking=True)
+        target = target.to(device, non_blocking=True)
+        output = model(images)
+        output_cls = output[0] if isinstance(output, tuple) else output
+        loss = criterion(output_cls, target)
+        acc1, acc5 = accuracy(output_cls, target, topk=(1, 5))
+        n = images.shape[0]
+        meters['loss'].update(loss.item())
+        meters['acc1'].update(acc1.item(), n=n)
+        meters['acc5'].update(acc5.item(), n=n)
+    for m in meters.values():
+        m.synchronize_between_processes()
+    print_out('Acc@1: {:.2f}, Acc@5: {:.2f}, loss: {:.2f}\n'.format(meters['acc1'].global_avg, meters['acc5'].global_avg,
+                                                                  meters['loss'].global_avg))
+    return {k: m.global_avg for k, m in meters.items()}
+
+
+def param_groups_weight_decay(model, weight_decay=0.05):
+    """timm 0.3.2 optim_factory.add_weight_decay as used by create_optimizer (main.py:385): 1-D parameters,
+    `.bias` and names returned by model.no_weight_decay() get no weight decay."""
+    skip = model.no_weight_decay() if hasattr(model, 'no_weight_decay') else set()
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (p.ndim == 1 or name.endswith('.bias') or name in skip) else decay).append(p)
+    return [{'params': no_decay, 'weight_decay': 0.}, {'params': decay, 'weight_decay': weight_decay}]

@@ -13,6 +13,10 @@ from ._lib import GemmArgs, RowMap, VR_BF16, VR_F32
 
 IDENT = (0, 0, 0)
 
+# bench.py instrumentation: when a list, every vr_gemm launch is bracketed by HIP events on torch's current stream
+# (the stream the kernel is launched on) and (kind, flops, bytes, ev0, ev1) is appended.
+PROFILE = None
+
 
 def _dt(t):
     if t.dtype == torch.float32:
@@ -57,7 +61,16 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     assert b.dtype == a.dtype, "A and B must share a dtype"
     args.act, args.atomic, args.split_k, args.rows_in = act, int(atomic), split_k, rows_in
     args.a_map, args.b_map, args.c_map = _rm(a_map), _rm(b_map), _rm(c_map)
+    if PROFILE is None:
+        _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
+    e1.record()
+    esz = a.element_size()
+    PROFILE.append((("bf16" if args.in_dtype == VR_BF16 else "f32", int(a_trans), int(b_trans)), 2.0 * M * N * K,
+                    float((M * K + N * K) * esz + M * N * out.element_size()), e0, e1))
     return out
 
 
