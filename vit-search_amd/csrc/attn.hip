@@ -5,10 +5,26 @@
 // with rows padded to D+1 words (lane j reads row j -> bank (j + d) mod 32: conflict free); each wave
 // owns query rows q = wave, wave+4, ...; scores are lane-parallel over keys, the PV product is
 // lane-parallel over the head dimension with p broadcast from LDS.
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/vitres_hip.h"
 
+namespace vr_attn_mfma {   // attn_mfma.hip
+bool supported(int N, int H, int D);
+int fwd(const void* qkv, void* o, float* lse, const int* keep, int B, int N, int H, int D, float scale, hipStream_t st);
+int bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, const int* keep, int B,
+        int N, int H, int D, float scale, hipStream_t st);
+}  // namespace vr_attn_mfma
+
 namespace {
+
+// VITRES_ATTN_VALU=1 forces the exact-fp32-arithmetic VALU kernels also for bf16 tensors (debugging aid)
+inline bool use_mfma(int dtype, int N, int H, int D) {
+    if (dtype != VR_BF16 || !vr_attn_mfma::supported(N, H, D)) return false;
+    const char* e = std::getenv("VITRES_ATTN_VALU");
+    return !(e && e[0] == '1');
+}
 
 constexpr int MAXT = 5;  // key groups of 64 per lane -> N <= 320
 
@@ -245,6 +261,12 @@ int set_lds(K kernel, size_t bytes) {
 extern "C" int vr_attn_fwd(const void* qkv, void* o, float* lse, const int32_t* keep_hd, int32_t B, int32_t N, int32_t H,
                            int32_t D, float scale, int32_t dtype, vr_stream_t stream) {
     if (!qkv || !o || !lse || B <= 0 || N <= 0 || H <= 0 || D <= 0) return VR_EINVAL;
+    if (use_mfma(dtype, N, H, D)) {
+        const int rc = vr_attn_mfma::fwd(qkv, o, lse, keep_hd, B, N, H, D, scale, (hipStream_t)stream);
+        if (rc) return rc;
+        VR_CHECK_LAUNCH();
+        return VR_OK;
+    }
     if (D > 64 || N > MAXT * 64 || fwd_lds(N, D) > LDS_MAX) return VR_EUNSUPPORTED;
     const size_t lds = fwd_lds(N, D);
     int rc;
@@ -267,6 +289,12 @@ extern "C" int vr_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
                            const int32_t* keep_hd, int32_t B, int32_t N, int32_t H, int32_t D, float scale, int32_t dtype,
                            vr_stream_t stream) {
     if (!qkv || !o || !d_o || !lse || !delta || !dqkv || B <= 0 || N <= 0 || H <= 0 || D <= 0) return VR_EINVAL;
+    if (use_mfma(dtype, N, H, D)) {
+        const int rc = vr_attn_mfma::bwd(qkv, o, d_o, lse, delta, dqkv, keep_hd, B, N, H, D, scale, (hipStream_t)stream);
+        if (rc) return rc;
+        VR_CHECK_LAUNCH();
+        return VR_OK;
+    }
     if (D > 64 || N > MAXT * 64 || dkv_lds(N, D) > LDS_MAX) return VR_EUNSUPPORTED;
     const size_t l1 = dq_lds(N, D), l2 = dkv_lds(N, D);
     int rc;

@@ -1,0 +1,454 @@
+// bf16 MFMA multi-head self-attention, forward and backward, for the ViT-Res token counts (N = 257 / 65 / 17 at
+// 224 px; any N <= 288) and head dims 32 / 48 / 64 (reference nets/supernet_blocks.py:105-109 and its autograd).
+//
+// One workgroup per (sample, head): the whole head lives in LDS, no online softmax is needed.
+//   forward   : LDS = K (chunk-major) + V^T; each wave owns 16-query tiles.
+//               S^T = K Q^T  (v_mfma_f32_16x16x32_bf16, A = K rows from LDS, B = Q rows from global)
+//               softmax over keys = registers + two cross-lane shuffles (xor 16, 32)
+//               O = P V      (A = P straight from the S^T accumulators, B = V^T from LDS)
+//   backward A: dQ     (LDS = K, V chunk-major + K^T)      per 16-query tile, same dataflow as the forward
+//   backward B: dK, dV (LDS = Q, dO chunk-major + Q^T, dO^T) per 16-key tile
+// Why S^T: the C/D layout of the 16x16 MFMA gives each lane 4 consecutive ROWS of one column; with rows = keys the
+// accumulators of two key tiles are exactly an A-operand (i = query, k = 8 key slots) of the next MFMA -- P never
+// leaves registers.  Any consistent assignment of contraction slots to keys is valid as long as the B operand uses
+// the same one: slot (g, e) of key-pair tile kp is key 32*kp + 16*(e/4) + 4*g + e%4.
+// LDS layouts (both conflict free for their read instruction):
+//   chunk-major  [D/8][Np][8 bf16]   : ds_read_b128 fragment (row = lane%16, chunk = 4*dk + lane/16)
+//   transposed   [Np/4][D][4 bf16]   : ds_read_b64 pairs, d XOR-swizzled by 16 on odd key quads (D != 48)
+#include "common.h"
+#include "../../include/vitres_hip.h"
+
+namespace vr_attn_mfma {
+
+typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
+
+template <int D> struct AC {
+    static constexpr int NCH = D / 8;          // 16-byte chunks per row
+    static constexpr int DK = (D + 31) / 32;   // MFMA k-steps over d
+    static constexpr int DT = D / 16;          // 16-wide output tiles over d
+    static constexpr bool SWZ = (D != 48);
+};
+
+__device__ __forceinline__ f32x4 mfma16(bfv8 a, bfv8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ---- staging ---------------------------------------------------------------------------------------------
+// rows [N][D] at src (row stride rs elements) -> chunk-major LDS, rows N..Np-1 zero
+template <int D>
+__device__ __forceinline__ void stage_chunked(char* dst, const bf16_t* __restrict__ src, int rs, int N, int Np, int tid,
+                                              int nthr) {
+    constexpr int NCH = AC<D>::NCH;
+    for (int idx = tid; idx < Np * NCH; idx += nthr) {
+        const int n = idx % Np, ch = idx / Np;
+        const bool ok = n < N;
+        uint4 v = *reinterpret_cast<const uint4*>(src + (long long)(ok ? n : 0) * rs + ch * 8);
+        if (!ok) v = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(dst + ((size_t)ch * Np + n) * 16) = v;
+    }
+}
+
+template <int D> __device__ __forceinline__ int tr_off(int kq, int d) {
+    const int dp = AC<D>::SWZ ? (d ^ ((kq & 1) << 4)) : d;
+    return kq * (D * 8) + dp * 8;
+}
+
+// rows [N][D] -> transposed LDS [Np/4][D][4]; thread handles 4 rows x 2 adjacent d
+template <int D>
+__device__ __forceinline__ void stage_transposed(char* dst, const bf16_t* __restrict__ src, int rs, int N, int Np, int tid,
+                                                 int nthr) {
+    constexpr int HP = D / 2;
+    for (int idx = tid; idx < (Np / 4) * HP; idx += nthr) {
+        const int dp = idx % HP, kq = idx / HP;
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = kq * 4 + e;
+            const bool ok = n < N;
+            const uint32_t x = *reinterpret_cast<const uint32_t*>(src + (long long)(ok ? n : 0) * rs + dp * 2);
+            w[e] = ok ? x : 0u;
+        }
+        const uint2 lo = make_uint2((w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16));
+        const uint2 hi = make_uint2((w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u));
+        *reinterpret_cast<uint2*>(dst + tr_off<D>(kq, dp * 2)) = lo;
+        *reinterpret_cast<uint2*>(dst + tr_off<D>(kq, dp * 2 + 1)) = hi;
+    }
+}
+
+// ---- fragments -------------------------------------------------------------------------------------------
+// 16 rows x 32 d from global rows (lane: row r0 + lane%16, d = dk*32 + 8*(lane/16) ..+7), zero outside [N) x [D)
+template <int D>
+__device__ __forceinline__ bfv8 gfrag(const bf16_t* __restrict__ src, int rs, int r0, int N, int dk, int lane) {
+    const int r = r0 + (lane & 15), d0 = dk * 32 + 8 * (lane >> 4);
+    const bool ok = (r < N) && (d0 < D);
+    uint4 v = *reinterpret_cast<const uint4*>(src + (long long)(ok ? r : 0) * rs + (ok ? d0 : 0));
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    return __builtin_bit_cast(bfv8, v);
+}
+template <int D>
+__device__ __forceinline__ bfv8 cfrag(const char* base, int Np, int n0, int dk, int lane) {
+    int ch = dk * 4 + (lane >> 4);
+    ch = ch < AC<D>::NCH ? ch : AC<D>::NCH - 1;      // partner operand is zero there (D = 48)
+    return *reinterpret_cast<const bfv8*>(base + ((size_t)ch * Np + n0 + (lane & 15)) * 16);
+}
+// contraction slots of pair tile kp for column d = dt*16 + lane%16
+template <int D>
+__device__ __forceinline__ bfv8 tfrag(const char* base, int kp, int dt, int lane) {
+    const int g = lane >> 4, d = dt * 16 + (lane & 15);
+    const uint2 a = *reinterpret_cast<const uint2*>(base + tr_off<D>(kp * 8 + g, d));
+    const uint2 b = *reinterpret_cast<const uint2*>(base + tr_off<D>(kp * 8 + 4 + g, d));
+    return __builtin_bit_cast(bfv8, make_uint4(a.x, a.y, b.x, b.y));
+}
+__device__ __forceinline__ bfv8 pack8(const f32x4& a, const f32x4& b) {
+    return __builtin_bit_cast(bfv8, make_uint4(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]),
+                                               pack_bf2(b[2], b[3])));
+}
+__device__ __forceinline__ float gmax(float v) {   // over the 4 lanes sharing lane%16
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float gsum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// ==========================================================================================================
+// forward
+// ==========================================================================================================
+template <int D, int NKP, int NW>
+__global__ __launch_bounds__(NW * 64) void fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                      float* __restrict__ lse, const int* __restrict__ keep_hd, int B,
+                                                      int N, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int HD = H * D, RS = 3 * HD;
+    const bf16_t* base = qkv + (long long)b * N * RS + h * D;
+    bf16_t* ob = o + (long long)b * N * HD + h * D;
+    float* lb = lse + ((long long)b * H + h) * N;
+    if (keep_hd && h * D >= keep_hd[b]) {
+        for (int i = tid; i < N * (D / 8); i += NW * 64) {
+            const int n = i / (D / 8), ch = i % (D / 8);
+            *reinterpret_cast<uint4*>(ob + (long long)n * HD + ch * 8) = make_uint4(0, 0, 0, 0);
+        }
+        for (int n = tid; n < N; n += NW * 64) lb[n] = 0.f;
+        return;
+    }
+    const int Np = (N + 31) / 32 * 32, nkt = Np / 16, nkp = Np / 32;
+    char* Kc = sm;
+    char* Vt = sm + (size_t)D * Np * 2;
+    stage_chunked<D>(Kc, base + HD, RS, N, Np, tid, NW * 64);
+    stage_transposed<D>(Vt, base + 2 * HD, RS, N, Np, tid, NW * 64);
+    __syncthreads();
+    for (int q0 = wave * 16; q0 < N; q0 += NW * 16) {
+        bfv8 qf[AC<D>::DK];
+#pragma unroll
+        for (int dk = 0; dk < AC<D>::DK; ++dk) qf[dk] = gfrag<D>(base, RS, q0, N, dk, lane);
+        f32x4 st[2 * NKP];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKP; ++kt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt) {
+#pragma unroll
+                for (int dk = 0; dk < AC<D>::DK; ++dk) acc = mfma16(cfrag<D>(Kc, Np, kt * 16, dk, lane), qf[dk], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool kok = (kt * 16 + 4 * g + r) < N;
+                acc[r] = kok ? acc[r] * scale : -INFINITY;
+                mx = fmaxf(mx, acc[r]);
+            }
+            st[kt] = acc;
+        }
+        mx = gmax(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKP; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(st[kt][r] - mx);
+                st[kt][r] = p;
+                sum += p;
+            }
+        sum = gsum(sum);
+        f32x4 oacc[AC<D>::DT];
+#pragma unroll
+        for (int dt = 0; dt < AC<D>::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < NKP; ++kp) {
+            if (kp < nkp) {
+                const bfv8 pf = pack8(st[2 * kp], st[2 * kp + 1]);
+#pragma unroll
+                for (int dt = 0; dt < AC<D>::DT; ++dt) oacc[dt] = mfma16(pf, tfrag<D>(Vt, kp, dt, lane), oacc[dt]);
+            }
+        }
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ir = __shfl(inv, 4 * g + r, 64);     // lane 4g+r holds query 4g+r of this tile
+            const int q = q0 + 4 * g + r;
+            if (q < N) {
+#pragma unroll
+                for (int dt = 0; dt < AC<D>::DT; ++dt) ob[(long long)q * HD + dt * 16 + c] = f2bf(oacc[dt][r] * ir);
+            }
+        }
+        if (g == 0 && q0 + c < N) lb[q0 + c] = mx + __logf(sum);
+    }
+}
+
+// ==========================================================================================================
+// backward A: dQ (+ delta = rowsum(dO * O))
+// ==========================================================================================================
+template <int D, int NKP, int NW>
+__global__ __launch_bounds__(NW * 64) void bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                         const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                         float* __restrict__ delta, bf16_t* __restrict__ dqkv,
+                                                         const int* __restrict__ keep_hd, int B, int N, int H,
+                                                         float scale) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int HD = H * D, RS = 3 * HD;
+    const bf16_t* base = qkv + (long long)b * N * RS + h * D;
+    bf16_t* dbase = dqkv + (long long)b * N * RS + h * D;
+    if (keep_hd && h * D >= keep_hd[b]) {
+        for (int i = tid; i < N * (D / 8); i += NW * 64) {
+            const int n = i / (D / 8), ch = i % (D / 8);
+            *reinterpret_cast<uint4*>(dbase + (long long)n * RS + ch * 8) = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
+    const bf16_t* ob = o + (long long)b * N * HD + h * D;
+    const bf16_t* gb = d_o + (long long)b * N * HD + h * D;
+    const float* lb = lse + ((long long)b * H + h) * N;
+    float* db = delta + ((long long)b * H + h) * N;
+    const int Np = (N + 31) / 32 * 32, nkp = Np / 32;
+    char* Kc = sm;
+    char* Vc = Kc + (size_t)D * Np * 2;
+    char* Kt = Vc + (size_t)D * Np * 2;
+    stage_chunked<D>(Kc, base + HD, RS, N, Np, tid, NW * 64);
+    stage_chunked<D>(Vc, base + 2 * HD, RS, N, Np, tid, NW * 64);
+    stage_transposed<D>(Kt, base + HD, RS, N, Np, tid, NW * 64);
+    __syncthreads();
+    for (int q0 = wave * 16; q0 < N; q0 += NW * 16) {
+        const bool qok = q0 + c < N;
+        bfv8 qf[AC<D>::DK], gf[AC<D>::DK];
+        float dl = 0.f;
+#pragma unroll
+        for (int dk = 0; dk < AC<D>::DK; ++dk) {
+            qf[dk] = gfrag<D>(base, RS, q0, N, dk, lane);
+            gf[dk] = gfrag<D>(gb, HD, q0, N, dk, lane);
+            const bfv8 of = gfrag<D>(ob, HD, q0, N, dk, lane);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += (float)gf[dk][e] * (float)of[e];
+        }
+        dl = gsum(dl);
+        const float l = qok ? lb[q0 + c] : 0.f;
+        if (g == 0 && qok) db[q0 + c] = dl;
+        f32x4 dq[AC<D>::DT];
+#pragma unroll
+        for (int dt = 0; dt < AC<D>::DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < NKP; ++kp) {
+            if (kp < nkp) {
+                f32x4 ds[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int kt = 2 * kp + t;
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int dk = 0; dk < AC<D>::DK; ++dk) {
+                        s = mfma16(cfrag<D>(Kc, Np, kt * 16, dk, lane), qf[dk], s);
+                        dp = mfma16(cfrag<D>(Vc, Np, kt * 16, dk, lane), gf[dk], dp);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = qok && ((kt * 16 + 4 * g + r) < N);
+                        const float p = ok ? __expf(s[r] * scale - l) : 0.f;
+                        s[r] = p * (dp[r] - dl) * scale;
+                    }
+                    ds[t] = s;
+                }
+                const bfv8 sf = pack8(ds[0], ds[1]);       // dS never leaves registers
+#pragma unroll
+                for (int dt = 0; dt < AC<D>::DT; ++dt) dq[dt] = mfma16(sf, tfrag<D>(Kt, kp, dt, lane), dq[dt]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = q0 + 4 * g + r;
+            if (q < N) {
+#pragma unroll
+                for (int dt = 0; dt < AC<D>::DT; ++dt) dbase[(long long)q * RS + dt * 16 + c] = f2bf(dq[dt][r]);
+            }
+        }
+    }
+}
+
+// ==========================================================================================================
+// backward B: dK, dV
+// ==========================================================================================================
+template <int D, int NKP, int NW>
+__global__ __launch_bounds__(NW * 64) void bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dqkv, const int* __restrict__ keep_hd,
+                                                          int B, int N, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int HD = H * D, RS = 3 * HD;
+    const bf16_t* base = qkv + (long long)b * N * RS + h * D;
+    bf16_t* dbase = dqkv + (long long)b * N * RS + h * D;
+    if (keep_hd && h * D >= keep_hd[b]) {
+        for (int i = tid; i < N * (D / 8); i += NW * 64) {
+            const int n = i / (D / 8), ch = i % (D / 8);
+            *reinterpret_cast<uint4*>(dbase + (long long)n * RS + HD + ch * 8) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(dbase + (long long)n * RS + 2 * HD + ch * 8) = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
+    const bf16_t* gb = d_o + (long long)b * N * HD + h * D;
+    const int Np = (N + 31) / 32 * 32, nqp = Np / 32;
+    char* Qc = sm;
+    char* Gc = Qc + (size_t)D * Np * 2;
+    char* Qt = Gc + (size_t)D * Np * 2;
+    char* Gt = Qt + (size_t)D * Np * 2;
+    float* Ls = reinterpret_cast<float*>(Gt + (size_t)D * Np * 2);
+    float* Ds = Ls + Np;
+    stage_chunked<D>(Qc, base, RS, N, Np, tid, NW * 64);
+    stage_chunked<D>(Gc, gb, HD, N, Np, tid, NW * 64);
+    stage_transposed<D>(Qt, base, RS, N, Np, tid, NW * 64);
+    stage_transposed<D>(Gt, gb, HD, N, Np, tid, NW * 64);
+    for (int n = tid; n < Np; n += NW * 64) {
+        Ls[n] = n < N ? lse[((long long)b * H + h) * N + n] : 0.f;
+        Ds[n] = n < N ? delta[((long long)b * H + h) * N + n] : 0.f;
+    }
+    __syncthreads();
+    for (int k0 = wave * 16; k0 < N; k0 += NW * 16) {
+        bfv8 kf[AC<D>::DK], vf[AC<D>::DK];
+#pragma unroll
+        for (int dk = 0; dk < AC<D>::DK; ++dk) {
+            kf[dk] = gfrag<D>(base + HD, RS, k0, N, dk, lane);
+            vf[dk] = gfrag<D>(base + 2 * HD, RS, k0, N, dk, lane);
+        }
+        f32x4 dka[AC<D>::DT], dva[AC<D>::DT];
+#pragma unroll
+        for (int dt = 0; dt < AC<D>::DT; ++dt) {
+            dka[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dva[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int qp = 0; qp < nqp; ++qp) {
+            f32x4 p[2], ds[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int q0 = qp * 32 + t * 16;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dk = 0; dk < AC<D>::DK; ++dk) {
+                    s = mfma16(cfrag<D>(Qc, Np, q0, dk, lane), kf[dk], s);
+                    dp = mfma16(cfrag<D>(Gc, Np, q0, dk, lane), vf[dk], dp);
+                }
+                const float4 l4 = *reinterpret_cast<const float4*>(Ls + q0 + 4 * g);
+                const float4 d4 = *reinterpret_cast<const float4*>(Ds + q0 + 4 * g);
+                const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (q0 + 4 * g + r) < N;
+                    const float pv = ok ? __expf(s[r] * scale - lr[r]) : 0.f;
+                    p[t][r] = pv;
+                    ds[t][r] = pv * (dp[r] - dr[r]) * scale;
+                }
+            }
+            const bfv8 pf = pack8(p[0], p[1]), sf = pack8(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < AC<D>::DT; ++dt) {
+                dva[dt] = mfma16(pf, tfrag<D>(Gt, qp, dt, lane), dva[dt]);
+                dka[dt] = mfma16(sf, tfrag<D>(Qt, qp, dt, lane), dka[dt]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = k0 + 4 * g + r;
+            if (k < N) {
+#pragma unroll
+                for (int dt = 0; dt < AC<D>::DT; ++dt) {
+                    dbase[(long long)k * RS + HD + dt * 16 + c] = f2bf(dka[dt][r]);
+                    dbase[(long long)k * RS + 2 * HD + dt * 16 + c] = f2bf(dva[dt][r]);
+                }
+            }
+        }
+    }
+}
+
+// ---- host dispatch ---------------------------------------------------------------------------------------
+template <typename K> static int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+template <int D, int NKP>
+static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, const int* keep, int B, int N, int H, float scale,
+                      hipStream_t st) {
+    constexpr int NW = 4;
+    const int Np = (N + 31) / 32 * 32;
+    const size_t lds = (size_t)2 * D * Np * 2;
+    int rc = set_lds(fwd_kernel<D, NKP, NW>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((fwd_kernel<D, NKP, NW>), dim3(B * H), dim3(NW * 64), lds, st, qkv, o, lse, keep, B, N, H, scale);
+    return 0;
+}
+template <int D, int NKP>
+static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse, float* delta, bf16_t* dqkv,
+                      const int* keep, int B, int N, int H, float scale, hipStream_t st) {
+    constexpr int NW = 8;
+    const int Np = (N + 31) / 32 * 32;
+    const size_t l1 = (size_t)3 * D * Np * 2, l2 = (size_t)4 * D * Np * 2 + 2 * Np * sizeof(float);
+    int rc = set_lds(bwd_dq_kernel<D, NKP, NW>, l1);
+    if (rc) return rc;
+    rc = set_lds(bwd_dkv_kernel<D, NKP, NW>, l2);
+    if (rc) return rc;
+    hipLaunchKernelGGL((bwd_dq_kernel<D, NKP, NW>), dim3(B * H), dim3(NW * 64), l1, st, qkv, o, d_o, lse, delta, dqkv, keep,
+                       B, N, H, scale);
+    hipLaunchKernelGGL((bwd_dkv_kernel<D, NKP, NW>), dim3(B * H), dim3(NW * 64), l2, st, qkv, d_o, lse, delta, dqkv, keep, B,
+                       N, H, scale);
+    return 0;
+}
+
+#define VR_ATTN_DISPATCH(FN, ...)                                            \
+    do {                                                                     \
+        const int nkp = (N + 31) / 32;                                       \
+        if (D == 64) {                                                       \
+            if (nkp <= 1) return FN<64, 1>(__VA_ARGS__);                     \
+            if (nkp <= 3) return FN<64, 3>(__VA_ARGS__);                     \
+            return FN<64, 9>(__VA_ARGS__);                                   \
+        } else if (D == 48) {                                                \
+            if (nkp <= 1) return FN<48, 1>(__VA_ARGS__);                     \
+            if (nkp <= 3) return FN<48, 3>(__VA_ARGS__);                     \
+            return FN<48, 9>(__VA_ARGS__);                                   \
+        } else {                                                             \
+            if (nkp <= 1) return FN<32, 1>(__VA_ARGS__);                     \
+            if (nkp <= 3) return FN<32, 3>(__VA_ARGS__);                     \
+            return FN<32, 9>(__VA_ARGS__);                                   \
+        }                                                                    \
+    } while (0)
+
+bool supported(int N, int H, int D) {
+    return (D == 32 || D == 48 || D == 64) && N >= 1 && N <= 288 && ((H * D) % 8 == 0);
+}
+
+int fwd(const void* qkv, void* o, float* lse, const int* keep, int B, int N, int H, int D, float scale, hipStream_t st) {
+    VR_ATTN_DISPATCH(launch_fwd, (const bf16_t*)qkv, (bf16_t*)o, lse, keep, B, N, H, scale, st);
+}
+int bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, const int* keep, int B,
+        int N, int H, int D, float scale, hipStream_t st) {
+    VR_ATTN_DISPATCH(launch_bwd, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse, delta, (bf16_t*)dqkv, keep, B,
+                     N, H, scale, st);
+}
+
+}  // namespace vr_attn_mfma
