@@ -70,6 +70,8 @@ typedef struct vr_gemm_args {
     const int32_t* keep_n; /* [batch] or NULL */
     const float* resid;  /* fp32 [*, ldc] or NULL (may alias C for in-place accumulate) */
     const void* dact_u;  /* pre-activation for gelu' (dtype = in_dtype, leading dim ldu) or NULL */
+    float* bias_grad;    /* wgrad only (a_trans && atomic): bias_grad[m] += sum_k A[k][m]  (the Linear's bias gradient,
+                            fused so that dY is read once), or NULL */
     int32_t M, N, K;
     int32_t lda, ldb, ldc, ldu;
     int32_t a_trans, b_trans;

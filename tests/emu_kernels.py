@@ -24,7 +24,7 @@ def _flat2d(t, ld):
 
 def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
          scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
-         a_map=None, b_map=None, c_map=None):
+         a_map=None, b_map=None, c_map=None, bias_grad=None):
     A2, B2 = _flat2d(a, lda), _flat2d(b, ldb)
     if not a_trans:
         Am = A2[_rows(M, a_map)][:, :K].float()
@@ -35,6 +35,8 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     else:
         Bm = B2[_rows(K, b_map if a_trans else None)][:, :N].float().t()
     v = Am @ Bm.t()
+    if bias_grad is not None:
+        bias_grad += Am.sum(dim=1)
     m_idx = torch.arange(M)
     sample = (m_idx // rows_in) if rows_in > 0 else torch.zeros(M, dtype=torch.long)
     mloc = (m_idx % rows_in) if rows_in > 0 else m_idx

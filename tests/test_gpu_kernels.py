@@ -122,10 +122,12 @@ def test_gemm_wgrad(dtype, T, No, Ki, split):
     x = rnd(T, Ki, seed=2).to(dtype)
     out = rnd(No, Ki, seed=3)
     kw = dict(M=No, N=Ki, K=T, lda=No, ldb=Ki, ldc=Ki, a_trans=True, b_trans=True, atomic=True, split_k=split)
-    ref = E.gemm(dy, x, out.clone(), **kw)
-    real = K.gemm(dy.to(DEV), x.to(DEV), out.to(DEV), **kw)
+    bg_ref, bg = rnd(No, seed=4), rnd(No, seed=4).to(DEV)
+    ref = E.gemm(dy, x, out.clone(), bias_grad=bg_ref, **kw)
+    real = K.gemm(dy.to(DEV), x.to(DEV), out.to(DEV), bias_grad=bg, **kw)
     t = 5e-5 if dtype == torch.float32 else 1.2e-2
     assert relerr(real, ref) < t, relerr(real, ref)
+    assert relerr(bg, bg_ref) < 2e-4, relerr(bg, bg_ref)       # fused bias gradient (exact sums of the stored values)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

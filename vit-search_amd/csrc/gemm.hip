@@ -118,6 +118,26 @@ template <> struct LoaderT<bf16_t> {
                                  (w[4] >> 16) | (w[5] & 0xffff0000u), (w[6] >> 16) | (w[7] & 0xffff0000u));
         }
     }
+    // running sums over the contraction index of this thread's two rows (fused bias gradient of the wgrad)
+    __device__ __forceinline__ void rowsum(float (&rs)[2]) const {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t a[4] = {v[h][0].x, v[h][0].y, v[h][0].z, v[h][0].w};
+            const uint32_t b[4] = {v[h][1].x, v[h][1].y, v[h][1].z, v[h][1].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                rs[0] += __uint_as_float(a[e] << 16) + __uint_as_float(a[e] & 0xffff0000u);
+                rs[1] += __uint_as_float(b[e] << 16) + __uint_as_float(b[e] & 0xffff0000u);
+            }
+        }
+    }
+    // rs -> bias_grad[r0 + ...] : 4 waves hold different k-octets of the same 128 rows
+    __device__ __forceinline__ void rowsum_flush(const float (&rs)[2], float* red, float* out, int r0, int R, int t) const {
+        red[(t >> 6) * 128 + 2 * (t & 63)] = rs[0];
+        red[(t >> 6) * 128 + 2 * (t & 63) + 1] = rs[1];
+        __syncthreads();
+        if (t < 128 && r0 + t < R) atomicAdd(out + r0 + t, red[t] + red[128 + t] + red[256 + t] + red[384 + t]);
+    }
     __device__ __forceinline__ void lstore(char* tile, int t) const {
         const int r = 2 * (t & 63);
 #pragma unroll
@@ -160,6 +180,16 @@ template <> struct LoaderT<float> {
             }
             v[h] = make_uint4(w[0], w[1], w[2], w[3]);
         }
+    }
+    __device__ __forceinline__ void rowsum(float (&rs)[2]) const {
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            rs[0] += (__uint_as_float(v[h].x) + __uint_as_float(v[h].y)) + (__uint_as_float(v[h].z) + __uint_as_float(v[h].w));
+    }
+    __device__ __forceinline__ void rowsum_flush(const float (&rs)[2], float* red, float* out, int r0, int R, int t) const {
+        red[(t >> 7) * 128 + (t & 127)] = rs[0];
+        __syncthreads();
+        if (t < 128 && r0 + t < R) atomicAdd(out + r0 + t, red[t] + red[128 + t]);
     }
     __device__ __forceinline__ void lstore(char* tile, int t) const {
         const int r = t & 127;
@@ -343,8 +373,11 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const vr_gemm_args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    float rs[2] = {0.f, 0.f};
+    const bool want_bg = TA && p.bias_grad != nullptr && blockIdx.x == 0;
     la.gload(kbeg, kend, t);
     lb.gload(kbeg, kend, t);
+    if constexpr (TA) { if (want_bg) la.rowsum(rs); }
     la.lstore(smem, t);
     lb.lstore(smem + TILE_BYTES, t);
     __syncthreads();
@@ -354,6 +387,7 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const vr_gemm_args p) {
         if (more) {
             la.gload(kbeg + (kt + 1) * BK, kend, t);
             lb.gload(kbeg + (kt + 1) * BK, kend, t);
+            if constexpr (TA) { if (want_bg) la.rowsum(rs); }
         }
         const char* As = smem + cur * 2 * TILE_BYTES;
         mma_tile<EPI != EPI_ATOMIC>(acc, As, As + TILE_BYTES, wm, wn, lane, (T*)nullptr);
@@ -366,6 +400,9 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const vr_gemm_args p) {
         cur ^= 1;
     }
 
+    if constexpr (TA) {
+        if (want_bg) la.rowsum_flush(rs, reinterpret_cast<float*>(smem), p.bias_grad, m0, p.M, t);
+    }
     if constexpr (EPI == EPI_ATOMIC) {
         // natural accumulator layout: a half-wave adds 32 consecutive fp32 of one output row (128 B) per instruction
         float* C = reinterpret_cast<float*>(p.C);
@@ -455,6 +492,7 @@ extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
     if (a.split_k > 1 && !a.atomic) return VR_EINVAL;
     if (a.atomic && a.out_dtype != VR_F32) return VR_EINVAL;
     if (a.act == 1 && !a.C2) return VR_EINVAL;
+    if (a.bias_grad && !(a.a_trans && a.atomic)) return VR_EINVAL;
     if (a.in_dtype != VR_F32 && a.in_dtype != VR_BF16) return VR_EUNSUPPORTED;
     if (a.out_dtype != VR_F32 && a.out_dtype != VR_BF16) return VR_EUNSUPPORTED;
     const int epc = a.in_dtype == VR_BF16 ? 8 : 4;

@@ -30,10 +30,10 @@ class Weights:
         self.w, self.b, self.w_c, self.ld = w, b, w_c, ld   # fp32 param, fp32 bias, compute-dtype matrix [out, ld]
 
 
-def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None):
+def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None, db=None):
     """dw[N_out, K_in] += dy[M, N_out]^T @ x[M, K_in]  (fp32 atomics, split over tokens)."""
     K.gemm(dy, x, dw, M=N_out, N=K_in, K=M, lda=lddy, ldb=ldx, ldc=ldw or K_in, a_trans=True, b_trans=True,
-           atomic=True, split_k=_split_k(M), a_map=a_map, b_map=b_map)
+           atomic=True, split_k=_split_k(M), a_map=a_map, b_map=b_map, bias_grad=db)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -64,14 +64,12 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     HD = H * D
     dt = cfg["dtype"]
     gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                       # d(branch output), compute dtype
-    K.colsum(gt, grads["proj.b"], M, C, C)
-    linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD)
+    linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"])
     d_o = torch.empty((B, N, HD), dtype=dt, device=x.device)
     K.gemm(gt, p["proj"].w_c, d_o, M=M, N=HD, K=C, lda=C, ldb=p["proj"].ld, ldc=HD, b_trans=True, keep_n=attn_keep,
            rows_in=N)
     dqkv = K.attn_bwd(qkv, o, d_o, lse, attn_keep, B, N, H, D, cfg["scale"])
-    K.colsum(dqkv, grads["qkv.b"], M, 3 * HD, 3 * HD)
-    linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C)
+    linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C, db=grads["qkv.b"])
     dy = torch.empty((B, N, C), dtype=dt, device=x.device)
     K.gemm(dqkv, p["qkv"].w_c, dy, M=M, N=C, K=3 * HD, lda=3 * HD, ldb=p["qkv"].ld, ldc=C, b_trans=True, rows_in=N)
     return K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, grads["n1w"], grads["n1b"])
@@ -101,13 +99,11 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     F = cfg["hidden"]
     dt = cfg["dtype"]
     gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
-    K.colsum(gt, grads["fc2.b"], M, C, C)
-    linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F)
+    linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"])
     du = torch.empty((B, N, F), dtype=dt, device=x.device)
     K.gemm(gt, p["fc2"].w_c, du, M=M, N=F, K=C, lda=C, ldb=p["fc2"].ld, ldc=F, b_trans=True, dact_u=u, ldu=F,
            keep_n=mlp_keep, rows_in=N)
-    K.colsum(du, grads["fc1.b"], M, F, F)
-    linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C)
+    linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"])
     dy = torch.empty((B, N, C), dtype=dt, device=x.device)
     K.gemm(du, p["fc1"].w_c, dy, M=M, N=C, K=F, lda=F, ldb=p["fc1"].ld, ldc=C, b_trans=True, rows_in=N)
     return K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"])
@@ -147,12 +143,10 @@ def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep):
     dt = cfg["dtype"]
     gt = K.scale_mask_cast(gout, None, new_keep, No, dt)                    # [B, No, Co]
     # token_transform (row 0 of every sample)
-    K.colsum(gt, grads["token.b"], B, Co, Co, row_map=(1, No, 0))
-    linear_wgrad(gt, y, grads["token.w"], B, Co, C, Co, C, a_map=(1, No, 0), b_map=(1, Ni, 0))
+    linear_wgrad(gt, y, grads["token.w"], B, Co, C, Co, C, a_map=(1, No, 0), b_map=(1, Ni, 0), db=grads["token.b"])
     # patch_reduce (rows 1..)
-    K.colsum(gt, grads["reduce.b"], B * P, Co, Co, row_map=(P, No, 1))
     K.batchsum(gout, grads["pos_sum"])                                      # [No, Co]; rows 1.. are d pos_embed
-    linear_wgrad(gt, col, grads["reduce.w"], B * P, Co, 9 * C, Co, 9 * C, a_map=(P, No, 1))
+    linear_wgrad(gt, col, grads["reduce.w"], B * P, Co, 9 * C, Co, 9 * C, a_map=(P, No, 1), db=grads["reduce.b"])
     dcol = torch.empty((B * P, 9 * C), dtype=dt, device=x.device)
     K.gemm(gt, p["reduce"].w_c, dcol, M=B * P, N=9 * C, K=Co, lda=Co, ldb=p["reduce"].ld, ldc=9 * C, b_trans=True,
            a_map=(P, No, 1), rows_in=P)
@@ -187,8 +181,7 @@ def embed0_bwd(g, saved, p, grads, cfg, keep):
     dt = cfg["dtype"]
     ldk = p["proj"].ld
     gt = K.scale_mask_cast(g, None, keep, N, dt)
-    K.colsum(gt, grads["proj.b"], B * P, C, C, row_map=(P, N, 1))
-    linear_wgrad(gt, col, grads["proj.w"], B * P, C, ldk, C, ldk, a_map=(P, N, 1))
+    linear_wgrad(gt, col, grads["proj.w"], B * P, C, ldk, C, ldk, a_map=(P, N, 1), db=grads["proj.b"])
     K.batchsum(g, grads["pos"])                                             # d pos_embed [N, C] (row 0 also = d tokens)
 
 
@@ -225,14 +218,12 @@ def head_bwd(dcls, dpat, saved, p, grads, cfg, keep):
         return out
     if dcls is not None:
         gc = padded(dcls.reshape(B, nc))
-        K.colsum(gc, grads["cls.b"], B, nc, ldp)
-        linear_wgrad(gc, y, grads["cls.w"], B, nc, C, ldp, C, b_map=(1, N, 0))
+        linear_wgrad(gc, y, grads["cls.w"], B, nc, C, ldp, C, b_map=(1, N, 0), db=grads["cls.b"])
         K.gemm(gc, p["cls"].w_c, dy, M=B, N=C, K=nc, lda=ldp, ldb=p["cls"].ld, ldc=C, b_trans=True, c_map=(1, N, 0))
     if dpat is not None:
         R = B * (N - 1)
         gp = padded(dpat.reshape(R, nc))
-        K.colsum(gp, grads["patch.b"], R, nc, ldp)
-        linear_wgrad(gp, y, grads["patch.w"], R, nc, C, ldp, C, b_map=(N - 1, N, 1))
+        linear_wgrad(gp, y, grads["patch.w"], R, nc, C, ldp, C, b_map=(N - 1, N, 1), db=grads["patch.b"])
         K.gemm(gp, p["patch"].w_c, dy, M=R, N=C, K=nc, lda=ldp, ldb=p["patch"].ld, ldc=C, b_trans=True,
                c_map=(N - 1, N, 1))
     return K.ln_bwd(dy, x, p["nw"], mean, rstd, keep, N, None, grads["nw"], grads["nb"])
