@@ -165,6 +165,29 @@ int vr_sr_resid_bwd(const float* dout, float* dx, int32_t B, int32_t g, int32_t 
 /* x[m, c] = 0 for c >= keep[sample(m)]  (ChannelDrop.forward `x * mask`, nets/channel_drop.py:82) */
 int vr_mask_rows(float* x, const int32_t* keep, int32_t M, int32_t C, int32_t rows_per_sample, vr_stream_t stream);
 
+/*
+ * Convolutional patch embedding (reference nets/patch_conv.py:23-73) as NHWC gathers around vr_gemm.
+ *  vr_im2col3x3   : 3x3 / pad 1 window gather -> col [B*Ho*Wo, ld], k = (kh, kw, c).  src_nchw_f32 = 1: src is the fp32
+ *                   NCHW image (conv1, any stride, ld >= 9*C zero padded); 0: src is NHWC in `dtype` (stride 1, C % 8 == 0,
+ *                   ld == 9*C).
+ *  vr_col2im3x3   : its adjoint for the NHWC / stride-1 case (gather form, no atomics).
+ *  vr_bn_stats    : sum[c] += sum_r z[r,c], sumsq[c] += sum_r z[r,c]^2  (train-mode BatchNorm2d statistics; caller zeroes).
+ *  vr_bn_relu     : out = relu(z * scale[c] + shift[c]) (+ res)          (ConvBnAct.forward :34-38 with folded BN affine).
+ *  vr_bn_bwd      : g = da * [bn(z) > 0]; sg[c] += sum g; sgz[c] += sum g*zhat (caller zeroes); then
+ *                   dz = scale * (g - sg/R - zhat*sgz/R) (training) or scale * g (eval).  d gamma = sgz, d beta = sg.
+ *  vr_patch_unfold: non-overlapping P x P patches, a NHWC [B, gh*P, gw*P, C] <-> col [B*gh*gw, (i, j, c)] (fold != 0: col -> a).
+ */
+int vr_im2col3x3(const void* src, void* col, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride,
+                 int32_t src_nchw_f32, int32_t ld, int32_t dtype, vr_stream_t stream);
+int vr_col2im3x3(const void* dcol, void* dsrc, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, vr_stream_t stream);
+int vr_bn_stats(const float* z, float* sum, float* sumsq, int64_t R, int32_t C, vr_stream_t stream);
+int vr_bn_relu(const float* z, const float* scale, const float* shift, const void* res, void* out, int64_t R, int32_t C,
+               int32_t dtype, vr_stream_t stream);
+int vr_bn_bwd(const void* da, const float* z, const float* scale, const float* shift, const float* mean, const float* rstd,
+              float* sg, float* sgz, void* dz, int64_t R, int32_t C, int32_t training, int32_t dtype, vr_stream_t stream);
+int vr_patch_unfold(void* a, void* col, int32_t B, int32_t gh, int32_t gw, int32_t P, int32_t C, int32_t fold, int32_t dtype,
+                    vr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,7 +233,60 @@ def mask_rows(x, keep, rows_per_sample):
     return x
 
 
-ALL = ["gemm", "cast_bf16", "ln_fwd", "ln_bwd", "attn_fwd", "attn_bwd", "softce", "colsum", "scale_mask_cast",
+def im2col3x3_image(img, stride, ld, out_dtype):
+    B, C, H, W = img.shape
+    u = F.unfold(img, kernel_size=3, stride=stride, padding=1)               # [B, C*9, L], k = (c, tap)
+    L = u.shape[-1]
+    u = u.view(B, C, 9, L).permute(0, 3, 2, 1).reshape(B * L, 9 * C)
+    out = torch.zeros(B * L, ld, dtype=out_dtype)
+    out[:, :9 * C] = u.to(out_dtype)
+    return out
+
+
+def im2col3x3(a, B, H, W, C):
+    img = a.view(B, H, W, C).float().permute(0, 3, 1, 2)
+    u = F.unfold(img, kernel_size=3, stride=1, padding=1).view(B, C, 9, H * W).permute(0, 3, 2, 1)
+    return u.reshape(B * H * W, 9 * C).to(a.dtype)
+
+
+def col2im3x3(dcol, B, H, W, C):
+    u = dcol.float().view(B, H * W, 9, C).permute(0, 3, 2, 1).reshape(B, C * 9, H * W)
+    img = F.fold(u, output_size=(H, W), kernel_size=3, stride=1, padding=1)
+    return img.permute(0, 2, 3, 1).reshape(B * H * W, C).to(dcol.dtype)
+
+
+def bn_stats(z, s, q):
+    s += z.sum(0)
+    q += (z * z).sum(0)
+
+
+def bn_relu(z, scale, shift, res, out_dtype):
+    v = torch.relu(z * scale + shift)
+    if res is not None:
+        v = v + res.float()
+    return v.to(out_dtype)
+
+
+def bn_bwd(da, z, scale, shift, mean, rstd, sg, sgz, training):
+    g = da.float() * ((z * scale + shift) > 0)
+    zh = (z - mean) * rstd
+    sg += g.sum(0)
+    sgz += (g * zh).sum(0)
+    inv_n = 1.0 / z.shape[0] if training else 0.0
+    return (scale * (g - sg * inv_n - zh * sgz * inv_n)).to(da.dtype)
+
+
+def patch_unfold(a, B, gh, gw, P, C):
+    x = a.view(B, gh, P, gw, P, C).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(B * gh * gw, P * P * C).clone()
+
+
+def patch_fold(col, B, gh, gw, P, C):
+    x = col.view(B, gh, gw, P, P, C).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(B * gh * P * gw * P, C).clone()
+
+
+ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "cast_bf16", "ln_fwd", "ln_bwd", "attn_fwd", "attn_bwd", "softce", "colsum", "scale_mask_cast",
        "batchsum", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
 
 

@@ -244,3 +244,43 @@ def test_small_kernels(dtype):
     dst = torch.empty(1000, dtype=torch.bfloat16, device=DEV)
     K.cast_bf16(src.to(DEV), dst)
     assert torch.equal(dst.cpu(), src.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_kernels(dtype):
+    B, H, W, m = 2, 12, 12, 24
+    img = rnd(B, 3, 2 * H, 2 * W, seed=1)
+    r, e = both("im2col3x3_image", (img, 2, 32, dtype))
+    assert r.shape == e.shape and relerr(r, e) < tol(dtype)
+    a = rnd(B * H * W, m, seed=2).to(dtype)
+    r, e = both("im2col3x3", (a, B, H, W, m))
+    assert relerr(r, e) < 1e-6
+    dcol = rnd(B * H * W, 9 * m, seed=3).to(dtype)
+    r, e = both("col2im3x3", (dcol, B, H, W, m))
+    assert relerr(r, e) < tol(dtype)
+    z = rnd(B * H * W, m, seed=4) + 0.2
+    s_ref, q_ref = torch.zeros(m), torch.zeros(m)
+    E.bn_stats(z, s_ref, q_ref)
+    sd, qd = torch.zeros(m, device=DEV), torch.zeros(m, device=DEV)
+    K.bn_stats(z.to(DEV), sd, qd)
+    assert relerr(sd, s_ref) < 1e-5 and relerr(qd, q_ref) < 1e-5
+    scale, shift = 1 + 0.1 * rnd(m, seed=5), 0.1 * rnd(m, seed=6)
+    res = rnd(B * H * W, m, seed=7).to(dtype)
+    r, e = both("bn_relu", (z, scale, shift, res, dtype))
+    assert relerr(r, e) < tol(dtype)
+    r, e = both("bn_relu", (z, scale, shift, None, dtype))
+    assert relerr(r, e) < tol(dtype)
+    mean, rstd = z.mean(0), 1.0 / z.var(0, unbiased=False).add(1e-5).sqrt()
+    da = rnd(B * H * W, m, seed=8).to(dtype)
+    for training in (True, False):
+        sg_r, sgz_r = torch.zeros(m), torch.zeros(m)
+        dz_r = E.bn_bwd(da, z, scale, shift, mean, rstd, sg_r, sgz_r, training)
+        sg, sgz = torch.zeros(m, device=DEV), torch.zeros(m, device=DEV)
+        dz = K.bn_bwd(da.to(DEV), z.to(DEV), scale.to(DEV), shift.to(DEV), mean.to(DEV), rstd.to(DEV), sg, sgz, training)
+        assert relerr(sg, sg_r) < 1e-4 and relerr(sgz, sgz_r) < 1e-4
+        assert relerr(dz, dz_r) < (1e-4 if dtype == torch.float32 else 1.5e-2)
+    a3 = rnd(B * 14 * 14, m, seed=9).to(dtype)
+    r, e = both("patch_unfold", (a3, B, 2, 2, 7, m))
+    assert torch.equal(r.cpu(), e)
+    r2, e2 = both("patch_fold", (e, B, 2, 2, 7, m))
+    assert torch.equal(r2.cpu(), a3) and torch.equal(e2, a3)

@@ -40,7 +40,7 @@ def rel(a, b):
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-6))
 
 
-MICRO = [(0, "plain"), (0, "multi"), (0, "single"), (0, "hybrid")]
+MICRO = [(0, "plain"), (0, "multi"), (0, "single"), (0, "hybrid"), (4, "plain"), (4, "multi"), (5, "plain"), (5, "multi")]
 
 
 @pytest.mark.parametrize("et,mode", MICRO)
@@ -79,13 +79,18 @@ def test_micro_fp32_vs_reference_golden_and_oracle(et, mode):
         op = dict(orc.named_parameters())
         for n, p in prod.named_parameters():                # every parameter gradient vs the oracle
             assert rel(p.grad, op[n].grad) < 5e-4, (n, rel(p.grad, op[n].grad))
+        if et != 0 and (tag + "bn.conv1.running_mean") in g.files:
+            bsd = prod.state_dict()
+            for bn in ("conv1", "conv3"):
+                assert rel(bsd["patch_embed.%s.bn.running_mean" % bn], g[tag + "bn.%s.running_mean" % bn]) < 1e-4
+                assert rel(bsd["patch_embed.%s.bn.running_var" % bn], g[tag + "bn.%s.running_var" % bn]) < 1e-4
     prod.eval()
     prod.load_state_dict(sd)
     with torch.no_grad():
         assert rel(prod(xd), g["eval.cls"]) < 1e-4
 
 
-@pytest.mark.parametrize("et,mode", [(0, "plain"), (0, "multi")])
+@pytest.mark.parametrize("et,mode", [(0, "plain"), (0, "multi"), (4, "plain"), (5, "multi")])
 def test_micro_bf16_close_to_reference(et, mode):
     """bf16 fast mode: activations/weights rounded to bf16 inside the GEMMs -> ~1e-2 on logits (documented)."""
     g = np.load(os.path.join(G, "f1_micro_t%d_%s.npz" % (et, mode)))
@@ -107,7 +112,8 @@ def test_micro_bf16_close_to_reference(et, mode):
     for k in g.files:
         if k.startswith("e31.grad."):
             worst = max(worst, rel(params[k[9:]].grad, g[k]))
-    assert worst < 8e-2, worst
+    # conv stems add three bf16 convolutions + train-mode BatchNorm on 16-channel maps in front of the gradient path
+    assert worst < (8e-2 if et == 0 else 1.5e-1), worst
 
 
 def test_full_size_sr_tiny_supernet_fp32_vs_reference():
@@ -136,3 +142,29 @@ def test_full_size_sr_tiny_supernet_fp32_vs_reference():
     assert rel(pat[:, :, :8], g["pat_head8"]) < 1e-3
     loss = O.soft_target_ce(cls, t.to(DEV)) + O.soft_target_ce(pat, pt.to(DEV))
     assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
+
+
+def test_full_size_ref_tiny_c1_fp32_vs_reference():
+    """BASELINE config C1: ViT-Res-Tiny reference net (conv patch embedding, 42.8 M params), forward + SoftCE loss on a
+    2x3x224x224 batch -- logits/loss vs the reference itself (fp32 parity mode), plus eval-mode logits."""
+    g = np.load(os.path.join(G, "f4_ref_tiny_c1.npz"))
+    prod = vitres.create_model("flexible_vit_sr_patch14_224_patch_output", num_classes=1000,
+                               network_def=recipe.REF_TINY_DEF, drop_path_rate=0.0)
+    shapes = [(k, tuple(v.shape)) for k, v in prod.state_dict().items()]
+    assert [k for k, _ in shapes] == list(g["keys"]) and [str(s) for _, s in shapes] == list(g["shapes"])
+    sd = recipe.fill_state_dict(shapes, 4242)
+    assert recipe.checksum(sd) == int(g["state_crc"])
+    prod.load_state_dict(sd)
+    assert sum(p.numel() for p in prod.parameters()) == int(g["n_params"]) == 42781736
+    prod = prod.to(DEV).set_compute_dtype(torch.float32)
+    x, t, pt, _ = recipe.inputs(11, 2, 224, 1000, 16)
+    prod.train()
+    with torch.no_grad():
+        cls, pat = prod(x.to(DEV), patch_output_type="seq")
+    loss = O.soft_target_ce(cls, t.to(DEV)) + O.soft_target_ce(pat, pt.to(DEV))
+    assert rel(cls, g["cls"]) < 1e-3 and rel(pat, g["pat"]) < 1e-3, (rel(cls, g["cls"]), rel(pat, g["pat"]))
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
+    prod.load_state_dict(sd)
+    prod.eval()
+    with torch.no_grad():
+        assert rel(prod(x.to(DEV)), g["eval.cls"]) < 1e-3

@@ -39,7 +39,8 @@ def rel(a, b):
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-6))
 
 
-@pytest.mark.parametrize("et,mode", [(0, "plain"), (0, "multi"), (0, "single"), (0, "hybrid")])
+@pytest.mark.parametrize("et,mode", [(0, "plain"), (0, "multi"), (0, "single"), (0, "hybrid"), (4, "plain"), (4, "multi"),
+                                     (5, "plain"), (5, "multi")])
 def test_emulated_model_matches_oracle_and_golden(monkeypatch, et, mode):
     emu_kernels.install(monkeypatch)
     g = np.load(os.path.join(G, "f1_micro_t%d_%s.npz" % (et, mode)))
@@ -72,6 +73,10 @@ def test_emulated_model_matches_oracle_and_golden(monkeypatch, et, mode):
         for n, p in prod.named_parameters():
             assert p.grad is not None, n
             assert rel(p.grad, op[n].grad) < 2e-4, (n, rel(p.grad, op[n].grad))
+        if et != 0:                                                # BatchNorm running statistics (buffers)
+            ob = dict(orc.named_buffers())
+            for n, bf in prod.named_buffers():
+                assert rel(bf.float(), ob[n].float()) < 1e-5, n
     prod.eval()
     prod.load_state_dict(sd)
     with torch.no_grad():

@@ -17,9 +17,11 @@ import torch
 from . import kernels as K
 
 
-def _split_k(tokens):
-    """Number of contraction splits for a weight-gradient GEMM over `tokens` rows."""
-    return max(1, min(64, tokens // 512))
+def _split_k(tokens, n_out=128, k_in=128):
+    """Number of contraction splits for a weight-gradient GEMM over `tokens` rows: enough workgroups to fill
+    256 CUs a few times over, never fewer than ~512 tokens per split."""
+    tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+    return max(1, min(tokens // 512, max(1, 1024 // tiles)))
 
 
 class Weights:
@@ -33,7 +35,7 @@ class Weights:
 def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None, db=None):
     """dw[N_out, K_in] += dy[M, N_out]^T @ x[M, K_in]  (fp32 atomics, split over tokens)."""
     K.gemm(dy, x, dw, M=N_out, N=K_in, K=M, lda=lddy, ldb=ldx, ldc=ldw or K_in, a_trans=True, b_trans=True,
-           atomic=True, split_k=_split_k(M), a_map=a_map, b_map=b_map, bias_grad=db)
+           atomic=True, split_k=_split_k(M, N_out, K_in), a_map=a_map, b_map=b_map, bias_grad=db)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -186,3 +186,58 @@ def mask_rows(x, keep, rows_per_sample):
     M = x.numel() // C
     _lib.check(_lib.lib().vr_mask_rows(_p(x), _p(keep), M, C, rows_per_sample, _stream()), "vr_mask_rows")
     return x
+
+
+# ---- convolutional patch embedding (stem.hip) ---------------------------------------------------------------
+def im2col3x3_image(img, stride, ld, out_dtype):
+    B, C, H, W = img.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    col = torch.empty((B * Ho * Wo, ld), dtype=out_dtype, device=img.device)
+    _lib.check(_lib.lib().vr_im2col3x3(_p(img), _p(col), B, H, W, C, stride, 1, ld, _dtcode(out_dtype), _stream()),
+               "vr_im2col3x3")
+    return col
+
+
+def im2col3x3(a, B, H, W, C):
+    col = torch.empty((B * H * W, 9 * C), dtype=a.dtype, device=a.device)
+    _lib.check(_lib.lib().vr_im2col3x3(_p(a), _p(col), B, H, W, C, 1, 0, 9 * C, _dt(a), _stream()), "vr_im2col3x3")
+    return col
+
+
+def col2im3x3(dcol, B, H, W, C):
+    d = torch.empty((B * H * W, C), dtype=dcol.dtype, device=dcol.device)
+    _lib.check(_lib.lib().vr_col2im3x3(_p(dcol), _p(d), B, H, W, C, _dt(dcol), _stream()), "vr_col2im3x3")
+    return d
+
+
+def bn_stats(z, s, q):
+    R, C = z.shape
+    _lib.check(_lib.lib().vr_bn_stats(_p(z), _p(s), _p(q), R, C, _stream()), "vr_bn_stats")
+
+
+def bn_relu(z, scale, shift, res, out_dtype):
+    R, C = z.shape
+    out = torch.empty((R, C), dtype=out_dtype, device=z.device)
+    _lib.check(_lib.lib().vr_bn_relu(_p(z), _p(scale), _p(shift), _p(res), _p(out), R, C, _dtcode(out_dtype), _stream()),
+               "vr_bn_relu")
+    return out
+
+
+def bn_bwd(da, z, scale, shift, mean, rstd, sg, sgz, training):
+    R, C = z.shape
+    dz = torch.empty((R, C), dtype=da.dtype, device=z.device)
+    _lib.check(_lib.lib().vr_bn_bwd(_p(da), _p(z), _p(scale), _p(shift), _p(mean), _p(rstd), _p(sg), _p(sgz), _p(dz), R, C,
+                                    int(training), _dt(da), _stream()), "vr_bn_bwd")
+    return dz
+
+
+def patch_unfold(a, B, gh, gw, P, C):
+    col = torch.empty((B * gh * gw, P * P * C), dtype=a.dtype, device=a.device)
+    _lib.check(_lib.lib().vr_patch_unfold(_p(a), _p(col), B, gh, gw, P, C, 0, _dt(a), _stream()), "vr_patch_unfold")
+    return col
+
+
+def patch_fold(col, B, gh, gw, P, C):
+    a = torch.empty((B * gh * P * gw * P, C), dtype=col.dtype, device=col.device)
+    _lib.check(_lib.lib().vr_patch_unfold(_p(a), _p(col), B, gh, gw, P, C, 1, _dt(col), _stream()), "vr_patch_unfold")
+    return a

@@ -1,0 +1,132 @@
+"""Convolutional patch embedding (network_def embed types 4 and 5) on the HIP path.
+
+Reference: nets/patch_conv.py:23-73 -- conv1 (3x3/s2, 3->m) + BN + ReLU, conv2/conv3 (3x3, m->m) + BN + ReLU,
+residual from conv1's output, conv_proj (7x7/s7, m->C) -> tokens; then tokens/pos_embed/ChannelDrop as in
+nets/vit_sr_supernet.py:398-407.  Activations are NHWC [B*112*112, m] in the compute dtype, pre-BN conv outputs
+fp32; every convolution is a gather (vr_im2col3x3 / vr_patch_unfold) + vr_gemm.  BatchNorm uses batch statistics
+in training (and updates the running buffers exactly like nn.BatchNorm2d: momentum 0.1, unbiased running_var).
+"""
+import torch
+
+from . import functional as Fn
+from . import kernels as K
+
+
+def _perm_weight(conv, dt, ld=None):
+    """[out, in, kh, kw] -> [out, (kh, kw, in)] zero-padded to ld columns, compute dtype."""
+    w = conv.weight.detach()
+    o, k = w.shape[0], w.shape[1] * w.shape[2] * w.shape[3]
+    wp = w.permute(0, 2, 3, 1).reshape(o, k)
+    ld = ld or k
+    out = torch.zeros((o, ld), dtype=dt, device=w.device)
+    out[:, :k] = wp
+    return out
+
+
+def embed_params(model):
+    pe, dt = model.patch_embed, model.compute_dtype
+    m = pe.mid_chans
+    if m % 8:
+        raise NotImplementedError('conv patch embedding needs mid_chans % 8 == 0 on the HIP path (got %d)' % m)
+    wp = _perm_weight(pe.conv_proj, dt)
+    return {"w1": _perm_weight(pe.conv1.conv, dt, ld=32), "w2": _perm_weight(pe.conv2.conv, dt),
+            "w3": _perm_weight(pe.conv3.conv, dt),
+            "proj": Fn.Weights(pe.conv_proj.weight, pe.conv_proj.bias.detach(), wp, wp.shape[1]),
+            "pos": model.pos_embed.detach(), "tokens": model.tokens.detach()}
+
+
+def _bn_affine(z, bn, training):
+    """Folded BatchNorm: returns (scale, shift, mean, rstd) fp32 [C]; updates running stats in training."""
+    C = z.shape[1]
+    if training:
+        sq = torch.zeros((2, C), dtype=torch.float32, device=z.device)
+        K.bn_stats(z, sq[0], sq[1])
+        n = z.shape[0]
+        mean = sq[0] / n
+        var = (sq[1] / n - mean * mean).clamp_min_(0.)
+        with torch.no_grad():
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+            bn.num_batches_tracked += 1
+    else:
+        mean, var = bn.running_mean.detach().float(), bn.running_var.detach().float()
+    rstd = torch.rsqrt(var + bn.eps)
+    scale = bn.weight.detach() * rstd
+    shift = bn.bias.detach() - mean * scale
+    return scale.contiguous(), shift.contiguous(), mean.contiguous(), rstd.contiguous()
+
+
+def embed_conv_fwd(model, x, p, cfg, keep, save):
+    pe, dt = model.patch_embed, cfg["dtype"]
+    B, _, H, W = x.shape
+    m, C, P = pe.mid_chans, cfg["dim"], cfg["patches"]
+    Hm, Wm = H // 2, W // 2
+    R = B * Hm * Wm
+    g = Hm // (model.patch_size // 2)
+    N = P + 1
+    tr = model.training
+
+    def conv(col, w, ld):
+        z = torch.empty((R, m), dtype=torch.float32, device=x.device)
+        K.gemm(col, w, z, M=R, N=m, K=ld, lda=ld, ldb=ld, ldc=m)
+        return z
+    col1 = K.im2col3x3_image(x, 2, 32, dt)
+    z1 = conv(col1, p["w1"], 32)
+    bn1 = _bn_affine(z1, pe.conv1.bn, tr)
+    a1 = K.bn_relu(z1, bn1[0], bn1[1], None, dt)
+    col2 = K.im2col3x3(a1, B, Hm, Wm, m)
+    z2 = conv(col2, p["w2"], 9 * m)
+    bn2 = _bn_affine(z2, pe.conv2.bn, tr)
+    a2 = K.bn_relu(z2, bn2[0], bn2[1], None, dt)
+    col3 = K.im2col3x3(a2, B, Hm, Wm, m)
+    z3 = conv(col3, p["w3"], 9 * m)
+    bn3 = _bn_affine(z3, pe.conv3.bn, tr)
+    a3 = K.bn_relu(z3, bn3[0], bn3[1], a1, dt)
+    ps = model.patch_size // 2
+    colp = K.patch_unfold(a3, B, g, g, ps, m)
+    ldk = ps * ps * m
+    out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
+    K.gemm(colp, p["proj"].w_c, out, M=B * P, N=C, K=ldk, lda=ldk, ldb=ldk, ldc=C, bias=p["proj"].b,
+           pos=p["pos"][0, 1:], keep_n=keep, rows_in=P, c_map=(P, N, 1))
+    K.embed_cls(p["tokens"], p["pos"], out, keep)
+    saved = (col1, z1, bn1, col2, z2, bn2, col3, z3, bn3, colp, (B, Hm, Wm, m, g, ps, tr)) if save else None
+    return out, saved
+
+
+def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv):
+    pe, dt = model.patch_embed, cfg["dtype"]
+    col1, z1, bn1, col2, z2, bn2, col3, z3, bn3, colp, (B, Hm, Wm, m, g, ps, tr) = saved
+    dev = gx.device
+    _, N, C = gx.shape
+    P = N - 1
+    R = B * Hm * Wm
+    ldk = ps * ps * m
+    gt = K.scale_mask_cast(gx, None, keep, N, dt)
+    # conv_proj
+    wtmp = torch.zeros((C, ldk), dtype=torch.float32, device=dev)
+    Fn.linear_wgrad(gt, colp, wtmp, B * P, C, ldk, C, ldk, a_map=(P, N, 1), db=gv(pe.conv_proj.bias))
+    gv(pe.conv_proj.weight).copy_(wtmp.view(C, ps, ps, m).permute(0, 3, 1, 2))
+    K.batchsum(gx, gv(model.pos_embed))
+    dcolp = torch.empty((B * P, ldk), dtype=dt, device=dev)
+    K.gemm(gt, p["proj"].w_c, dcolp, M=B * P, N=ldk, K=C, lda=C, ldb=ldk, ldc=ldk, b_trans=True, a_map=(P, N, 1))
+    da3 = K.patch_fold(dcolp, B, g, g, ps, m)                      # d(relu(bn3) + a1)
+
+    def conv_bwd(da, z, bn, col, w, conv_mod, ld, need_dx):
+        sg = torch.zeros((2, m), dtype=torch.float32, device=dev)
+        dz = K.bn_bwd(da, z, bn[0], bn[1], bn[2], bn[3], sg[0], sg[1], tr)
+        gv(conv_mod.bn.weight).copy_(sg[1])
+        gv(conv_mod.bn.bias).copy_(sg[0])
+        wt = torch.zeros((m, ld), dtype=torch.float32, device=dev)
+        Fn.linear_wgrad(dz, col, wt, R, m, ld, m, ld)
+        cin = conv_mod.conv.weight.shape[1]
+        gv(conv_mod.conv.weight).copy_(wt[:, :9 * cin].reshape(m, 3, 3, cin).permute(0, 3, 1, 2))
+        if not need_dx:
+            return None
+        dcol = torch.empty((R, ld), dtype=dt, device=dev)
+        K.gemm(dz, w, dcol, M=R, N=ld, K=m, lda=m, ldb=ld, ldc=ld, b_trans=True)
+        return K.col2im3x3(dcol, B, Hm, Wm, m)
+    da2 = conv_bwd(da3, z3, bn3, col3, p["w3"], pe.conv3, 9 * m, True)
+    da1 = conv_bwd(da2, z2, bn2, col2, p["w2"], pe.conv2, 9 * m, True)
+    da1 = da1 + da3                                                 # residual branch (patch_conv.py:69)
+    conv_bwd(da1, z1, bn1, col1, p["w1"], pe.conv1, 32, False)
