@@ -1,0 +1,84 @@
+"""N > 1 data-parallel path on CPU: world_size 2 over gloo, kernels emulated (tests/emu_kernels.py).
+Checks the reference's DDP semantics (main.py:366-367): parameters broadcast from rank 0, gradients averaged over
+ranks, identical parameters on every rank after the optimizer step, per-rank seeds -> different sampled archs."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _Patch:
+    def setattr(self, obj, name, value, raising=True):
+        setattr(obj, name, value)
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "vit-search_amd"), HERE,
+              os.path.join(HERE, "golden"), os.path.join(os.path.dirname(HERE), "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emu_kernels
+    import recipe
+    import vitres
+    from vitres import engine
+    emu_kernels.install(_Patch())
+    torch.manual_seed(100 + rank)                      # reference: seed + rank (main.py:261-267)
+    model = vitres.create_model("flexible_vit_sr_patch14_224_patch_output_supernet", img_size=recipe.MICRO_IMG,
+                                num_classes=recipe.MICRO_CLASSES, network_def=recipe.MICRO_DEFS[0], drop_path_rate=0.0,
+                                num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30)
+    model.set_compute_dtype(torch.float32)
+    model._ensure_arena(torch.device("cpu"))
+    sync = engine.GradSync(model)
+    sync.broadcast_parameters()
+    p0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    model.train()
+    model.set_epoch(31)
+    x, t, pt, _ = recipe.inputs(500 + rank, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    crit = lambda a, b: torch.sum(-b * torch.log_softmax(a, -1), -1).mean()   # noqa: E731
+    # local gradients first (no exchange), then the real step from the same CPU RNG state (same masks)
+    rng = torch.random.get_rng_state()
+    cls, pat = model(x, patch_output_type="seq")
+    (crit(cls, t) + crit(pat, pt)).backward()
+    keeps = torch.stack(model.last_keeps).clone()
+    g_local = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    model.zero_grad(set_to_none=True)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    torch.random.set_rng_state(rng)
+    engine.train_step(model, crit, opt, x, t, pt, "seq", epoch=31, train_iter=0, arch_sample="multi", grad_sync=sync)
+    g_sync = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    p1 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    torch.save({"p0": p0, "p1": p1, "g_local": g_local, "g_sync": g_sync, "keeps": keeps},
+               os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(2))
+    assert torch.equal(r0["p0"], r1["p0"])                                # rank-0 parameters everywhere
+    assert not torch.equal(r0["keeps"], r1["keeps"])                      # different archs per rank (seed + rank)
+    assert torch.allclose(r0["g_sync"], r1["g_sync"], rtol=0, atol=0)     # identical after the all-reduce
+    assert torch.equal(r0["p1"], r1["p1"])                                # and identical parameters after the step
+    # the exchanged gradient is the mean of what each rank computes alone for ITS masks; the second forward of a rank
+    # re-samples from the same RNG state (train_step restores the CPU RNG), so local grads are comparable
+    mean = 0.5 * (r0["g_local"] + r1["g_local"])
+    err = float((r0["g_sync"] - mean).abs().max() / mean.abs().max())
+    assert err < 1e-5, err
