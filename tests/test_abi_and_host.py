@@ -1,0 +1,103 @@
+"""CPU checks: the C-ABI library loads and exports every symbol include/vitres_hip.h declares (no compute calls
+without a GPU); host-side data (search spaces, MAC estimator, sub-net slicing) against the reference's golden vectors."""
+import ast
+import os
+import re
+
+import numpy as np
+import torch
+
+import recipe
+import vitres
+from vitres import _lib, supernet_config
+from vitres.nets import net_utils
+from vitres.network_utils import ComputationEstimator
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "vitres_hip.h")).read()
+    declared = set(re.findall(r"^int\s+(vr_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.lib()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.vr_version() >= 1000
+
+
+def test_search_spaces_and_macs_match_reference():
+    g = np.load(os.path.join(G, "f6_schema_macs.npz"))
+    est = ComputationEstimator(distill=False, input_resolution=224, patch_size=14)
+    for name, nd in (("sr_tiny", recipe.SR_TINY_DEF), ("sr_small", recipe.SR_SMALL_DEF), ("sr_tiny_mh", recipe.SR_TINY_MH_DEF),
+                     ("sr_small_mh", recipe.SR_SMALL_MH_DEF)):
+        sp = getattr(supernet_config, name)
+        assert sp.network_def == nd
+        flat = []
+        for ent in sp.num_channels_to_keep:
+            if ent is None:
+                flat.append("None")
+            elif isinstance(ent, dict):
+                flat.append(str({k: (None if v is None else [int(a) for a in v]) for k, v in ent.items()}))
+            else:
+                flat.append(str([int(a) for a in ent]))
+        assert flat == list(g[name + ".choices"])
+        assert est(nd) == int(g[name + ".macs"])
+    assert est(recipe.REF_TINY_DEF) == int(g["ref_tiny.macs"]) == 1794400000 + (int(g["ref_tiny.macs"]) - 1794400000)
+    assert abs(est(recipe.REF_TINY_DEF) - 1.7944e9) < 1e5
+    est56 = ComputationEstimator(distill=False, input_resolution=56, patch_size=14)
+    for i, nd in enumerate(recipe.MICRO_CANDIDATES):
+        assert est56(nd) == int(g["micro_cand%d.macs" % i])
+
+
+def test_state_dict_schema_and_sub_state_dict():
+    g = np.load(os.path.join(G, "f6_schema_macs.npz"))
+    with torch.device("meta"):
+        m = vitres.create_model("flexible_vit_sr_patch14_224_patch_output", num_classes=1000, network_def=recipe.REF_TINY_DEF)
+    assert list(m.state_dict().keys()) == list(g["ref_tiny.keys"])
+    assert [str(tuple(v.shape)) for v in m.state_dict().values()] == list(g["ref_tiny.shapes"])
+    assert m.no_weight_decay() == {"tokens"}
+    g5 = np.load(os.path.join(G, "f5_subnet.npz"))
+    sup = vitres.create_model("flexible_vit_sr_patch14_224_patch_output_supernet", img_size=56, num_classes=10,
+                              network_def=recipe.MICRO_DEFS[0], num_channels_to_keep=recipe.micro_keep_config(),
+                              example_per_arch=2, num_warmup_epochs=30)
+    sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in sup.state_dict().items()], 100)
+    sup.load_state_dict(sd)
+    for i, nd in enumerate(recipe.MICRO_CANDIDATES):
+        sub = vitres.create_model("flexible_vit_sr_patch14_224_patch_output", img_size=56, num_classes=10, network_def=nd)
+        ssd = net_utils.get_sub_state_dict(sup.state_dict(), sub.state_dict())
+        assert recipe.checksum(ssd) == int(g5["cand%d.crc" % i])
+        sub.load_state_dict(ssd)
+
+
+def test_rewiring_matches_reference():
+    g = np.load(os.path.join(G, "f7_rewiring.npz"))
+    m = vitres.create_model("flexible_vit_sr_patch14_224_patch_output_supernet", img_size=56, num_classes=10,
+                            network_def=recipe.MICRO_DEFS[0], num_channels_to_keep=recipe.micro_keep_config(),
+                            example_per_arch=2, num_warmup_epochs=30)
+    m.load_state_dict(recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 100))
+    m.set_epoch(0)
+    after = m.state_dict()
+    n = 0
+    for k in g.files:
+        if k.startswith("blocks."):
+            assert np.array_equal(after[k].numpy(), g[k]), k
+            n += 1
+    assert n == 12
+
+
+def test_channel_drop_tables_and_rng_protocol():
+    from vitres.nets.channel_drop import ChannelDrop
+    g = np.load(os.path.join(G, "f3_channel_drop.npz"))
+    for ci, case in enumerate(g["cases"]):
+        choices, B, epa, warm, single = ast.literal_eval(str(case))
+        for e in (0, 8, 15, 30, 31):
+            cd = ChannelDrop(np.array(choices), num_warmup_epochs=warm, example_per_arch=epa, single_arch=single)
+            cd.train()
+            cd.set_epoch(e)
+            torch.manual_seed(1000 + ci * 10 + e)
+            draws = np.stack([cd.sample_keep(B, max(choices)).numpy() for _ in range(3)])
+            tag = "c%d.e%d." % (ci, e)
+            assert np.array_equal(draws, g[tag + "draws"])
+            assert list(cd.table.numpy()) == list(g[tag + "table"]) and cd.num_layer_config == int(g[tag + "nlc"])
