@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -147,9 +148,21 @@ def main():
     crit = SoftTargetCrossEntropy()
     arch = "multi" if w["space"] else None
 
-    def step(i):
+    def eager_step(i):
         return engine.train_step(model, crit, opt, x, t, pt, "seq", epoch=31, train_iter=i, arch_sample=arch,
                                  grad_sync=sync)
+
+    graphed = None
+    if not args.no_graph:
+        graphed = engine.GraphedTrainStep(model, crit, x, t, pt, "seq")
+
+    def step(i):
+        if graphed is None:
+            return eager_step(i)
+        loss = graphed(x, t, pt, epoch=31, train_iter=i, arch_sample=arch)     # fwd + loss + bwd (hipGraph replay)
+        sync.all_reduce_grads()
+        opt.step()
+        return loss
 
     for i in range(args.warmup):
         step(i)
@@ -181,7 +194,7 @@ def main():
     if args.profile_steps > 0:
         K.PROFILE = []
         for i in range(args.profile_steps):
-            step(10_000 + i)
+            eager_step(10_000 + i)
         torch.cuda.synchronize()
         agg = {}
         for kind, fl, by, e0, e1 in K.PROFILE:
@@ -213,7 +226,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": args.workload, "global_batch": B * world, "per_gpu_batch": B,
                    "example_per_arch": w["epa"], "epoch": 31, "drop_path": w["drop_path"], "parallelism": "dp%d" % world,
-                   "optimizer": "AdamW(torch fused)", "final_loss": round(lossv[-1], 4)},
+                   "optimizer": "AdamW(torch fused)", "hipgraph": graphed is not None, "final_loss": round(lossv[-1], 4)},
         "roofline": roof, "cpu_baseline": cpu,
     }
     print(json.dumps(out))

@@ -168,3 +168,40 @@ def test_full_size_ref_tiny_c1_fp32_vs_reference():
     prod.eval()
     with torch.no_grad():
         assert rel(prod(x.to(DEV)), g["eval.cls"]) < 1e-3
+
+
+def test_hipgraph_replay_matches_eager():
+    """engine.GraphedTrainStep (forward+loss+backward captured into a hipGraph, masks through a static buffer) gives the
+    same loss, masks and gradients as the eager path, iteration after iteration."""
+    from vitres import engine
+    from vitres.losses import SoftTargetCrossEntropy
+    prod, orc, sd = build_pair(0, "multi", 100)
+    prod.set_compute_dtype(torch.float32)
+    prod.train()
+    prod.set_epoch(31)
+    prod.load_state_dict(sd)
+    crit = SoftTargetCrossEntropy()
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1))
+    eager = []
+    for it in range(3):                                   # eager reference first; nothing of its autograd graph survives
+        torch.manual_seed(900 + it)
+        for p in prod.parameters():
+            p.grad = None
+        out = prod(x, patch_output_type="seq")
+        loss = crit(out[0], t) + crit(out[1], pt)
+        loss.backward()
+        eager.append((loss.item(), torch.stack(prod.last_keeps).clone(),
+                      {n: p.grad.detach().cpu().clone() for n, p in prod.named_parameters()}))
+        del out, loss
+    assert not torch.equal(eager[0][1], eager[1][1])      # different masks per iteration
+    for p in prod.parameters():
+        p.grad = None
+    graphed = engine.GraphedTrainStep(prod, crit, x, t, pt, "seq")
+    for it in range(3):
+        torch.manual_seed(900 + it)
+        loss_g = graphed(x, t, pt, epoch=31, train_iter=it, arch_sample=None).item()
+        loss_e, keeps_e, grads_e = eager[it]
+        assert torch.equal(torch.stack(prod.last_keeps), keeps_e)
+        assert abs(loss_g - loss_e) < 1e-5 * abs(loss_e)
+        for n, p in prod.named_parameters():
+            assert rel(p.grad, grads_e[n]) < 1e-4, n

@@ -248,10 +248,12 @@ constexpr size_t LDS_MAX = 160 * 1024;
 
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024) {
+    static size_t granted = 0;     // one instance per kernel type K; the driver call is idempotent
+    if (bytes > 64 * 1024 && bytes > granted) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)bytes);
         if (e != hipSuccess) return (int)e;
+        granted = bytes;
     }
     return 0;
 }

@@ -383,11 +383,15 @@ __global__ __launch_bounds__(NW * 64) void bwd_dkv_kernel(const bf16_t* __restri
 }
 
 // ---- host dispatch ---------------------------------------------------------------------------------------
+// Raising the dynamic-LDS limit is a per-function, idempotent driver call; it is made once per (kernel, size class)
+// so that later launches (e.g. under hipGraph stream capture) are pure stream work.
 template <typename K> static int set_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024) {
+    static size_t granted = 0;     // one instance per kernel type K
+    if (bytes > 64 * 1024 && bytes > granted) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)bytes);
         if (e != hipSuccess) return (int)e;
+        granted = bytes;
     }
     return 0;
 }

@@ -126,6 +126,67 @@ def train_step(model, criterion, optimizer, samples, targets, patch_targets=None
     return loss.detach()
 
 
+class GraphedTrainStep:
+    """forward + loss + backward of one iteration captured ONCE into a hipGraph and replayed every step
+    (the step issues ~600 kernel launches; replay removes their host cost).  What changes between iterations goes
+    through static device buffers: the batch, the soft targets, and the int32 keep rows of every ChannelDrop, which
+    are still sampled on the host with the reference's RNG protocol before each replay.  DropPath noise comes from
+    torch's graph-safe device generator.  The gradient exchange and the optimizer stay outside the graph."""
+
+    def __init__(self, model, criterion, samples, targets, patch_targets=None, patch_output_type=None, warmup=2):
+        self.model, self.criterion, self.pot = model, criterion, patch_output_type
+        self.x, self.t = samples.clone(), targets.clone()
+        self.pt = patch_targets.clone() if patch_targets is not None else None
+        B = samples.shape[0]
+        rng = torch.random.get_rng_state()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                              # eager warm-up (arena, LDS attributes, allocator)
+            for _ in range(warmup):
+                model.zero_grad(set_to_none=True)
+                self._loss(model(self.x, patch_output_type=self.pot)).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        plan = model.sample_plan(B)
+        self.keep_static = None
+        if plan.rows:
+            self.keep_static = torch.stack(plan.rows).to(torch.int32).to(samples.device)
+        model.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            plan.keep_dev = self.keep_static
+            self.loss = self._loss(model(self.x, patch_output_type=self.pot, plan=plan))
+            self.loss.backward()
+        self.loss = self.loss.detach()
+        torch.random.set_rng_state(rng)
+
+    def _loss(self, out):
+        if self.pt is None:
+            return self.criterion(out[0] if isinstance(out, tuple) else out, self.t)
+        cls_pred, patch_pred = out
+        return self.criterion(cls_pred, self.t) + self.criterion(patch_pred, self.pt if self.pot == 'seq' else self.t)
+
+    def __call__(self, samples, targets, patch_targets=None, epoch=0, train_iter=0, arch_sample=None):
+        rng = None
+        if arch_sample is not None:                                # engine.py:119-131
+            rng = torch.random.get_rng_state()
+            if arch_sample in ('single', 'hybrid'):
+                torch.manual_seed(epoch * 10000 + train_iter)
+            elif arch_sample != 'multi':
+                raise ValueError('arch_sample has invalid value {}.'.format(arch_sample))
+        plan = self.model.sample_plan(samples.shape[0])
+        if rng is not None:
+            torch.random.set_rng_state(rng)
+        if self.keep_static is not None:
+            self.keep_static.copy_(torch.stack(plan.rows).to(torch.int32).pin_memory(), non_blocking=True)
+        if samples.data_ptr() != self.x.data_ptr():
+            self.x.copy_(samples, non_blocking=True)
+            self.t.copy_(targets, non_blocking=True)
+            if self.pt is not None:
+                self.pt.copy_(patch_targets, non_blocking=True)
+        self.graph.replay()
+        return self.loss
+
+
 def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler=None, max_norm=0,
                     model_ema=None, mixup_fn=None, print_freq=100, teacher_model=None, hard_distill=True, alpha=0.5,
                     logger=None, arch_sample=False, patch_mixup_fn=None, grad_sync=None, sync_every=1):

@@ -95,10 +95,10 @@ class SpatialReductionPatchEmbedding(nn.Module):
 
 class _Plan:
     """Host-side description of one forward: which keep vector / drop-path scale each layer uses."""
-    __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch")
+    __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch", "n_dp")
 
     def __init__(self):
-        self.rows, self.layers, self.keep_dev, self.head, self.scales, self.batch = [], [], None, None, None, 0
+        self.rows, self.layers, self.keep_dev, self.head, self.scales, self.batch, self.n_dp = [], [], None, None, None, 0, 0
 
     def add(self, keep):
         if keep is None:
@@ -329,7 +329,9 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         return a["gcur"][off:off + n].view(p.shape)
 
     # ---- host-side mask plan -----------------------------------------------------------------------
-    def _make_plan(self, B, device):
+    def sample_plan(self, B):
+        """Host side of one forward: sample every ChannelDrop (reference RNG protocol, call order) and lay out which
+        keep row / drop-path scale each layer uses.  No device work -- see _upload_plan."""
         plan = _Plan()
         plan.batch = B
         tr = self.training
@@ -372,21 +374,33 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 plan.layers.append(None)
                 layer_keep = None
         plan.head = e_idx
-        if plan.rows:
-            host = torch.stack(plan.rows).to(torch.int32)
-            plan.keep_dev = host.to(device, non_blocking=True)
-        if n_dp:
-            kp = []
-            for blk in self.blocks:
-                if isinstance(blk, Block) and not isinstance(blk.drop_path, nn.Identity) and blk.drop_path.drop_prob > 0:
-                    kp += [1.0 - blk.drop_path.drop_prob] * 2
-            kp = torch.tensor(kp, dtype=torch.float32, device=device).unsqueeze(1)
-            plan.scales = torch.floor(kp + torch.rand(n_dp, B, device=device)) / kp
+        plan.n_dp = n_dp
         self.last_keeps = log
         return plan
 
+    def _upload_plan(self, plan, device):
+        """Device side of a plan: one H2D copy of all keep rows (unless a static buffer was attached, e.g. by a
+        captured hipGraph) and the drop-path scale vectors."""
+        B = plan.batch
+        if plan.rows and plan.keep_dev is None:
+            host = torch.stack(plan.rows).to(torch.int32)
+            if device.type == 'cuda':
+                host = host.pin_memory()
+            plan.keep_dev = host.to(device, non_blocking=True)
+        if plan.n_dp and plan.scales is None:
+            kp = getattr(self, "_dp_keep_prob", None)
+            if kp is None or kp.device != device or kp.shape[0] != plan.n_dp:      # built once (not under graph capture)
+                vals = []
+                for blk in self.blocks:
+                    if isinstance(blk, Block) and not isinstance(blk.drop_path, nn.Identity) and blk.drop_path.drop_prob > 0:
+                        vals += [1.0 - blk.drop_path.drop_prob] * 2
+                kp = torch.tensor(vals, dtype=torch.float32).unsqueeze(1).to(device)
+                self._dp_keep_prob = kp
+            plan.scales = torch.floor(kp + torch.rand(plan.n_dp, B, device=device)) / kp
+        return plan
+
     # ---- forward -----------------------------------------------------------------------------------
-    def forward(self, x, patch_output_type=None):
+    def forward(self, x, patch_output_type=None, plan=None):
         if _REQUIRE_CUDA and not x.is_cuda:
             raise RuntimeError('vitres runs on MI355X through libvitres_hip.so only; got a %s tensor '
                                '(the CPU restatement lives in oracle/ and is test infrastructure)' % x.device)
@@ -397,7 +411,9 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             raise ValueError()
         self._ensure_arena(x.device)
         with_patch = bool(self.patch_output and self.training)
-        plan = self._make_plan(x.shape[0], x.device)
+        if plan is None:
+            plan = self.sample_plan(x.shape[0])
+        self._upload_plan(plan, x.device)
         params = self._arena["params"]
         out = _ViTResFn.apply(self, x.contiguous().float(), plan, with_patch, *params)
         return out
