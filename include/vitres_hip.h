@@ -54,10 +54,15 @@ typedef struct vr_rowmap {
  *   dgrad     dx = dy W      : a_trans 0, b_trans 1      (B = W viewed as [K_out rows][N_in contraction])
  *   wgrad     dW = dy^T x    : a_trans 1, b_trans 1, contraction over tokens, split_k > 1, atomic = 1
  * Epilogue, in this order:  v = acc (+ bias[n]) (+ pos[m % rows_in][n]);
- *   act==1: C gets the pre-activation u=v, C2 gets gelu(u) (masked by keep_n);   (Mlp.forward)
+ *   act==1: C gets the pre-activation u=v, C2 gets gelu(u), both 0 where masked by keep_n;   (Mlp.forward)
  *   dact_u != NULL: v *= gelu'(u[m][n]);                                          (fc2 dgrad -> du)
  *   keep_n: v = 0 where n >= keep_n[sample(m)];  scale: v *= scale[sample(m)];   (ChannelDrop, DropPath)
  *   resid != NULL: v += resid[out_row][n] (fp32, ldc layout);  atomic: atomicAdd into fp32 C.
+ * Masked-work skipping (the supernet's sampled sub-networks): keep_k[s] promises that A[m, k] == 0 for
+ * rows m of sample s and (k % k_period) >= keep_k[s]; K slices with no kept k for any sample of the tile are not
+ * loaded, and output tiles with no kept column (keep_n) skip their whole K loop (they still store the masked value).
+ * In wgrad form the samples are those of the token range of the split: keep_k bounds the kept output ROWS, keep_n the
+ * kept output COLUMNS (rows/columns beyond are exactly zero gradients); fully masked tiles are not computed.
  */
 typedef struct vr_gemm_args {
     const void* A;
@@ -70,6 +75,7 @@ typedef struct vr_gemm_args {
     const int32_t* keep_n; /* [batch] or NULL */
     const float* resid;  /* fp32 [*, ldc] or NULL (may alias C for in-place accumulate) */
     const void* dact_u;  /* pre-activation for gelu' (dtype = in_dtype, leading dim ldu) or NULL */
+    const int32_t* keep_k; /* [batch] or NULL: work-skipping hint, see below */
     float* bias_grad;    /* wgrad only (a_trans && atomic): bias_grad[m] += sum_k A[k][m]  (the Linear's bias gradient,
                             fused so that dY is read once), or NULL */
     int32_t M, N, K;
@@ -80,7 +86,9 @@ typedef struct vr_gemm_args {
     int32_t act;         /* 0 none, 1 gelu dual store */
     int32_t atomic;      /* 1: atomicAdd fp32 */
     int32_t split_k;     /* >= 1 */
-    int32_t rows_in;     /* rows per sample of the M index (0: single sample) */
+    int32_t rows_in;     /* rows per sample of the M index (0: single sample); wgrad: tokens per sample of the K index */
+    int32_t n_period;    /* > 0: column n is kept iff (n % n_period) < keep_n[s] (per-head prefixes of the qkv layout) */
+    int32_t k_period;    /* same for keep_k */
     vr_rowmap a_map;     /* remap of A's token rows (M index if a_trans==0, K index if a_trans==1) */
     vr_rowmap b_map;     /* remap of B's token rows (only meaningful when b_trans==1 && a_trans==1) */
     vr_rowmap c_map;     /* remap of output rows */

@@ -24,7 +24,8 @@ def _flat2d(t, ld):
 
 def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
          scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
-         a_map=None, b_map=None, c_map=None, bias_grad=None):
+         a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0):
+    # keep_k / k_period are pure work-skipping hints (the skipped operands are zero by contract): ignored here
     A2, B2 = _flat2d(a, lda), _flat2d(b, ldb)
     if not a_trans:
         Am = A2[_rows(M, a_map)][:, :K].float()
@@ -37,6 +38,8 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     v = Am @ Bm.t()
     if bias_grad is not None:
         bias_grad += Am.sum(dim=1)
+    if atomic and a_trans:                  # wgrad form: rows_in / keep_* describe the contraction tokens (hints only)
+        rows_in, keep_n, scale = 0, None, None
     m_idx = torch.arange(M)
     sample = (m_idx // rows_in) if rows_in > 0 else torch.zeros(M, dtype=torch.long)
     mloc = (m_idx % rows_in) if rows_in > 0 else m_idx
@@ -45,10 +48,12 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     if pos is not None:
         v = v + _flat2d(pos, N)[mloc]
     keep = keep_n.long()[sample] if keep_n is not None else torch.full((M,), N)
-    nmask = torch.arange(N)[None, :] < keep[:, None]
+    ncol = torch.arange(N) % n_period if n_period > 0 else torch.arange(N)
+    nmask = ncol[None, :] < keep[:, None]
     orow = _rows(M, c_map)
     C2d = _flat2d(out, ldc)
     if act == 1:
+        v = torch.where(nmask, v, torch.zeros_like(v))
         C2d[orow, :N] = v.to(out.dtype)
         h = torch.where(nmask, F.gelu(v), torch.zeros_like(v))
         _flat2d(out2, ldc)[orow, :N] = h.to(out.dtype)

@@ -284,3 +284,49 @@ def test_stem_kernels(dtype):
     assert torch.equal(r.cpu(), e)
     r2, e2 = both("patch_fold", (e, B, 2, 2, 7, m))
     assert torch.equal(r2.cpu(), a3) and torch.equal(e2, a3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_masked_work_skipping(dtype):
+    """keep_k / keep_n / periods only skip work that is zero by contract: results equal the dense statement."""
+    B, Nt, C, H, D = 6, 65, 256, 4, 64
+    HD, M = H * D, 6 * 65
+    g = torch.Generator().manual_seed(3)
+    ek = torch.tensor([256, 160, 256, 64, 192, 160], dtype=torch.int32)          # embed keep per sample
+    ak = torch.tensor([256, 128, 64, 192, 128, 256], dtype=torch.int32)          # head-prefix keep (multiples of D)
+    rowmask = lambda keep, width, period=0: ((torch.arange(width) % period if period else torch.arange(width))[None, :]
+                                             < keep.long().repeat_interleave(Nt)[:, None])
+    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+    # forward qkv: A = y masked by ek, columns kept per head prefix
+    y = (rnd(M, C, seed=1) * rowmask(ek, C)).to(dtype)
+    w = rnd(3 * HD, C, seed=2, scale=C ** -0.5).to(dtype)
+    bias = rnd(3 * HD, seed=3)
+    kw = dict(M=M, N=3 * HD, K=C, lda=C, ldb=C, ldc=3 * HD, bias=bias, rows_in=Nt, keep_k=ek, keep_n=ak, n_period=HD)
+    ref = E.gemm(y, w, torch.zeros(M, 3 * HD, dtype=dtype), **kw)
+    real = K.gemm(y.to(DEV), w.to(DEV), torch.full((M, 3 * HD), 7.0, dtype=dtype, device=DEV), **{k: to(v) for k, v in kw.items()})
+    assert relerr(real, ref) < tol(dtype)
+    # dgrad through qkv: A = dqkv zero in dropped heads (periodic k skipping), output masked by ek
+    dqkv = (rnd(M, 3 * HD, seed=4) * rowmask(ak, 3 * HD, HD)).to(dtype)
+    kw = dict(M=M, N=C, K=3 * HD, lda=3 * HD, ldb=C, ldc=C, b_trans=True, rows_in=Nt, keep_k=ak, k_period=HD, keep_n=ek)
+    ref = E.gemm(dqkv, w, torch.zeros(M, C, dtype=dtype), **kw)
+    real = K.gemm(dqkv.to(DEV), w.to(DEV), torch.full((M, C), 7.0, dtype=dtype, device=DEV), **{k: to(v) for k, v in kw.items()})
+    assert relerr(real, ref) < tol(dtype)
+    # wgrad: dW[3HD, C] += dqkv^T y with row (periodic) and column keeps, bias gradient fused
+    out = torch.zeros(3 * HD, C)
+    bg_ref, bg = torch.zeros(3 * HD), torch.zeros(3 * HD, device=DEV)
+    kw = dict(M=3 * HD, N=C, K=M, lda=3 * HD, ldb=C, ldc=C, a_trans=True, b_trans=True, atomic=True, split_k=6, rows_in=Nt,
+              keep_k=ak, k_period=HD, keep_n=ek)
+    ref = E.gemm(dqkv, y, out.clone(), bias_grad=bg_ref, **kw)
+    real = K.gemm(dqkv.to(DEV), y.to(DEV), out.to(DEV), bias_grad=bg, **{k: to(v) for k, v in kw.items()})
+    assert relerr(real, ref) < (5e-5 if dtype == torch.float32 else 1.2e-2)
+    assert relerr(bg, bg_ref) < 2e-4
+    # residual epilogue with a fully masked sample (layer drop: keep 0) and prefix keep_k
+    ok = torch.tensor([256, 0, 256, 64, 0, 160], dtype=torch.int32)
+    o = (rnd(M, HD, seed=5) * rowmask(ak, HD)).to(dtype)
+    wp = rnd(C, HD, seed=6, scale=HD ** -0.5).to(dtype)
+    resid = rnd(M, C, seed=7) * rowmask(ek, C)
+    scale = torch.tensor([1.25, 1.25, 0.0, 1.25, 1.25, 1.0])
+    kw = dict(M=M, N=C, K=HD, lda=HD, ldb=HD, ldc=C, bias=rnd(C, seed=8), scale=scale, keep_n=ok, resid=resid, rows_in=Nt, keep_k=ak)
+    ref = E.gemm(o, wp, torch.zeros(M, C), **kw)
+    real = K.gemm(o.to(DEV), wp.to(DEV), torch.full((M, C), 7.0, device=DEV), **{k: to(v) for k, v in kw.items()})
+    assert relerr(real, ref) < tol(dtype)

@@ -16,16 +16,28 @@
 // rows of per-sample metadata per lane.
 // Global loads are never predicated (hipcc waits vmcnt(0) around a branched load): addresses are clamped and the
 // value is selected afterwards; all addressing is hoisted out of the K loop as 32-bit byte offsets.
+#include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "../../include/vitres_hip.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, NTHR = 256;
 constexpr int LROW = 144;  // padded LDS row, bytes (128-byte K-slice payload)
-constexpr int TILE_BYTES = BM * LROW;
+
+// Workgroup tile = WR x WC waves, each wave MI x NI MFMA tiles of 32x32.
+//   Std : 2x2 waves of 64x64   -> 128x128, 256 threads, 72 KB LDS (2 workgroups / CU)
+//   Big : 2x4 waves of 128x64  -> 256x256, 512 threads, 144 KB LDS (1 workgroup / CU): half the global->LDS bytes per
+//         MAC; the K loop of the Std tile is bound by the CU's load path (~17 B/clk measured), not by MFMA or HBM.
+template <int WR_, int WC_, int MI_, int NI_> struct TileCfg {
+    static constexpr int WR = WR_, WC = WC_, MI = MI_, NI = NI_;
+    static constexpr int BM = WR * MI * 32, BN = WC * NI * 32, NTHR = WR * WC * 64;
+    static constexpr int A_BYTES = BM * LROW, B_BYTES = BN * LROW, BUF_BYTES = A_BYTES + B_BYTES;
+};
+typedef TileCfg<2, 2, 2, 2> CfgStd;
+typedef TileCfg<2, 4, 4, 2> CfgBig;
 
 template <typename T> struct Cfg;
 template <> struct Cfg<bf16_t> {
@@ -37,27 +49,32 @@ template <> struct Cfg<float> {
     static constexpr int EPC = 4;
 };
 
+struct Stage {          // one K slice of one operand in flight: 64 bytes per thread
+    uint4 v[4];
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // K-contiguous operand: tile row = 8 chunks of 16 B; thread t: chunk t&7, rows (t>>3) + 32h.
 // ---------------------------------------------------------------------------------------------------------
-template <typename T> struct LoaderN {
+template <typename T, int ROWS, int NTHR> struct LoaderN {
+    static constexpr int RPP = NTHR / 8;   // rows per pass; ROWS / RPP == 4 passes for both tile configs
+    static_assert(ROWS / RPP == 4, "loader shape");
     const char* base;
     uint32_t off[4];  // byte offset of (row, this thread's chunk) at k = 0; out-of-range rows are clamped to row 0
     bool rok[4];
     int kchunk;       // element offset of this thread's chunk inside a K slice
-    uint4 v[4];
 
     __device__ __forceinline__ void init(const T* p, int ld, const RowMap& rm, int r0, int R, int t) {
         base = reinterpret_cast<const char*>(p);
         kchunk = (t & 7) * Cfg<T>::EPC;
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const int r = r0 + (t >> 3) + 32 * h;
+            const int r = r0 + (t >> 3) + RPP * h;
             rok[h] = r < R;
             off[h] = (uint32_t)((map_row(rm, rok[h] ? r : 0) * (long long)ld + kchunk) * (long long)sizeof(T));
         }
     }
-    __device__ __forceinline__ void gload(int k0, int kend, int) {
+    __device__ __forceinline__ void gload(Stage& s, int k0, int kend, int) const {
         const bool kok = (k0 + kchunk) < kend;
         const uint32_t kb = (uint32_t)k0 * (uint32_t)sizeof(T);
         const uint32_t back = (uint32_t)(kchunk * (int)sizeof(T));
@@ -66,13 +83,13 @@ template <typename T> struct LoaderN {
             const uint32_t o = kok ? off[h] + kb : off[h] - back;       // clamp to the row start: always readable
             uint4 x = *reinterpret_cast<const uint4*>(base + o);
             if (!(kok && rok[h])) x = make_uint4(0, 0, 0, 0);
-            v[h] = x;
+            s.v[h] = x;
         }
     }
-    __device__ __forceinline__ void lstore(char* tile, int t) const {
+    __device__ __forceinline__ void lstore(const Stage& s, char* tile, int t) const {
 #pragma unroll
         for (int h = 0; h < 4; ++h)
-            *reinterpret_cast<uint4*>(tile + ((t >> 3) + 32 * h) * LROW + (t & 7) * 16) = v[h];
+            *reinterpret_cast<uint4*>(tile + ((t >> 3) + RPP * h) * LROW + (t & 7) * 16) = s.v[h];
     }
 };
 
@@ -81,27 +98,29 @@ template <typename T> struct LoaderN {
 //   bf16: thread t owns row pair 2*(t&63), k-octets (t>>6) + 4h (h = 0,1): 16 dword loads, 256 B per wave-load
 //   fp32: thread t owns row t&127, k-quads (t>>7) + 2h (h = 0..3): 16 dword loads
 // ---------------------------------------------------------------------------------------------------------
-template <typename T> struct LoaderT;
+template <typename T, int ROWS, int NTHR> struct LoaderT;
 
-template <> struct LoaderT<bf16_t> {
+template <int ROWS, int NTHR> struct LoaderT<bf16_t, ROWS, NTHR> {
+    static constexpr int NP = ROWS / 2;          // row pairs
+    static constexpr int OPP = NTHR / NP;        // k-octets per pass (4)
+    static_assert(OPP == 4, "loader shape");
     const char* base;
     uint32_t coloff, ldb;
     bool rok, ident;
     RowMap rm;
-    uint4 v[2][2];
     __device__ __forceinline__ void init(const bf16_t* p, int ld, const RowMap& m, int r0, int R, int t) {
         base = reinterpret_cast<const char*>(p);
-        const int r = r0 + 2 * (t & 63);
+        const int r = r0 + 2 * (t % NP);
         rok = r < R;
         coloff = (uint32_t)((rok ? r : 0) * 2);
         ldb = (uint32_t)ld * 2u;
         rm = m;
         ident = m.rpi == 0;
     }
-    __device__ __forceinline__ void gload(int k0, int kend, int t) {
+    __device__ __forceinline__ void gload(Stage& s, int k0, int kend, int t) const {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int kb = k0 + 8 * ((t >> 6) + 4 * h);
+            const int kb = k0 + 8 * ((t / NP) + OPP * h);
             uint32_t w[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -112,18 +131,18 @@ template <> struct LoaderT<bf16_t> {
                 const uint32_t x = *reinterpret_cast<const uint32_t*>(base + o + coloff);
                 w[e] = ok ? x : 0u;
             }
-            v[h][0] = make_uint4((w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16),
+            s.v[2 * h] = make_uint4((w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16),
                                  (w[4] & 0xffffu) | (w[5] << 16), (w[6] & 0xffffu) | (w[7] << 16));
-            v[h][1] = make_uint4((w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u),
+            s.v[2 * h + 1] = make_uint4((w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u),
                                  (w[4] >> 16) | (w[5] & 0xffff0000u), (w[6] >> 16) | (w[7] & 0xffff0000u));
         }
     }
     // running sums over the contraction index of this thread's two rows (fused bias gradient of the wgrad)
-    __device__ __forceinline__ void rowsum(float (&rs)[2]) const {
+    __device__ __forceinline__ void rowsum(const Stage& s, float (&rs)[2]) const {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const uint32_t a[4] = {v[h][0].x, v[h][0].y, v[h][0].z, v[h][0].w};
-            const uint32_t b[4] = {v[h][1].x, v[h][1].y, v[h][1].z, v[h][1].w};
+            const uint32_t a[4] = {s.v[2 * h].x, s.v[2 * h].y, s.v[2 * h].z, s.v[2 * h].w};
+            const uint32_t b[4] = {s.v[2 * h + 1].x, s.v[2 * h + 1].y, s.v[2 * h + 1].z, s.v[2 * h + 1].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 rs[0] += __uint_as_float(a[e] << 16) + __uint_as_float(a[e] & 0xffff0000u);
@@ -133,41 +152,42 @@ template <> struct LoaderT<bf16_t> {
     }
     // rs -> bias_grad[r0 + ...] : 4 waves hold different k-octets of the same 128 rows
     __device__ __forceinline__ void rowsum_flush(const float (&rs)[2], float* red, float* out, int r0, int R, int t) const {
-        red[(t >> 6) * 128 + 2 * (t & 63)] = rs[0];
-        red[(t >> 6) * 128 + 2 * (t & 63) + 1] = rs[1];
+        red[(t / NP) * ROWS + 2 * (t % NP)] = rs[0];
+        red[(t / NP) * ROWS + 2 * (t % NP) + 1] = rs[1];
         __syncthreads();
-        if (t < 128 && r0 + t < R) atomicAdd(out + r0 + t, red[t] + red[128 + t] + red[256 + t] + red[384 + t]);
+        if (t < ROWS && r0 + t < R) atomicAdd(out + r0 + t, red[t] + red[ROWS + t] + red[2 * ROWS + t] + red[3 * ROWS + t]);
     }
-    __device__ __forceinline__ void lstore(char* tile, int t) const {
-        const int r = 2 * (t & 63);
+    __device__ __forceinline__ void lstore(const Stage& s, char* tile, int t) const {
+        const int r = 2 * (t % NP);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int o = (t >> 6) + 4 * h;
-            *reinterpret_cast<uint4*>(tile + r * LROW + o * 16) = v[h][0];
-            *reinterpret_cast<uint4*>(tile + (r + 1) * LROW + o * 16) = v[h][1];
+            const int o = (t / NP) + OPP * h;
+            *reinterpret_cast<uint4*>(tile + r * LROW + o * 16) = s.v[2 * h];
+            *reinterpret_cast<uint4*>(tile + (r + 1) * LROW + o * 16) = s.v[2 * h + 1];
         }
     }
 };
 
-template <> struct LoaderT<float> {
+template <int ROWS, int NTHR> struct LoaderT<float, ROWS, NTHR> {
+    static constexpr int QPP = NTHR / ROWS;      // k-quads per pass (2)
+    static_assert(QPP == 2, "loader shape");
     const char* base;
     uint32_t coloff, ldb;
     bool rok, ident;
     RowMap rm;
-    uint4 v[4];
     __device__ __forceinline__ void init(const float* p, int ld, const RowMap& m, int r0, int R, int t) {
         base = reinterpret_cast<const char*>(p);
-        const int r = r0 + (t & 127);
+        const int r = r0 + (t % ROWS);
         rok = r < R;
         coloff = (uint32_t)((rok ? r : 0) * 4);
         ldb = (uint32_t)ld * 4u;
         rm = m;
         ident = m.rpi == 0;
     }
-    __device__ __forceinline__ void gload(int k0, int kend, int t) {
+    __device__ __forceinline__ void gload(Stage& s, int k0, int kend, int t) const {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const int kb = k0 + 4 * ((t >> 7) + 2 * h);
+            const int kb = k0 + 4 * ((t / ROWS) + QPP * h);
             uint32_t w[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -178,64 +198,66 @@ template <> struct LoaderT<float> {
                 const uint32_t x = *reinterpret_cast<const uint32_t*>(base + o + coloff);
                 w[e] = ok ? x : 0u;
             }
-            v[h] = make_uint4(w[0], w[1], w[2], w[3]);
+            s.v[h] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
-    __device__ __forceinline__ void rowsum(float (&rs)[2]) const {
+    __device__ __forceinline__ void rowsum(const Stage& s, float (&rs)[2]) const {
 #pragma unroll
         for (int h = 0; h < 4; ++h)
-            rs[0] += (__uint_as_float(v[h].x) + __uint_as_float(v[h].y)) + (__uint_as_float(v[h].z) + __uint_as_float(v[h].w));
+            rs[0] += (__uint_as_float(s.v[h].x) + __uint_as_float(s.v[h].y)) + (__uint_as_float(s.v[h].z) + __uint_as_float(s.v[h].w));
     }
     __device__ __forceinline__ void rowsum_flush(const float (&rs)[2], float* red, float* out, int r0, int R, int t) const {
-        red[(t >> 7) * 128 + (t & 127)] = rs[0];
+        red[(t / ROWS) * ROWS + (t % ROWS)] = rs[0];
         __syncthreads();
-        if (t < 128 && r0 + t < R) atomicAdd(out + r0 + t, red[t] + red[128 + t]);
+        if (t < ROWS && r0 + t < R) atomicAdd(out + r0 + t, red[t] + red[ROWS + t]);
     }
-    __device__ __forceinline__ void lstore(char* tile, int t) const {
-        const int r = t & 127;
+    __device__ __forceinline__ void lstore(const Stage& s, char* tile, int t) const {
+        const int r = t % ROWS;
 #pragma unroll
-        for (int h = 0; h < 4; ++h) *reinterpret_cast<uint4*>(tile + r * LROW + ((t >> 7) + 2 * h) * 16) = v[h];
+        for (int h = 0; h < 4; ++h) *reinterpret_cast<uint4*>(tile + r * LROW + ((t / ROWS) + QPP * h) * 16) = s.v[h];
     }
 };
 
-// ---- LDS -> MFMA (transposed tile: first operand = B fragment) -------------------------------------------
-template <bool SWAP>
-__device__ __forceinline__ void mma_tile(f32x16 (&acc)[2][2], const char* As, const char* Bs, int wm, int wn, int lane,
+// ---- LDS -> MFMA (SWAP: transposed tile, first operand = B fragment) ------------------------------------------
+template <bool SWAP, int MI, int NI>
+__device__ __forceinline__ void mma_tile(f32x16 (&acc)[MI][NI], const char* As, const char* Bs, int wm, int wn, int lane,
                                          bf16_t*) {
     typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
     const int rr = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        bfv8 a[2], b[2];
+        bfv8 a[MI], b[NI];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            a[i] = *reinterpret_cast<const bfv8*>(As + (wm * 64 + i * 32 + rr) * LROW + (ks * 2 + kh) * 16);
-            b[i] = *reinterpret_cast<const bfv8*>(Bs + (wn * 64 + i * 32 + rr) * LROW + (ks * 2 + kh) * 16);
-        }
+        for (int i = 0; i < MI; ++i)
+            a[i] = *reinterpret_cast<const bfv8*>(As + (wm * MI * 32 + i * 32 + rr) * LROW + (ks * 2 + kh) * 16);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NI; ++j)
+            b[j] = *reinterpret_cast<const bfv8*>(Bs + (wn * NI * 32 + j * 32 + rr) * LROW + (ks * 2 + kh) * 16);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
                 acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0)
                                  : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
 }
-template <bool SWAP>
-__device__ __forceinline__ void mma_tile(f32x16 (&acc)[2][2], const char* As, const char* Bs, int wm, int wn, int lane,
+template <bool SWAP, int MI, int NI>
+__device__ __forceinline__ void mma_tile(f32x16 (&acc)[MI][NI], const char* As, const char* Bs, int wm, int wn, int lane,
                                          float*) {
     const int rr = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-        float a[2], b[2];
+        float a[MI], b[NI];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            a[i] = *reinterpret_cast<const float*>(As + (wm * 64 + i * 32 + rr) * LROW + (ks * 2 + kh) * 4);
-            b[i] = *reinterpret_cast<const float*>(Bs + (wn * 64 + i * 32 + rr) * LROW + (ks * 2 + kh) * 4);
-        }
+        for (int i = 0; i < MI; ++i)
+            a[i] = *reinterpret_cast<const float*>(As + (wm * MI * 32 + i * 32 + rr) * LROW + (ks * 2 + kh) * 4);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NI; ++j)
+            b[j] = *reinterpret_cast<const float*>(Bs + (wn * NI * 32 + j * 32 + rr) * LROW + (ks * 2 + kh) * 4);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
                 acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0)
                                  : __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
@@ -272,6 +294,21 @@ template <typename TI> __device__ __forceinline__ void load4(const void* base, l
     }
 }
 
+__device__ __forceinline__ bool kept_col(int n, int period, int keep) { return (period > 0 ? n % period : n) < keep; }
+// does [x0, x0 + len) contain an index with (x % period) < keep ?
+__device__ __forceinline__ bool range_has_kept(int x0, int len, int period, int keep) {
+    if (keep <= 0) return false;
+    if (period <= 0) return x0 < keep;
+    const int r = x0 % period;
+    return r < keep || r + len > period;
+}
+__device__ __forceinline__ int max_keep(const int* keep, int s_lo, int s_hi, int dense) {
+    if (!keep) return dense;
+    int mk = 0;
+    for (int s = s_lo; s <= s_hi; ++s) mk = max(mk, keep[s]);
+    return mk;
+}
+
 // Epilogue flavours (compile-time, keeps every instantiation small enough to unroll fully):
 //   EPI_STORE : (+bias)(+pos) -> keep mask -> scale -> (+resid) -> store TO
 //   EPI_GELU  : (+bias) -> C = u, C2 = gelu(u) masked by keep            (Mlp.fc1)
@@ -279,181 +316,462 @@ template <typename TI> __device__ __forceinline__ void load4(const void* base, l
 //   EPI_ATOMIC: keep mask/scale -> atomicAdd fp32                          (split-K wgrad)
 enum { EPI_STORE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_ATOMIC = 3 };
 
-// epilogue of 4 consecutive columns n..n+3 of one output row
-template <typename T, typename TO, int EPI>
-__device__ __forceinline__ void epilogue_quad(const vr_gemm_args& p, float (&v)[4], int n, bool mok, int mloc,
-                                              long long orow, float sc, int keep, bool first_split, bool vec_ok) {
-    const int nvalid = min(4, p.N - n);          // <= 0: nothing to write
-    const int nc = nvalid > 0 ? n : 0;
-    const bool vec = vec_ok && nvalid == 4;
-    const int nv = nvalid > 0 ? nvalid : 1;
-    const bool any = mok && nvalid > 0;
-    float aux[4];
-    bool ok[4];
+// Epilogue of one lane = 2 output rows (i) x 8 column quads (j, g).  ALL global loads (bias, pos-embed, residual,
+// GELU pre-activation) are issued before the first store: on gfx950 vmcnt counts stores too, so a load issued after
+// a store cannot be waited for without draining that store (measured: 16 interleaved load/store pairs cost 14 us
+// of a 50 us kernel).
+template <typename T, typename TO, int EPI, int MI, int NI>
+__device__ __forceinline__ void epilogue_all(const vr_gemm_args& p, f32x16 (&acc)[MI][NI], int m0, int n0, int wm, int wn,
+                                             int lane, bool first_split) {
+    const RowMap cmap = {p.c_map.rpi, p.c_map.rps, p.c_map.off};
+    const bool vec_ok = (p.ldc % 4 == 0) && (p.N % 4 == 0) && (EPI != EPI_DGELU || p.ldu % 4 == 0);
+    const bool has_bias = (EPI == EPI_STORE || EPI == EPI_GELU) && p.bias && first_split;
+    const bool has_pos = (EPI == EPI_STORE) && p.pos && first_split;
+    const bool has_res = (EPI == EPI_STORE) && p.resid;
+    int nq[NI][4], nvq[NI][4];
+    bool vq[NI][4];
+    float bv[NI][4][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ok[e] = mok && (e < nvalid);
-    const long long oidx = orow * p.ldc + nc;
-    if constexpr (EPI == EPI_STORE || EPI == EPI_GELU) {
-        if (p.bias && first_split) {
-            load4<float>(p.bias, nc, aux, vec, nv);
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += aux[e];
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * NI * 32 + j * 32 + 8 * g + 4 * (lane >> 5);
+            const int nvalid = min(4, p.N - n);
+            nvq[j][g] = nvalid;
+            nq[j][g] = nvalid > 0 ? n : 0;
+            vq[j][g] = vec_ok && nvalid == 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[j][g][e] = 0.f;
+            if (has_bias) load4<float>(p.bias, nq[j][g], bv[j][g], vq[j][g], nvalid > 0 ? nvalid : 1);
         }
-    }
-    if constexpr (EPI == EPI_STORE) {
-        if (p.pos && first_split) {
-            load4<float>(p.pos, (long long)mloc * p.N + nc, aux, vec, nv);
+    bool mok[MI];
+    int mloc[MI], keep[MI];
+    long long orow[MI];
+    float sc[MI];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += aux[e];
-        }
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * MI * 32 + i * 32 + (lane & 31);
+        mok[i] = m < p.M;
+        const int mc = mok[i] ? m : 0;
+        const int sample = p.rows_in > 0 ? mc / p.rows_in : 0;
+        mloc[i] = p.rows_in > 0 ? mc - sample * p.rows_in : mc;
+        orow[i] = map_row(cmap, mc);
+        sc[i] = p.scale ? p.scale[sample] : 1.0f;
+        keep[i] = p.keep_n ? p.keep_n[sample] : (1 << 30);
     }
-    if constexpr (EPI == EPI_GELU) {
-        float h[4];
+    if (has_pos) {                                    // rare (patch embedding / SR): added to the accumulators up front
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (nc + e < keep) ? gelu_f(v[e]) : 0.f;
-        if (any) {
-            store4<TO>(p.C, oidx, v, vec, ok);
-            store4<TO>(p.C2, oidx, h, vec, ok);
-        }
-        return;
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float pv[4];
+                    load4<float>(p.pos, (long long)mloc[i] * p.N + nq[j][g], pv, vq[j][g], nvq[j][g] > 0 ? nvq[j][g] : 1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += pv[e];
+                }
     }
-    if constexpr (EPI == EPI_DGELU) {
-        load4<T>(p.dact_u, orow * p.ldu + nc, aux, vec, nv);
+    // one row (I) at a time: its side-input quads are loaded together, then its quads are stored (one vmcnt drain per
+    // row instead of one per quad).  Rows are expanded through an index_sequence so that acc[I] is a compile-time index
+    // even when the unroller refuses a plain loop (acc would otherwise spill to scratch).
+    auto row = [&](auto Ic) {
+        constexpr int i = decltype(Ic)::value;
+        float rv[NI][4][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(aux[e]);
-    }
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (nc + e < keep) ? v[e] * sc : 0.f;
-    if constexpr (EPI == EPI_ATOMIC) {
+            for (int g = 0; g < 4; ++g) {
+                const int nv = nvq[j][g] > 0 ? nvq[j][g] : 1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (ok[e]) atomicAdd(reinterpret_cast<float*>(p.C) + oidx + e, v[e]);
-        return;
-    }
-    if constexpr (EPI == EPI_STORE) {
-        if (p.resid) {
-            load4<float>(p.resid, oidx, aux, vec, nv);
+                for (int e = 0; e < 4; ++e) rv[j][g][e] = 0.f;
+                if constexpr (EPI == EPI_DGELU) load4<T>(p.dact_u, orow[i] * p.ldu + nq[j][g], rv[j][g], vq[j][g], nv);
+                if constexpr (EPI == EPI_STORE) {
+                    if (has_res) load4<float>(p.resid, orow[i] * p.ldc + nq[j][g], rv[j][g], vq[j][g], nv);
+                }
+            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += aux[e];
-        }
-    }
-    if (any) store4<TO>(p.C, oidx, v, vec, ok);
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nc = nq[j][g];
+                const bool any = mok[i] && nvq[j][g] > 0;
+                const long long oidx = orow[i] * p.ldc + nc;
+                float v[4];
+                bool ok[4], kc[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[i][j][4 * g + e] + bv[j][g][e];
+                    ok[e] = mok[i] && (e < nvq[j][g]);
+                    kc[e] = kept_col(nc + e, p.n_period, keep[i]);
+                }
+                if constexpr (EPI == EPI_GELU) {
+                    float h[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = kc[e] ? v[e] : 0.f;       // masked hidden units: u = 0, gelu(u) = 0 (their K loop may be skipped)
+                        h[e] = kc[e] ? gelu_f(v[e]) : 0.f;
+                    }
+                    if (any) {
+                        store4<TO>(p.C, oidx, v, vq[j][g], ok);
+                        store4<TO>(p.C2, oidx, h, vq[j][g], ok);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (EPI == EPI_DGELU) v[e] *= dgelu_f(rv[j][g][e]);
+                        v[e] = kc[e] ? v[e] * sc[i] : 0.f;
+                        if constexpr (EPI == EPI_STORE) v[e] += rv[j][g][e];
+                    }
+                    if (any) store4<TO>(p.C, oidx, v, vq[j][g], ok);
+                }
+            }
+    };
+    [&]<int... Is>(std::integer_sequence<int, Is...>) { (row(std::integral_constant<int, Is>{}), ...); }
+    (std::make_integer_sequence<int, MI>{});
 }
 
-template <typename T, bool TA, bool TB, typename TO, int EPI>
-__global__ __launch_bounds__(NTHR) void gemm_kernel(const vr_gemm_args p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // A0 B0 A1 B1
-    constexpr int BK = Cfg<T>::BK;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-
-    int kbeg = 0, kend = p.K;
-    if (p.split_k > 1) {
-        int per = (p.K + p.split_k - 1) / p.split_k;
-        per = (per + BK - 1) / BK * BK;
-        kbeg = blockIdx.z * per;
-        kend = min(p.K, kbeg + per);
-        if (kbeg >= kend) return;
+// CW consecutive elements (CW = 4 or 8): 16-byte accesses whenever the group is whole and aligned
+template <typename TI, int CW> __device__ __forceinline__ void loadw(const void* base, long long idx, float (&v)[CW], bool vec,
+                                                                     int nvalid) {
+    const TI* p = reinterpret_cast<const TI*>(base) + idx;
+    if (vec) {
+        if constexpr (sizeof(TI) == 4) {
+#pragma unroll
+            for (int h = 0; h < CW / 4; ++h) {
+                const float4 x = *reinterpret_cast<const float4*>(p + 4 * h);
+                v[4 * h] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
+            }
+        } else if constexpr (CW == 8) {
+            const uint4 u = *reinterpret_cast<const uint4*>(p);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                v[2 * h] = __uint_as_float(w[h] << 16);
+                v[2 * h + 1] = __uint_as_float(w[h] & 0xffff0000u);
+            }
+        } else {
+            const uint2 u = *reinterpret_cast<const uint2*>(p);
+            v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+            v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < CW; ++e) v[e] = Elem<TI>::ld(p + (e < nvalid ? e : 0));
     }
-    const int ntiles = (kend - kbeg + BK - 1) / BK;
+}
+template <typename TO, int CW> __device__ __forceinline__ void storew(void* base, long long idx, const float (&v)[CW], bool vec,
+                                                                      bool rowok, int nvalid) {
+    TO* p = reinterpret_cast<TO*>(base) + idx;
+    if (vec) {
+        if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+            for (int h = 0; h < CW / 4; ++h)
+                *reinterpret_cast<float4*>(p + 4 * h) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+        } else if constexpr (CW == 8) {
+            *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]),
+                                                      pack_bf2(v[6], v[7]));
+        } else {
+            *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < CW; ++e)
+            if (rowok && e < nvalid) Elem<TO>::st(p + e, v[e]);
+    }
+}
 
-    const RowMap amap = {p.a_map.rpi, p.a_map.rps, p.a_map.off};
-    const RowMap bmap = {p.b_map.rpi, p.b_map.rps, p.b_map.off};
-    typename std::conditional<TA, LoaderT<T>, LoaderN<T>>::type la;
-    typename std::conditional<TB, LoaderT<T>, LoaderN<T>>::type lb;
-    la.init(reinterpret_cast<const T*>(p.A), p.lda, amap, m0, p.M, t);
-    lb.init(reinterpret_cast<const T*>(p.B), p.ldb, bmap, n0, p.N, t);
-
-    f32x16 acc[2][2];
+// Epilogue through LDS (128x128 tile): the accumulators are parked in LDS as fp32 [128][132]; every thread then owns a
+// fixed group of CW consecutive columns (16 bytes of OUTPUT: 8 bf16 or 4 fp32 -- stores are issue-bound, so every store
+// instruction must carry 16 B per lane) and walks down the rows: each wave-instruction reads / writes whole rows of the
+// tile, the bias group is loaded once per thread, and all side inputs of a batch of 8 rows are in flight before the
+// first store of the batch (vmcnt counts stores: a load issued after a store cannot be waited for without draining it).
+constexpr int CROW = 132;  // floats per parked row (528 B = 33 x 16 B, odd -> conflict-free float4 accesses)
+template <typename T, typename TO, int EPI>
+__device__ __forceinline__ void epilogue_lds(const vr_gemm_args& p, f32x16 (&acc)[2][2], float* Ct, int m0, int n0, int wm,
+                                             int wn, int t, bool first_split) {
+    constexpr int CW = sizeof(TO) == 2 ? 8 : 4;      // columns per thread
+    constexpr int TPR = 128 / CW;                    // threads per tile row
+    constexpr int RPP = 256 / TPR;                   // rows per pass
+    constexpr int NPASS = 128 / RPP;                 // 8 (bf16) or 16 (fp32) rows per thread
+    constexpr int BATCH = 8;
+    const int lane = t & 63;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float rs[2] = {0.f, 0.f};
-    const bool want_bg = TA && p.bias_grad != nullptr && blockIdx.x == 0;
-    la.gload(kbeg, kend, t);
-    lb.gload(kbeg, kend, t);
-    if constexpr (TA) { if (want_bg) la.rowsum(rs); }
-    la.lstore(smem, t);
-    lb.lstore(smem + TILE_BYTES, t);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const bool more = kt + 1 < ntiles;
-        if (more) {
-            la.gload(kbeg + (kt + 1) * BK, kend, t);
-            lb.gload(kbeg + (kt + 1) * BK, kend, t);
-            if constexpr (TA) { if (want_bg) la.rowsum(rs); }
-        }
-        const char* As = smem + cur * 2 * TILE_BYTES;
-        mma_tile<EPI != EPI_ATOMIC>(acc, As, As + TILE_BYTES, wm, wn, lane, (T*)nullptr);
-        if (more) {
-            char* Ad = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            la.lstore(Ad, t);
-            lb.lstore(Ad + TILE_BYTES, t);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    if constexpr (TA) {
-        if (want_bg) la.rowsum_flush(rs, reinterpret_cast<float*>(smem), p.bias_grad, m0, p.M, t);
-    }
-    if constexpr (EPI == EPI_ATOMIC) {
-        // natural accumulator layout: a half-wave adds 32 consecutive fp32 of one output row (128 B) per instruction
-        float* C = reinterpret_cast<float*>(p.C);
-        const RowMap cm = {p.c_map.rpi, p.c_map.rps, p.c_map.off};
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const long long orow = map_row(cm, m < p.M ? m : 0);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-                    if (m < p.M && n < p.N) atomicAdd(C + orow * p.ldc + n, acc[i][j][r]);
-                }
-            }
-        return;
-    }
-    // ---- epilogue (transposed accumulators): lane owns rows m_i = ... + (lane&31) and, per accumulator quad g,
-    // the 4 consecutive columns n = n0 + wn*64 + j*32 + 8*g + 4*(lane>>5) + e
-    const RowMap cmap = {p.c_map.rpi, p.c_map.rps, p.c_map.off};
-    const bool first_split = blockIdx.z == 0;
-    const bool vec_ok = (p.ldc % 4 == 0) && (p.N % 4 == 0) && (EPI != EPI_DGELU || p.ldu % 4 == 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + (lane & 31);
-        const bool mok = m < p.M;
-        const int mc = mok ? m : 0;
-        const int sample = p.rows_in > 0 ? mc / p.rows_in : 0;
-        const int mloc = p.rows_in > 0 ? mc - sample * p.rows_in : mc;
-        const long long orow = map_row(cmap, mc);
-        const float sc = p.scale ? p.scale[sample] : 1.0f;
-        const int keep = p.keep_n ? p.keep_n[sample] : p.N;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float v[4];
+                const int ml = wm * 64 + i * 32 + (lane & 31), nl = wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
+                *reinterpret_cast<float4*>(Ct + ml * CROW + nl) =
+                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            }
+    __syncthreads();
+    const RowMap cmap = {p.c_map.rpi, p.c_map.rps, p.c_map.off};
+    const bool vec_ok = (p.ldc % CW == 0) && (p.N % CW == 0) && (EPI != EPI_DGELU || p.ldu % CW == 0);
+    const int nl = CW * (t % TPR);
+    const int n = n0 + nl;
+    const int nvalid = min(CW, p.N - n);
+    const int nc = nvalid > 0 ? n : 0;
+    const int nv = nvalid > 0 ? nvalid : 1;
+    const bool vec = vec_ok && nvalid == CW;
+    float bv[CW];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
-                epilogue_quad<T, TO, EPI>(p, v, n, mok, mloc, orow, sc, keep, first_split, vec_ok);
+    for (int e = 0; e < CW; ++e) bv[e] = 0.f;
+    if ((EPI == EPI_STORE || EPI == EPI_GELU) && p.bias && first_split) loadw<float, CW>(p.bias, nc, bv, vec, nv);
+    const bool has_pos = (EPI == EPI_STORE) && p.pos && first_split;
+    const bool has_res = (EPI == EPI_STORE) && p.resid;
+#pragma unroll
+    for (int b0 = 0; b0 < NPASS; b0 += BATCH) {
+        bool mok[BATCH];
+        int keep[BATCH];
+        long long orow[BATCH];
+        float sc[BATCH], rv[BATCH][CW], pv[BATCH][CW];
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+            const int m = m0 + (t / TPR) + RPP * (b0 + q);
+            mok[q] = m < p.M;
+            const int mc = mok[q] ? m : 0;
+            const int sample = p.rows_in > 0 ? mc / p.rows_in : 0;
+            const int mloc = p.rows_in > 0 ? mc - sample * p.rows_in : mc;
+            orow[q] = map_row(cmap, mc);
+            sc[q] = p.scale ? p.scale[sample] : 1.0f;
+            keep[q] = p.keep_n ? p.keep_n[sample] : (1 << 30);
+#pragma unroll
+            for (int e = 0; e < CW; ++e) { rv[q][e] = 0.f; pv[q][e] = 0.f; }
+            if constexpr (EPI == EPI_DGELU) loadw<T, CW>(p.dact_u, orow[q] * p.ldu + nc, rv[q], vec, nv);
+            if constexpr (EPI == EPI_STORE) {
+                if (has_res) loadw<float, CW>(p.resid, orow[q] * p.ldc + nc, rv[q], vec, nv);
+                if (has_pos) loadw<float, CW>(p.pos, (long long)mloc * p.N + nc, pv[q], vec, nv);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+            const int rl = (t / TPR) + RPP * (b0 + q);
+            float v[CW];
+#pragma unroll
+            for (int h = 0; h < CW / 4; ++h) {
+                const float4 a4 = *reinterpret_cast<const float4*>(Ct + rl * CROW + nl + 4 * h);
+                v[4 * h] = a4.x; v[4 * h + 1] = a4.y; v[4 * h + 2] = a4.z; v[4 * h + 3] = a4.w;
+            }
+            bool kc[CW];
+#pragma unroll
+            for (int e = 0; e < CW; ++e) {
+                v[e] += bv[e] + pv[q][e];
+                kc[e] = kept_col(nc + e, p.n_period, keep[q]);
+            }
+            const bool any = mok[q] && nvalid > 0;
+            const long long oidx = orow[q] * p.ldc + nc;
+            if constexpr (EPI == EPI_GELU) {
+                float h[CW];
+#pragma unroll
+                for (int e = 0; e < CW; ++e) {
+                    v[e] = kc[e] ? v[e] : 0.f;       // masked hidden units: u = 0, gelu(u) = 0 (their K loop may be skipped)
+                    h[e] = kc[e] ? gelu_f(v[e]) : 0.f;
+                }
+                if (any) {
+                    storew<TO, CW>(p.C, oidx, v, vec, mok[q], nvalid);
+                    storew<TO, CW>(p.C2, oidx, h, vec, mok[q], nvalid);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < CW; ++e) {
+                    if constexpr (EPI == EPI_DGELU) v[e] *= dgelu_f(rv[q][e]);
+                    v[e] = kc[e] ? v[e] * sc[q] : 0.f;
+                    if constexpr (EPI == EPI_STORE) v[e] += rv[q][e];
+                }
+                if (any) storew<TO, CW>(p.C, oidx, v, vec, mok[q], nvalid);
             }
         }
     }
 }
 
+// Persistent workgroups: gridDim.x = (resident workgroups per CU) x CUs; each walks the output tiles
+// tile, tile + gridDim.x, ...  The first K slice of the NEXT tile is fetched into registers before the epilogue of the
+// current one, so its HBM latency hides behind the stores and the chip never runs in lock-step load / store phases.
+template <typename T, bool TA, bool TB, typename TO, int EPI, typename TC>
+__global__ __launch_bounds__(TC::NTHR, 2) void gemm_kernel(const vr_gemm_args p) {
+    constexpr int BM = TC::BM, BN = TC::BN, NTHR = TC::NTHR, MI = TC::MI, NI = TC::NI;
+    constexpr int TILE_BYTES = TC::A_BYTES, BUF = TC::BUF_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];  // [A0 B0][A1 B1]
+    constexpr int BK = Cfg<T>::BK;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / TC::WC, wn = wave % TC::WC;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int total = tiles_n * tiles_m * p.split_k;
+    int kper = p.K;
+    if (p.split_k > 1) kper = ((p.K + p.split_k - 1) / p.split_k + BK - 1) / BK * BK;
+    const RowMap amap = {p.a_map.rpi, p.a_map.rps, p.a_map.off};
+    const RowMap bmap = {p.b_map.rpi, p.b_map.rps, p.b_map.off};
+
+    typename std::conditional<TA, LoaderT<T, BM, NTHR>, LoaderN<T, BM, NTHR>>::type la;
+    typename std::conditional<TB, LoaderT<T, BN, NTHR>, LoaderN<T, BN, NTHR>>::type lb;
+    Stage sa, sb;
+    float rs[2] = {0.f, 0.f};
+    // ---- state of the tile being set up / computed ----
+    int m0 = 0, n0 = 0, z = 0, kbeg = 0, kend = 0, ntiles = 0, kmax = 0;
+    bool n_any = true, want_bg = false;
+
+    auto setup = [&](int tile) {
+        const int tn = tile % tiles_n, rest = tile / tiles_n;
+        const int tm = rest % tiles_m;
+        z = rest / tiles_m;
+        m0 = tm * BM;
+        n0 = tn * BN;
+        kbeg = z * kper;
+        kend = min(p.K, kbeg + kper);
+        ntiles = kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
+        // masked-work skipping: which samples does this tile touch, and how much of K / N do they keep
+        kmax = 1 << 30;
+        n_any = true;
+        if ((p.keep_k || p.keep_n) && ntiles > 0) {
+            int s_lo = 0, s_hi = 0;
+            if (p.rows_in > 0) {
+                if constexpr (TA) { s_lo = kbeg / p.rows_in; s_hi = (kend - 1) / p.rows_in; }
+                else { s_lo = m0 / p.rows_in; s_hi = (min(m0 + BM, p.M) - 1) / p.rows_in; }
+            }
+            kmax = max_keep(p.keep_k, s_lo, s_hi, 1 << 30);
+            const int nmax = max_keep(p.keep_n, s_lo, s_hi, 1 << 30);
+            n_any = range_has_kept(n0, BN, p.n_period, nmax);
+            if constexpr (TA) {
+                // wgrad: keep_k bounds the kept output rows; a tile without kept rows or columns adds exactly zero
+                if (!n_any || !range_has_kept(m0, BM, p.k_period, kmax)) ntiles = 0;
+            }
+        }
+        la.init(reinterpret_cast<const T*>(p.A), p.lda, amap, m0, p.M, t);
+        lb.init(reinterpret_cast<const T*>(p.B), p.ldb, bmap, n0, p.N, t);
+        rs[0] = 0.f;
+        rs[1] = 0.f;
+        want_bg = TA && p.bias_grad != nullptr && tn == 0 && ntiles > 0;
+    };
+    auto tile_live = [&](int kt) -> bool {
+        if constexpr (TA) return true;
+        else return n_any && (p.keep_k == nullptr || range_has_kept(kbeg + kt * BK, BK, p.k_period, kmax));
+    };
+    auto next_live = [&](int kt) -> int {
+        while (kt < ntiles && !tile_live(kt)) ++kt;
+        return kt;
+    };
+    // slice i is computed from LDS while slice i+1 is in flight into registers (a second slice in flight was measured:
+    // no gain -- the K loop is bound by the CU's load path, not by latency -- and it costs 32 VGPRs)
+    auto fetch = [&](int kt) {
+        la.gload(sa, kbeg + kt * BK, kend, t);
+        lb.gload(sb, kbeg + kt * BK, kend, t);
+        if constexpr (TA) { if (want_bg) la.rowsum(sa, rs); }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    setup(tile);
+    int kt = next_live(0);
+    if (kt < ntiles) fetch(kt);
+    for (;;) {
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if (kt < ntiles) {
+            la.lstore(sa, smem, t);
+            lb.lstore(sb, smem + TILE_BYTES, t);
+        }
+        __syncthreads();
+        int cur = 0;
+        while (kt < ntiles) {
+            const int nxt = next_live(kt + 1);
+            const bool more = nxt < ntiles;
+            if (more) fetch(nxt);
+            const char* As = smem + cur * BUF;
+            mma_tile<EPI != EPI_ATOMIC, MI, NI>(acc, As, As + TILE_BYTES, wm, wn, lane, (T*)nullptr);
+            if (more) {
+                char* Ad = smem + (cur ^ 1) * BUF;
+                la.lstore(sa, Ad, t);
+                lb.lstore(sb, Ad + TILE_BYTES, t);
+            }
+            __syncthreads();
+            cur ^= 1;
+            kt = nxt;
+        }
+        if constexpr (TA) {
+            if (want_bg) la.rowsum_flush(rs, reinterpret_cast<float*>(smem), p.bias_grad, m0, p.M, t);
+        }
+        // coordinates of the finished tile, then start the next tile's first slice before storing this one
+        const int em0 = m0, en0 = n0;
+        const bool efirst = z == 0, edone = ntiles > 0 || !TA;
+        const int nxt_tile = tile + gridDim.x;
+        const bool has_next = nxt_tile < total;
+        if (has_next) {
+            setup(nxt_tile);
+            kt = next_live(0);
+            if (kt < ntiles) fetch(kt);
+        }
+        if constexpr (EPI == EPI_ATOMIC) {
+            // natural accumulator layout: a half-wave adds 32 consecutive fp32 of one output row (128 B) per instruction
+            if (edone) {
+                float* C = reinterpret_cast<float*>(p.C);
+                const RowMap cm = {p.c_map.rpi, p.c_map.rps, p.c_map.off};
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = em0 + wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const long long orow = map_row(cm, m < p.M ? m : 0);
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            const int n = en0 + wn * NI * 32 + j * 32 + (lane & 31);
+                            if (m < p.M && n < p.N) atomicAdd(C + orow * p.ldc + n, acc[i][j][r]);
+                        }
+                    }
+            }
+        } else {
+            // transposed accumulators: lane owns rows m_i = ... + (lane&31) and, per accumulator quad g, the 4
+            // consecutive columns n = n0 + wn*NI*32 + j*32 + 8*g + 4*(lane>>5) + e
+            if constexpr (BM == 128 && BN == 128 && sizeof(TO) == 4) {
+                // fp32 outputs (residual-stream updates): parked in LDS, whole-row 16-byte accesses (measured 64 -> 46 us);
+                // bf16 outputs are faster straight from registers (measured: the LDS round trip costs more than it saves)
+                epilogue_lds<T, TO, EPI>(p, acc, reinterpret_cast<float*>(smem), em0, en0, wm, wn, t, efirst);
+            } else {
+                epilogue_all<T, TO, EPI, MI, NI>(p, acc, em0, en0, wm, wn, lane, efirst);
+            }
+        }
+        if (!has_next) break;
+        if constexpr (EPI != EPI_ATOMIC && BM == 128 && BN == 128 && sizeof(TO) == 4) __syncthreads();   // Ct is re-used by the next lstore
+        tile = nxt_tile;
+    }
+}
+
+inline int cu_count() {
+    static int n = 0;           // read once per process (one process per GPU)
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 template <typename T, bool TA, bool TB, typename TO, int EPI>
-void launch1(const vr_gemm_args& a, hipStream_t stream) {
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.split_k);
-    hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TO, EPI>), grid, dim3(NTHR), 0, stream, a);
+void launch1(vr_gemm_args a, hipStream_t stream) {
+    // measured (tools/gemm_probe.py): the 256x256 tile wins for the split-K weight gradients only -- for the forward /
+    // dgrad shapes (K <= 1024) its 1 workgroup / CU residency and tail cost more than the halved load traffic buys
+    const long long big_tiles = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const int want_split = a.atomic ? max(1, min(a.K / 512, 1 << 16)) : 1;
+    static const bool knob_big = !(std::getenv("VITRES_GEMM_BIG") && std::getenv("VITRES_GEMM_BIG")[0] == '0');
+    static const bool knob_persist = !(std::getenv("VITRES_GEMM_PERSIST") && std::getenv("VITRES_GEMM_PERSIST")[0] == '0');
+    const bool big = knob_big && a.atomic && (a.M >= 192 && a.N >= 192) && big_tiles * want_split >= 192;
+    const long long tiles = big ? big_tiles : (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (a.atomic && a.split_k <= 0) a.split_k = (int)max(1LL, min((long long)want_split, max(1LL, 1024 / tiles)));
+    const long long total = tiles * a.split_k;
+    if (big) {
+        const int grid = (int)(knob_persist ? min(total, (long long)cu_count()) : total);   // 144 KB LDS: one workgroup per CU
+        hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TO, EPI, CfgBig>), dim3(grid), dim3(CfgBig::NTHR), 0, stream, a);
+    } else {
+        const int grid = (int)(knob_persist ? min(total, 2LL * cu_count()) : total);        // 72 KB LDS, <= 256 VGPR: two per CU
+        hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TO, EPI, CfgStd>), dim3(grid), dim3(CfgStd::NTHR), 0, stream, a);
+    }
 }
 
 template <typename T>
@@ -461,7 +779,6 @@ int launch(const vr_gemm_args& a, hipStream_t stream) {
     const bool of32 = a.out_dtype == VR_F32;
     if (a.atomic) {                                             // weight gradients (fp32 accumulate)
         if (a.a_trans && a.b_trans) launch1<T, true, true, float, EPI_ATOMIC>(a, stream);
-        else if (!a.a_trans && !a.b_trans) launch1<T, false, false, float, EPI_ATOMIC>(a, stream);
         else return VR_EUNSUPPORTED;
     } else if (a.a_trans) {
         return VR_EUNSUPPORTED;
@@ -488,7 +805,7 @@ extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
     if (!args || !args->A || !args->B || !args->C) return VR_EINVAL;
     vr_gemm_args a = *args;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return VR_EINVAL;
-    if (a.split_k < 1) a.split_k = 1;
+    if (a.split_k < 0 || (!a.atomic && a.split_k == 0)) a.split_k = 1;   // 0 with atomic = choose automatically
     if (a.split_k > 1 && !a.atomic) return VR_EINVAL;
     if (a.atomic && a.out_dtype != VR_F32) return VR_EINVAL;
     if (a.act == 1 && !a.C2) return VR_EINVAL;

@@ -22,12 +22,12 @@ class GemmArgs(ctypes.Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("C2", c_void_p),
         ("bias", c_void_p), ("pos", c_void_p), ("scale", c_void_p), ("keep_n", c_void_p),
-        ("resid", c_void_p), ("dact_u", c_void_p), ("bias_grad", c_void_p),
+        ("resid", c_void_p), ("dact_u", c_void_p), ("keep_k", c_void_p), ("bias_grad", c_void_p),
         ("M", c_int32), ("N", c_int32), ("K", c_int32),
         ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldu", c_int32),
         ("a_trans", c_int32), ("b_trans", c_int32),
         ("in_dtype", c_int32), ("out_dtype", c_int32),
-        ("act", c_int32), ("atomic", c_int32), ("split_k", c_int32), ("rows_in", c_int32),
+        ("act", c_int32), ("atomic", c_int32), ("split_k", c_int32), ("rows_in", c_int32), ("n_period", c_int32), ("k_period", c_int32),
         ("a_map", RowMap), ("b_map", RowMap), ("c_map", RowMap),
     ]
 

@@ -32,10 +32,13 @@ class Weights:
         self.w, self.b, self.w_c, self.ld = w, b, w_c, ld   # fp32 param, fp32 bias, compute-dtype matrix [out, ld]
 
 
-def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None, db=None):
-    """dw[N_out, K_in] += dy[M, N_out]^T @ x[M, K_in]  (fp32 atomics, split over tokens)."""
+def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None, db=None, keep_rows=None,
+                 keep_cols=None, row_period=0, tokens_per_sample=0):
+    """dw[N_out, K_in] += dy[M, N_out]^T @ x[M, K_in]  (fp32 atomics, split over tokens; db[N_out] += colsum(dy)).
+    keep_rows / keep_cols: per-sample kept prefix of dy's / x's channels -> fully masked tiles are skipped."""
     K.gemm(dy, x, dw, M=N_out, N=K_in, K=M, lda=lddy, ldb=ldx, ldc=ldw or K_in, a_trans=True, b_trans=True,
-           atomic=True, split_k=_split_k(M, N_out, K_in), a_map=a_map, b_map=b_map, bias_grad=db)
+           atomic=True, split_k=0, a_map=a_map, b_map=b_map, bias_grad=db,
+           keep_k=keep_rows, keep_n=keep_cols, k_period=row_period, rows_in=tokens_per_sample)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -49,11 +52,12 @@ def attn_branch_fwd(x, p, cfg, embed_keep, attn_keep, out_keep, scale, save):
     dt = cfg["dtype"]
     y, mean, rstd = K.ln_fwd(x, p["n1w"], p["n1b"], embed_keep, N, cfg["eps"], dt)
     qkv = torch.empty((B, N, 3 * HD), dtype=dt, device=x.device)
-    K.gemm(y, p["qkv"].w_c, qkv, M=M, N=3 * HD, K=C, lda=C, ldb=p["qkv"].ld, ldc=3 * HD, bias=p["qkv"].b, rows_in=N)
+    K.gemm(y, p["qkv"].w_c, qkv, M=M, N=3 * HD, K=C, lda=C, ldb=p["qkv"].ld, ldc=3 * HD, bias=p["qkv"].b, rows_in=N,
+           keep_k=embed_keep, keep_n=attn_keep, n_period=HD)
     o, lse = K.attn_fwd(qkv, attn_keep, B, N, H, D, cfg["scale"])
     x1 = torch.empty_like(x)
     K.gemm(o, p["proj"].w_c, x1, M=M, N=C, K=HD, lda=HD, ldb=p["proj"].ld, ldc=C, bias=p["proj"].b, scale=scale,
-           keep_n=out_keep, resid=x, rows_in=N)
+           keep_n=out_keep, resid=x, rows_in=N, keep_k=attn_keep)
     saved = (x, mean, rstd, y, qkv, o, lse) if save else None
     return x1, saved
 
@@ -66,14 +70,17 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     HD = H * D
     dt = cfg["dtype"]
     gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                       # d(branch output), compute dtype
-    linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"])
+    linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"], keep_rows=out_keep, keep_cols=attn_keep,
+                 tokens_per_sample=N)
     d_o = torch.empty((B, N, HD), dtype=dt, device=x.device)
     K.gemm(gt, p["proj"].w_c, d_o, M=M, N=HD, K=C, lda=C, ldb=p["proj"].ld, ldc=HD, b_trans=True, keep_n=attn_keep,
-           rows_in=N)
+           rows_in=N, keep_k=out_keep)
     dqkv = K.attn_bwd(qkv, o, d_o, lse, attn_keep, B, N, H, D, cfg["scale"])
-    linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C, db=grads["qkv.b"])
+    linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C, db=grads["qkv.b"], keep_rows=attn_keep,
+                 keep_cols=embed_keep, row_period=HD, tokens_per_sample=N)
     dy = torch.empty((B, N, C), dtype=dt, device=x.device)
-    K.gemm(dqkv, p["qkv"].w_c, dy, M=M, N=C, K=3 * HD, lda=3 * HD, ldb=p["qkv"].ld, ldc=C, b_trans=True, rows_in=N)
+    K.gemm(dqkv, p["qkv"].w_c, dy, M=M, N=C, K=3 * HD, lda=3 * HD, ldb=p["qkv"].ld, ldc=C, b_trans=True, rows_in=N,
+           keep_k=attn_keep, k_period=HD, keep_n=embed_keep)
     return K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, grads["n1w"], grads["n1b"])
 
 
@@ -86,10 +93,10 @@ def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save):
     u = torch.empty((B, N, F), dtype=dt, device=x.device)
     h = torch.empty((B, N, F), dtype=dt, device=x.device)
     K.gemm(y, p["fc1"].w_c, u, out2=h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b, act=1,
-           keep_n=mlp_keep, rows_in=N)
+           keep_n=mlp_keep, rows_in=N, keep_k=embed_keep)
     x2 = torch.empty_like(x)
     K.gemm(h, p["fc2"].w_c, x2, M=M, N=C, K=F, lda=F, ldb=p["fc2"].ld, ldc=C, bias=p["fc2"].b, scale=scale,
-           keep_n=out_keep, resid=x, rows_in=N)
+           keep_n=out_keep, resid=x, rows_in=N, keep_k=mlp_keep)
     saved = (x, mean, rstd, y, u, h) if save else None
     return x2, saved
 
@@ -101,13 +108,16 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     F = cfg["hidden"]
     dt = cfg["dtype"]
     gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
-    linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"])
+    linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"], keep_rows=out_keep, keep_cols=mlp_keep,
+                 tokens_per_sample=N)
     du = torch.empty((B, N, F), dtype=dt, device=x.device)
     K.gemm(gt, p["fc2"].w_c, du, M=M, N=F, K=C, lda=C, ldb=p["fc2"].ld, ldc=F, b_trans=True, dact_u=u, ldu=F,
-           keep_n=mlp_keep, rows_in=N)
-    linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"])
+           keep_n=mlp_keep, rows_in=N, keep_k=out_keep)
+    linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"], keep_rows=mlp_keep, keep_cols=embed_keep,
+                 tokens_per_sample=N)
     dy = torch.empty((B, N, C), dtype=dt, device=x.device)
-    K.gemm(du, p["fc1"].w_c, dy, M=M, N=C, K=F, lda=F, ldb=p["fc1"].ld, ldc=C, b_trans=True, rows_in=N)
+    K.gemm(du, p["fc1"].w_c, dy, M=M, N=C, K=F, lda=F, ldb=p["fc1"].ld, ldc=C, b_trans=True, rows_in=N, keep_k=mlp_keep,
+           keep_n=embed_keep)
     return K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"])
 
 
@@ -125,7 +135,8 @@ def sr_fwd(x, p, cfg, embed_keep, new_keep, save):
     out = K.sr_resid(x, B, g, C, Co)
     col = K.sr_im2col(y, B, g, C)
     K.gemm(col, p["reduce"].w_c, out, M=B * go * go, N=Co, K=9 * C, lda=9 * C, ldb=p["reduce"].ld, ldc=Co,
-           bias=p["reduce"].b, pos=p["pos"], resid=out, rows_in=go * go, c_map=(go * go, No, 1))
+           bias=p["reduce"].b, pos=p["pos"], resid=out, rows_in=go * go, c_map=(go * go, No, 1), keep_k=embed_keep,
+           k_period=C)
     K.gemm(y, p["token"].w_c, out, M=B, N=Co, K=C, lda=C, ldb=p["token"].ld, ldc=Co, bias=p["token"].b, resid=out,
            rows_in=1, a_map=(1, Ni, 0), c_map=(1, No, 0))
     if new_keep is not None:

@@ -48,12 +48,13 @@ def _rm(m):
 
 def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
          scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
-         a_map=None, b_map=None, c_map=None, bias_grad=None):
+         a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0):
     """out[M,N] = epilogue(a[M,K] @ b[N,K]^T) -- see vr_gemm in include/vitres_hip.h."""
     args = GemmArgs()
     args.A, args.B, args.C, args.C2 = _p(a), _p(b), _p(out), _p(out2)
     args.bias, args.pos, args.scale, args.keep_n = _p(bias), _p(pos), _p(scale), _p(keep_n)
-    args.resid, args.dact_u, args.bias_grad = _p(resid), _p(dact_u), _p(bias_grad)
+    args.resid, args.dact_u, args.bias_grad, args.keep_k = _p(resid), _p(dact_u), _p(bias_grad), _p(keep_k)
+    args.n_period, args.k_period = n_period, k_period
     args.M, args.N, args.K = M, N, K
     args.lda, args.ldb, args.ldc, args.ldu = lda, ldb, ldc, ldu
     args.a_trans, args.b_trans = int(a_trans), int(b_trans)

@@ -95,10 +95,11 @@ class SpatialReductionPatchEmbedding(nn.Module):
 
 class _Plan:
     """Host-side description of one forward: which keep vector / drop-path scale each layer uses."""
-    __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch", "n_dp")
+    __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch", "n_dp", "order")
 
     def __init__(self):
         self.rows, self.layers, self.keep_dev, self.head, self.scales, self.batch, self.n_dp = [], [], None, None, None, 0, 0
+        self.order = None
 
     def add(self, keep):
         if keep is None:
@@ -376,7 +377,28 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         plan.head = e_idx
         plan.n_dp = n_dp
         self.last_keeps = log
+        # Arch-grouped execution order: sample b runs architecture (b mod G), G = B / example_per_arch
+        # (channel_drop.py:101-105 tiles the G sampled rows).  Running the batch as G contiguous groups makes every
+        # GEMM tile / wgrad split see ONE architecture, so masked K slices and output tiles can be skipped.  Results
+        # are returned in the caller's order; nothing but the internal row order changes.
+        cd = self.embed_channel_drop
+        if tr and cd is not None and plan.rows and cd.example_per_arch and B % cd.example_per_arch == 0:
+            epa = cd.example_per_arch
+            G = B // epa
+            if 1 < G < B:
+                plan.order = [j * G + g for g in range(G) for j in range(epa)]
+                idx = torch.tensor(plan.order)
+                plan.rows = [r[idx] for r in plan.rows]
         return plan
+
+    def _order_tensors(self, order, device):
+        cache = getattr(self, "_order_cache", None)
+        key = (len(order), order[1] if len(order) > 1 else 0, str(device))
+        if cache is None or cache[0] != key:
+            o = torch.tensor(order, dtype=torch.int64)
+            cache = (key, o.to(device), torch.argsort(o).to(device))
+            self._order_cache = cache
+        return cache[1], cache[2]
 
     def _upload_plan(self, plan, device):
         """Device side of a plan: one H2D copy of all keep rows (unless a static buffer was attached, e.g. by a
@@ -415,7 +437,13 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             plan = self.sample_plan(x.shape[0])
         self._upload_plan(plan, x.device)
         params = self._arena["params"]
-        out = _ViTResFn.apply(self, x.contiguous().float(), plan, with_patch, *params)
+        x = x.contiguous().float()
+        if plan.order is not None:
+            fwd_idx, inv_idx = self._order_tensors(plan.order, x.device)
+            x = x.index_select(0, fwd_idx)
+        out = _ViTResFn.apply(self, x, plan, with_patch, *params)
+        if plan.order is not None:
+            out = tuple(o.index_select(0, inv_idx) for o in out) if isinstance(out, tuple) else out.index_select(0, inv_idx)
         return out
 
     def _layer_params(self, blk):
