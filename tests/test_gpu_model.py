@@ -205,3 +205,24 @@ def test_hipgraph_replay_matches_eager():
         assert abs(loss_g - loss_e) < 1e-5 * abs(loss_e)
         for n, p in prod.named_parameters():
             assert rel(p.grad, grads_e[n]) < 1e-4, n
+
+
+def test_evo_candidates_on_resident_supernet_match_reference_sliced_subnets():
+    """Config C5: a candidate sub-network evaluated as a keep-descriptor on the resident supernet gives the logits the
+    REFERENCE computes for the prefix-sliced standalone sub-network (get_sub_state_dict, fixture F5)."""
+    from vitres import evo_eval
+    g = np.load(os.path.join(G, "f5_subnet.npz"))
+    sup = vitres.create_model("flexible_vit_sr_patch14_224_patch_output_supernet", img_size=recipe.MICRO_IMG,
+                              num_classes=recipe.MICRO_CLASSES, network_def=recipe.MICRO_DEFS[0],
+                              num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30)
+    sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in sup.state_dict().items()], 100)
+    assert recipe.checksum(sd) == int(g["state_crc"])
+    sup.load_state_dict(sd)
+    sup = sup.to(DEV).set_compute_dtype(torch.float32).eval()
+    x, _, _, labels = recipe.inputs(9, 6, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    for i, nd in enumerate(recipe.MICRO_CANDIDATES):
+        with torch.no_grad():
+            out = sup(x.to(DEV), plan=evo_eval.plan_for_subnet(sup, nd, 6))
+        assert rel(out, g["cand%d.logits" % i]) < 1e-4, (i, rel(out, g["cand%d.logits" % i]))
+    scores = evo_eval.score_population(sup, recipe.MICRO_CANDIDATES, [(x.to(DEV), labels.to(DEV))])
+    assert len(scores) == 4 and all(0.0 <= s <= 100.0 for s in scores)
