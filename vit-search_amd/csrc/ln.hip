@@ -24,9 +24,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
         const int c = (lane + 64 * j) * 4;
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[j] = *reinterpret_cast<const float4*>(xr + (c < C ? c : 0));       // clamped, never branched around
+        if (c >= C) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < C) {
-            v[j] = *reinterpret_cast<const float4*>(xr + c);
             if (c + 0 >= kc) v[j].x = 0.f;
             if (c + 1 >= kc) v[j].y = 0.f;
             if (c + 2 >= kc) v[j].z = 0.f;
@@ -89,14 +89,14 @@ template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
                        __uint_as_float(u.y & 0xffff0000u));
 }
 
-constexpr int BWD_ROWS = 32;  // rows per workgroup (8 per wave)
+// rows per workgroup are chosen per launch: more rows = fewer dgamma/dbeta atomics, fewer rows = more workgroups
 
 template <typename TI, int MAXV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TI* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const int* __restrict__ keep,
                                                      const float* __restrict__ dx_in, float* __restrict__ dx_out,
-                                                     float* __restrict__ dw, float* __restrict__ db, int M, int C, int rps) {
+                                                     float* __restrict__ dw, float* __restrict__ db, int M, int C, int rps, int BWD_ROWS) {
     __shared__ float red[2][4][64 * 4];  // [dw|db][wave][lane*4+e], reused per j
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 gw[MAXV], gb[MAXV], ww[MAXV];
@@ -108,50 +108,67 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TI* __restrict__ dy, 
         ww[j] = (c < C) ? *reinterpret_cast<const float4*>(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int mbeg = blockIdx.x * BWD_ROWS;
-    for (int rr = wave; rr < BWD_ROWS; rr += 4) {
-        const int m = mbeg + rr;
-        if (m >= M) break;
-        const int kc = keep ? keep[m / rps] : C;
-        const float mu = mean[m], rs = rstd[m];
-        const float inv_n = kc > 0 ? 1.0f / (float)kc : 0.f;
-        float4 g[MAXV], z[MAXV];
-        float s1 = 0.f, s2 = 0.f;
+    constexpr int RU = MAXV == 1 ? 4 : (MAXV <= 2 ? 2 : 1);           // rows in flight per wave: all their loads are issued before any reduction
+    for (int rr = wave; rr < BWD_ROWS; rr += 4 * RU) {
+        float4 gv[RU][MAXV], xv[RU][MAXV], rv[RU][MAXV];
+        int kc[RU];
+        float mu[RU], rs[RU];
+        bool rok[RU];
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int c = (lane + 64 * j) * 4;
-            g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            z[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < C) {
-                float4 gv = load4<TI>(dy + (long long)m * C + c);
-                float4 xv = *reinterpret_cast<const float4*>(x + (long long)m * C + c);
-                if (c + 0 >= kc) { gv.x = 0.f; xv.x = mu; }
-                if (c + 1 >= kc) { gv.y = 0.f; xv.y = mu; }
-                if (c + 2 >= kc) { gv.z = 0.f; xv.z = mu; }
-                if (c + 3 >= kc) { gv.w = 0.f; xv.w = mu; }
-                z[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                gw[j].x += gv.x * z[j].x; gw[j].y += gv.y * z[j].y; gw[j].z += gv.z * z[j].z; gw[j].w += gv.w * z[j].w;
-                gb[j].x += gv.x; gb[j].y += gv.y; gb[j].z += gv.z; gb[j].w += gv.w;
-                g[j] = make_float4(gv.x * ww[j].x, gv.y * ww[j].y, gv.z * ww[j].z, gv.w * ww[j].w);  // dz
+        for (int u = 0; u < RU; ++u) {
+            const int m = mbeg + rr + 4 * u;
+            rok[u] = (rr + 4 * u < BWD_ROWS) && (m < M);
+            const int mc = rok[u] ? m : 0;
+            kc[u] = keep ? keep[mc / rps] : C;
+            mu[u] = mean[mc];
+            rs[u] = rstd[mc];
+#pragma unroll
+            for (int j = 0; j < MAXV; ++j) {
+                const int c = (lane + 64 * j) * 4;
+                const int cc = c < C ? c : 0;                        // clamped: loads are never branched around
+                gv[u][j] = load4<TI>(dy + (long long)mc * C + cc);
+                xv[u][j] = *reinterpret_cast<const float4*>(x + (long long)mc * C + cc);
+                rv[u][j] = dx_in ? *reinterpret_cast<const float4*>(dx_in + (long long)mc * C + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const float inv_n = kc[u] > 0 ? 1.0f / (float)kc[u] : 0.f;
+            float4 g[MAXV], z[MAXV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXV; ++j) {
+                const int c = (lane + 64 * j) * 4;
+                float4 a = gv[u][j], xx = xv[u][j];
+                const bool in = (c < C) && rok[u];
+                if (!(in && c + 0 < kc[u])) { a.x = 0.f; xx.x = mu[u]; }
+                if (!(in && c + 1 < kc[u])) { a.y = 0.f; xx.y = mu[u]; }
+                if (!(in && c + 2 < kc[u])) { a.z = 0.f; xx.z = mu[u]; }
+                if (!(in && c + 3 < kc[u])) { a.w = 0.f; xx.w = mu[u]; }
+                z[j] = make_float4((xx.x - mu[u]) * rs[u], (xx.y - mu[u]) * rs[u], (xx.z - mu[u]) * rs[u], (xx.w - mu[u]) * rs[u]);
+                gw[j].x += a.x * z[j].x; gw[j].y += a.y * z[j].y; gw[j].z += a.z * z[j].z; gw[j].w += a.w * z[j].w;
+                gb[j].x += a.x; gb[j].y += a.y; gb[j].z += a.z; gb[j].w += a.w;
+                g[j] = make_float4(a.x * ww[j].x, a.y * ww[j].y, a.z * ww[j].z, a.w * ww[j].w);  // dz
                 s1 += g[j].x + g[j].y + g[j].z + g[j].w;
                 s2 += g[j].x * z[j].x + g[j].y * z[j].y + g[j].z * z[j].z + g[j].w * z[j].w;
             }
-        }
-        s1 = wave_sum(s1) * inv_n;
-        s2 = wave_sum(s2) * inv_n;
+            s1 = wave_sum(s1) * inv_n;
+            s2 = wave_sum(s2) * inv_n;
+            const int m = mbeg + rr + 4 * u;
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int c = (lane + 64 * j) * 4;
-            if (c < C) {
-                // channels >= keep get exactly 0 (also for the pass-through residual gradient): the reference lets
-                // garbage flow there until the stage's `x * mask` kills it (nets/channel_drop.py:82); same param grads.
-                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (dx_in) r = *reinterpret_cast<const float4*>(dx_in + (long long)m * C + c);
-                float4 o;
-                o.x = (c + 0 < kc) ? (g[j].x - (s1 + z[j].x * s2)) * rs + r.x : 0.f;
-                o.y = (c + 1 < kc) ? (g[j].y - (s1 + z[j].y * s2)) * rs + r.y : 0.f;
-                o.z = (c + 2 < kc) ? (g[j].z - (s1 + z[j].z * s2)) * rs + r.z : 0.f;
-                o.w = (c + 3 < kc) ? (g[j].w - (s1 + z[j].w * s2)) * rs + r.w : 0.f;
-                *reinterpret_cast<float4*>(dx_out + (long long)m * C + c) = o;
+            for (int j = 0; j < MAXV; ++j) {
+                const int c = (lane + 64 * j) * 4;
+                if (c < C && rok[u]) {
+                    // channels >= keep get exactly 0 (also for the pass-through residual gradient): the reference lets
+                    // garbage flow there until the stage's `x * mask` kills it (nets/channel_drop.py:82); same param grads.
+                    const float4 r = rv[u][j];
+                    float4 o;
+                    o.x = (c + 0 < kc[u]) ? (g[j].x - (s1 + z[j].x * s2)) * rs[u] + r.x : 0.f;
+                    o.y = (c + 1 < kc[u]) ? (g[j].y - (s1 + z[j].y * s2)) * rs[u] + r.y : 0.f;
+                    o.z = (c + 2 < kc[u]) ? (g[j].z - (s1 + z[j].z * s2)) * rs[u] + r.z : 0.f;
+                    o.w = (c + 3 < kc[u]) ? (g[j].w - (s1 + z[j].w * s2)) * rs[u] + r.w : 0.f;
+                    *reinterpret_cast<float4*>(dx_out + (long long)m * C + c) = o;
+                }
             }
         }
     }
@@ -213,15 +230,16 @@ extern "C" int vr_ln_bwd(const void* dy, const float* x, const float* w, const f
     if (C % 4 || C > 64 * 4 * MAXV_LIMIT) return VR_EUNSUPPORTED;
     if (dy_dtype != VR_F32 && dy_dtype != VR_BF16) return VR_EUNSUPPORTED;
     if (rows_per_sample <= 0) rows_per_sample = M;
+    const int BWD_ROWS = M >= 32768 ? 64 : (M >= 8192 ? 32 : (M >= 2048 ? 8 : 4));
     dim3 grid((M + BWD_ROWS - 1) / BWD_ROWS);
     const int nv = (C + 255) / 256;
 #define VR_LN_BWD(NV)                                                                                                  \
     if (dy_dtype == VR_F32)                                                                                            \
         hipLaunchKernelGGL((ln_bwd_kernel<float, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, x, w, \
-                           mean, rstd, keep, dx_in, dx_out, dw, db, M, C, rows_per_sample);                            \
+                           mean, rstd, keep, dx_in, dx_out, dw, db, M, C, rows_per_sample, BWD_ROWS);                  \
     else                                                                                                               \
         hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, \
-                           w, mean, rstd, keep, dx_in, dx_out, dw, db, M, C, rows_per_sample);
+                           w, mean, rstd, keep, dx_in, dx_out, dw, db, M, C, rows_per_sample, BWD_ROWS);
     switch (nv) {
         case 1: VR_LN_BWD(1) break;
         case 2: VR_LN_BWD(2) break;
