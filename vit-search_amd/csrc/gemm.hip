@@ -761,7 +761,8 @@ void launch1(vr_gemm_args a, hipStream_t stream) {
     const int want_split = a.atomic ? max(1, min(a.K / 512, 1 << 16)) : 1;
     static const bool knob_big = !(std::getenv("VITRES_GEMM_BIG") && std::getenv("VITRES_GEMM_BIG")[0] == '0');
     static const bool knob_persist = !(std::getenv("VITRES_GEMM_PERSIST") && std::getenv("VITRES_GEMM_PERSIST")[0] == '0');
-    const bool big = knob_big && a.atomic && (a.M >= 192 && a.N >= 192) && big_tiles * want_split >= 192;
+    const bool shared = a.sched == 1;
+    const bool big = knob_big && !shared && a.atomic && (a.M >= 192 && a.N >= 192) && big_tiles * want_split >= 192;
     const long long tiles = big ? big_tiles : (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (a.atomic && a.split_k <= 0) a.split_k = (int)max(1LL, min((long long)want_split, max(1LL, 1024 / tiles)));
     const long long total = tiles * a.split_k;
@@ -769,7 +770,7 @@ void launch1(vr_gemm_args a, hipStream_t stream) {
         const int grid = (int)(knob_persist ? min(total, (long long)cu_count()) : total);   // 144 KB LDS: one workgroup per CU
         hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TO, EPI, CfgBig>), dim3(grid), dim3(CfgBig::NTHR), 0, stream, a);
     } else {
-        const int grid = (int)(knob_persist ? min(total, 2LL * cu_count()) : total);        // 72 KB LDS, <= 256 VGPR: two per CU
+        const int grid = (int)((knob_persist && !shared) ? min(total, 2LL * cu_count()) : total);        // 72 KB LDS, <= 256 VGPR: two per CU
         hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TO, EPI, CfgStd>), dim3(grid), dim3(CfgStd::NTHR), 0, stream, a);
     }
 }

@@ -27,7 +27,7 @@ class GemmArgs(ctypes.Structure):
         ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldu", c_int32),
         ("a_trans", c_int32), ("b_trans", c_int32),
         ("in_dtype", c_int32), ("out_dtype", c_int32),
-        ("act", c_int32), ("atomic", c_int32), ("split_k", c_int32), ("rows_in", c_int32), ("n_period", c_int32), ("k_period", c_int32),
+        ("act", c_int32), ("atomic", c_int32), ("split_k", c_int32), ("rows_in", c_int32), ("n_period", c_int32), ("k_period", c_int32), ("sched", c_int32),
         ("a_map", RowMap), ("b_map", RowMap), ("c_map", RowMap),
     ]
 

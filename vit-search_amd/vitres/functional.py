@@ -24,6 +24,44 @@ def _split_k(tokens, n_out=128, k_in=128):
     return max(1, min(tokens // 512, max(1, 1024 // tiles)))
 
 
+# ---- two-stream execution of independent GEMMs ----------------------------------------------------------------
+# The weight-gradient GEMM of a Linear and the data-gradient GEMM that feeds the next backward op are independent.
+# At ViT-Res shapes each alone leaves most of the chip idle in its prologue / epilogue / tail phases, so they are
+# issued on two streams (parallel branches once the step is captured into a hipGraph) with `sched=1` launches
+# (one workgroup per tile) so the hardware interleaves both kernels' workgroups on every CU.
+OVERLAP = True
+_side_streams = {}
+
+
+class _Side:
+    """`with _Side() as s:` runs the body on a side stream that first waits for everything queued on the current one;
+    call `.join()` (or leave the enclosing function through join_all) before tensors it reads are released."""
+
+    def __init__(self):
+        self.main = torch.cuda.current_stream()
+        dev = self.main.device
+        if dev not in _side_streams:
+            _side_streams[dev] = torch.cuda.Stream(device=dev)
+        self.side = _side_streams[dev]
+        self.ctx = None
+
+    def __enter__(self):
+        self.side.wait_stream(self.main)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        self.ctx.__exit__(*a)
+
+    def join(self):
+        self.main.wait_stream(self.side)
+
+
+def _overlap(x):
+    return OVERLAP and x.is_cuda
+
+
 class Weights:
     """Per-forward view of one Linear-like parameter pair in the compute dtype."""
     __slots__ = ("w", "b", "w_c", "ld")
@@ -33,12 +71,12 @@ class Weights:
 
 
 def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None, db=None, keep_rows=None,
-                 keep_cols=None, row_period=0, tokens_per_sample=0):
+                 keep_cols=None, row_period=0, tokens_per_sample=0, sched=0):
     """dw[N_out, K_in] += dy[M, N_out]^T @ x[M, K_in]  (fp32 atomics, split over tokens; db[N_out] += colsum(dy)).
     keep_rows / keep_cols: per-sample kept prefix of dy's / x's channels -> fully masked tiles are skipped."""
     K.gemm(dy, x, dw, M=N_out, N=K_in, K=M, lda=lddy, ldb=ldx, ldc=ldw or K_in, a_trans=True, b_trans=True,
            atomic=True, split_k=0, a_map=a_map, b_map=b_map, bias_grad=db,
-           keep_k=keep_rows, keep_n=keep_cols, k_period=row_period, rows_in=tokens_per_sample)
+           keep_k=keep_rows, keep_n=keep_cols, k_period=row_period, rows_in=tokens_per_sample, sched=sched)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -69,19 +107,40 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     H, D = cfg["heads"], cfg["head_dim"]
     HD = H * D
     dt = cfg["dtype"]
+    ov = _overlap(g)
+    sch = 1 if ov else 0
     gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                       # d(branch output), compute dtype
-    linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"], keep_rows=out_keep, keep_cols=attn_keep,
-                 tokens_per_sample=N)
+
+    def wgrad_proj():
+        linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"], keep_rows=out_keep, keep_cols=attn_keep,
+                     tokens_per_sample=N, sched=sch)
+    side = None
+    if ov:
+        side = _Side()
+        with side:
+            wgrad_proj()
+    else:
+        wgrad_proj()
     d_o = torch.empty((B, N, HD), dtype=dt, device=x.device)
     K.gemm(gt, p["proj"].w_c, d_o, M=M, N=HD, K=C, lda=C, ldb=p["proj"].ld, ldc=HD, b_trans=True, keep_n=attn_keep,
-           rows_in=N, keep_k=out_keep)
+           rows_in=N, keep_k=out_keep, sched=sch)
     dqkv = K.attn_bwd(qkv, o, d_o, lse, attn_keep, B, N, H, D, cfg["scale"])
-    linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C, db=grads["qkv.b"], keep_rows=attn_keep,
-                 keep_cols=embed_keep, row_period=HD, tokens_per_sample=N)
+
+    def wgrad_qkv():
+        linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C, db=grads["qkv.b"], keep_rows=attn_keep,
+                     keep_cols=embed_keep, row_period=HD, tokens_per_sample=N, sched=sch)
+    if ov:
+        with side:
+            wgrad_qkv()
+    else:
+        wgrad_qkv()
     dy = torch.empty((B, N, C), dtype=dt, device=x.device)
     K.gemm(dqkv, p["qkv"].w_c, dy, M=M, N=C, K=3 * HD, lda=3 * HD, ldb=p["qkv"].ld, ldc=C, b_trans=True, rows_in=N,
-           keep_k=attn_keep, k_period=HD, keep_n=embed_keep)
-    return K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, grads["n1w"], grads["n1b"])
+           keep_k=attn_keep, k_period=HD, keep_n=embed_keep, sched=sch)
+    out = K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, grads["n1w"], grads["n1b"])
+    if ov:
+        side.join()
+    return out
 
 
 def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save):
@@ -107,18 +166,39 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     M = B * N
     F = cfg["hidden"]
     dt = cfg["dtype"]
+    ov = _overlap(g)
+    sch = 1 if ov else 0
     gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
-    linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"], keep_rows=out_keep, keep_cols=mlp_keep,
-                 tokens_per_sample=N)
+
+    def wgrad_fc2():
+        linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"], keep_rows=out_keep, keep_cols=mlp_keep,
+                     tokens_per_sample=N, sched=sch)
+    side = None
+    if ov:
+        side = _Side()
+        with side:
+            wgrad_fc2()
+    else:
+        wgrad_fc2()
     du = torch.empty((B, N, F), dtype=dt, device=x.device)
     K.gemm(gt, p["fc2"].w_c, du, M=M, N=F, K=C, lda=C, ldb=p["fc2"].ld, ldc=F, b_trans=True, dact_u=u, ldu=F,
-           keep_n=mlp_keep, rows_in=N, keep_k=out_keep)
-    linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"], keep_rows=mlp_keep, keep_cols=embed_keep,
-                 tokens_per_sample=N)
+           keep_n=mlp_keep, rows_in=N, keep_k=out_keep, sched=sch)
+
+    def wgrad_fc1():
+        linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"], keep_rows=mlp_keep, keep_cols=embed_keep,
+                     tokens_per_sample=N, sched=sch)
+    if ov:
+        with side:
+            wgrad_fc1()
+    else:
+        wgrad_fc1()
     dy = torch.empty((B, N, C), dtype=dt, device=x.device)
     K.gemm(du, p["fc1"].w_c, dy, M=M, N=C, K=F, lda=F, ldb=p["fc1"].ld, ldc=C, b_trans=True, rows_in=N, keep_k=mlp_keep,
-           keep_n=embed_keep)
-    return K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"])
+           keep_n=embed_keep, sched=sch)
+    out = K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"])
+    if ov:
+        side.join()
+    return out
 
 
 # --------------------------------------------------------------------------------------------------

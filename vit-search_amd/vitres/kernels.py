@@ -48,13 +48,13 @@ def _rm(m):
 
 def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
          scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
-         a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0):
+         a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0):
     """out[M,N] = epilogue(a[M,K] @ b[N,K]^T) -- see vr_gemm in include/vitres_hip.h."""
     args = GemmArgs()
     args.A, args.B, args.C, args.C2 = _p(a), _p(b), _p(out), _p(out2)
     args.bias, args.pos, args.scale, args.keep_n = _p(bias), _p(pos), _p(scale), _p(keep_n)
     args.resid, args.dact_u, args.bias_grad, args.keep_k = _p(resid), _p(dact_u), _p(bias_grad), _p(keep_k)
-    args.n_period, args.k_period = n_period, k_period
+    args.n_period, args.k_period, args.sched = n_period, k_period, sched
     args.M, args.N, args.K = M, N, K
     args.lda, args.ldb, args.ldc, args.ldu = lda, ldb, ldc, ldu
     args.a_trans, args.b_trans = int(a_trans), int(b_trans)
@@ -65,12 +65,36 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     if PROFILE is None:
         _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
         return out
+    # algorithmic FLOPs of this launch = those of the kept (un-masked) sub-problems only (skipped work is never counted)
+    def kept(keep, dim, period):
+        if keep is None:
+            return None
+        k = keep.detach().to("cpu", torch.float64)
+        return torch.clamp(k, max=period) * (dim // period) if period else torch.clamp(k, max=dim)
+    if a_trans:                                   # wgrad: keep_k bounds output rows (M), keep_n output columns (N)
+        kr, kc = kept(keep_k, M, k_period), kept(keep_n, N, n_period)
+        if kr is None and kc is None:
+            flops = 2.0 * M * N * K
+        else:
+            nb = len(kr if kr is not None else kc)
+            kr = kr if kr is not None else torch.full((nb,), float(M), dtype=torch.float64)
+            kc = kc if kc is not None else torch.full((nb,), float(N), dtype=torch.float64)
+            flops = float((2.0 * rows_in * kr * kc).sum())
+    else:
+        kk, kn = kept(keep_k, K, k_period), kept(keep_n, N, n_period)
+        if kk is None and kn is None:
+            flops = 2.0 * M * N * K
+        else:
+            nb = len(kk if kk is not None else kn)
+            kk = kk if kk is not None else torch.full((nb,), float(K), dtype=torch.float64)
+            kn = kn if kn is not None else torch.full((nb,), float(N), dtype=torch.float64)
+            flops = float((2.0 * rows_in * kk * kn).sum())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
     e1.record()
     esz = a.element_size()
-    PROFILE.append((("bf16" if args.in_dtype == VR_BF16 else "f32", int(a_trans), int(b_trans)), 2.0 * M * N * K,
+    PROFILE.append((("bf16" if args.in_dtype == VR_BF16 else "f32", int(a_trans), int(b_trans)), flops, 2.0 * M * N * K,
                     float((M * K + N * K) * esz + M * N * out.element_size()), e0, e1))
     return out
 
