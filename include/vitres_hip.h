@@ -103,6 +103,25 @@ int vr_gemm(const vr_gemm_args* args, vr_stream_t stream);
 int vr_cast_f32_bf16(const float* src, void* dst, int64_t n, vr_stream_t stream);
 
 /*
+ * Transposed bf16 shadows of a batch of fp32 matrices in one launch: for every descriptor d,
+ *   dst[d.dst_off + c * d.ld_dst + r] = bf16(src[d.src_off + r * d.cols + c])   r < rows, c < cols
+ * (offsets in elements; ld_dst >= rows; columns rows..ld_dst of dst are not written -- keep them zero).
+ * The data-gradient GEMM of a Linear (autograd of F.linear, nets/supernet_blocks.py:41,110) then reads W^T K-contiguous
+ * like the forward reads W.  descs is a DEVICE array of n descriptors; max_tiles = max over d of
+ * ceil(rows/64) * ceil(cols/64).
+ */
+typedef struct vr_tr_desc {
+    int64_t src_off;
+    int64_t dst_off;
+    int32_t rows;
+    int32_t cols;
+    int32_t ld_dst;
+    int32_t reserved;
+} vr_tr_desc;
+int vr_cast_transpose_batch(const float* src, void* dst, const vr_tr_desc* descs, int32_t n, int32_t max_tiles,
+                            vr_stream_t stream);
+
+/*
  * Masked LayerNorm forward (nets/masked_layer_norm.py:23-50,113-125).  x fp32 [M,C] -> y (dtype) [M,C];
  * mean/rstd fp32 [M] saved for backward.  keep NULL -> plain LayerNorm (F.layer_norm path :118-122).
  */

@@ -80,6 +80,14 @@ def cast_bf16(src, dst):
     return dst
 
 
+def cast_transpose_batch(src, dst, descs):
+    _, _, entries = descs
+    for so, do, r, c, ld in entries:
+        w = src[so:so + r * c].view(r, c)
+        dst[do:do + c * ld].view(c, ld)[:, :r] = w.t().to(dst.dtype)
+    return dst
+
+
 def _keep_mask(keep, M, C, rps):
     if keep is None:
         return torch.ones(M, C, dtype=torch.bool), torch.full((M,), C, dtype=torch.float32)
@@ -291,7 +299,7 @@ def patch_fold(col, B, gh, gw, P, C):
     return x.reshape(B * gh * P * gw * P, C).clone()
 
 
-ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "cast_bf16", "ln_fwd", "ln_bwd", "attn_fwd", "attn_bwd", "softce", "colsum", "scale_mask_cast",
+ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "attn_fwd", "attn_bwd", "softce", "colsum", "scale_mask_cast",
        "batchsum", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
 
 

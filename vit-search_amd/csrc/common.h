@@ -34,8 +34,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair with the gfx950 converter (v_cvt_pk_bf16_f32: round-to-nearest-even, one instruction)
+typedef __bf16 vr_bf2 __attribute__((ext_vector_type(2)));
+typedef float vr_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const vr_f2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vr_bf2));
 }
 
 template <typename T> struct Elem;
@@ -67,6 +71,32 @@ __device__ __forceinline__ float dgelu_f(float u) {
     const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
     const float pdf = 0.39894228040143268f * __expf(-0.5f * u * u);
     return cdf + u * pdf;
+}
+
+// GELU for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution) -- one rcp, one
+// exp and 7 fma instead of libm's erff; the exp is shared with the derivative's pdf term.  Tails are evaluated without
+// cancellation (Phi(u) = 0.5 poly e for u < 0).
+__device__ __forceinline__ void gelu_terms_fast(float u, float& cdf, float& pdf) {
+    const float x = fabsf(u) * 0.70710678118654752f;
+    const float tt = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    const float e = __expf(-x * x);
+    float poly = fmaf(1.061405429f, tt, -1.453152027f);
+    poly = fmaf(poly, tt, 1.421413741f);
+    poly = fmaf(poly, tt, -0.284496736f);
+    poly = fmaf(poly, tt, 0.254829592f);
+    const float half_tail = 0.5f * poly * tt * e;            // 0.5 * erfc(|x|)
+    cdf = u >= 0.f ? 1.0f - half_tail : half_tail;
+    pdf = 0.39894228040143268f * e;
+}
+__device__ __forceinline__ float gelu_fast(float u) {
+    float c, d;
+    gelu_terms_fast(u, c, d);
+    return u * c;
+}
+__device__ __forceinline__ float dgelu_fast(float u) {
+    float c, d;
+    gelu_terms_fast(u, c, d);
+    return fmaf(u, d, c);
 }
 
 // token-row remap:  row(m) = (m / rpi) * rps + off + (m % rpi) ; rpi == 0 -> identity

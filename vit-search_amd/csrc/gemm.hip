@@ -22,8 +22,12 @@
 
 #include "common.h"
 #include "../../include/vitres_hip.h"
+#include "gemm_shared.h"
+
+bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream);   // gemm_nt.hip
 
 namespace {
+using namespace vr_gemm_shared;
 
 constexpr int LROW = 144;  // padded LDS row, bytes (128-byte K-slice payload)
 
@@ -294,28 +298,6 @@ template <typename TI> __device__ __forceinline__ void load4(const void* base, l
     }
 }
 
-__device__ __forceinline__ bool kept_col(int n, int period, int keep) { return (period > 0 ? n % period : n) < keep; }
-// does [x0, x0 + len) contain an index with (x % period) < keep ?
-__device__ __forceinline__ bool range_has_kept(int x0, int len, int period, int keep) {
-    if (keep <= 0) return false;
-    if (period <= 0) return x0 < keep;
-    const int r = x0 % period;
-    return r < keep || r + len > period;
-}
-__device__ __forceinline__ int max_keep(const int* keep, int s_lo, int s_hi, int dense) {
-    if (!keep) return dense;
-    int mk = 0;
-    for (int s = s_lo; s <= s_hi; ++s) mk = max(mk, keep[s]);
-    return mk;
-}
-
-// Epilogue flavours (compile-time, keeps every instantiation small enough to unroll fully):
-//   EPI_STORE : (+bias)(+pos) -> keep mask -> scale -> (+resid) -> store TO
-//   EPI_GELU  : (+bias) -> C = u, C2 = gelu(u) masked by keep            (Mlp.fc1)
-//   EPI_DGELU : * gelu'(u) -> keep mask -> store TO                        (fc2 dgrad)
-//   EPI_ATOMIC: keep mask/scale -> atomicAdd fp32                          (split-K wgrad)
-enum { EPI_STORE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_ATOMIC = 3 };
-
 // Epilogue of one lane = 2 output rows (i) x 8 column quads (j, g).  ALL global loads (bias, pos-embed, residual,
 // GELU pre-activation) are issued before the first store: on gfx950 vmcnt counts stores too, so a load issued after
 // a store cannot be waited for without draining that store (measured: 16 interleaved load/store pairs cost 14 us
@@ -410,7 +392,7 @@ __device__ __forceinline__ void epilogue_all(const vr_gemm_args& p, f32x16 (&acc
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = kc[e] ? v[e] : 0.f;       // masked hidden units: u = 0, gelu(u) = 0 (their K loop may be skipped)
-                        h[e] = kc[e] ? gelu_f(v[e]) : 0.f;
+                        h[e] = kc[e] ? (sizeof(T) == 2 ? gelu_fast(v[e]) : gelu_f(v[e])) : 0.f;
                     }
                     if (any) {
                         store4<TO>(p.C, oidx, v, vq[j][g], ok);
@@ -419,7 +401,7 @@ __device__ __forceinline__ void epilogue_all(const vr_gemm_args& p, f32x16 (&acc
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if constexpr (EPI == EPI_DGELU) v[e] *= dgelu_f(rv[j][g][e]);
+                        if constexpr (EPI == EPI_DGELU) v[e] *= (sizeof(T) == 2 ? dgelu_fast(rv[j][g][e]) : dgelu_f(rv[j][g][e]));
                         v[e] = kc[e] ? v[e] * sc[i] : 0.f;
                         if constexpr (EPI == EPI_STORE) v[e] += rv[j][g][e];
                     }
@@ -429,56 +411,6 @@ __device__ __forceinline__ void epilogue_all(const vr_gemm_args& p, f32x16 (&acc
     };
     [&]<int... Is>(std::integer_sequence<int, Is...>) { (row(std::integral_constant<int, Is>{}), ...); }
     (std::make_integer_sequence<int, MI>{});
-}
-
-// CW consecutive elements (CW = 4 or 8): 16-byte accesses whenever the group is whole and aligned
-template <typename TI, int CW> __device__ __forceinline__ void loadw(const void* base, long long idx, float (&v)[CW], bool vec,
-                                                                     int nvalid) {
-    const TI* p = reinterpret_cast<const TI*>(base) + idx;
-    if (vec) {
-        if constexpr (sizeof(TI) == 4) {
-#pragma unroll
-            for (int h = 0; h < CW / 4; ++h) {
-                const float4 x = *reinterpret_cast<const float4*>(p + 4 * h);
-                v[4 * h] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
-            }
-        } else if constexpr (CW == 8) {
-            const uint4 u = *reinterpret_cast<const uint4*>(p);
-            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                v[2 * h] = __uint_as_float(w[h] << 16);
-                v[2 * h + 1] = __uint_as_float(w[h] & 0xffff0000u);
-            }
-        } else {
-            const uint2 u = *reinterpret_cast<const uint2*>(p);
-            v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-            v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < CW; ++e) v[e] = Elem<TI>::ld(p + (e < nvalid ? e : 0));
-    }
-}
-template <typename TO, int CW> __device__ __forceinline__ void storew(void* base, long long idx, const float (&v)[CW], bool vec,
-                                                                      bool rowok, int nvalid) {
-    TO* p = reinterpret_cast<TO*>(base) + idx;
-    if (vec) {
-        if constexpr (sizeof(TO) == 4) {
-#pragma unroll
-            for (int h = 0; h < CW / 4; ++h)
-                *reinterpret_cast<float4*>(p + 4 * h) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
-        } else if constexpr (CW == 8) {
-            *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]),
-                                                      pack_bf2(v[6], v[7]));
-        } else {
-            *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < CW; ++e)
-            if (rowok && e < nvalid) Elem<TO>::st(p + e, v[e]);
-    }
 }
 
 // Epilogue through LDS (128x128 tile): the accumulators are parked in LDS as fp32 [128][132]; every thread then owns a
@@ -567,7 +499,7 @@ __device__ __forceinline__ void epilogue_lds(const vr_gemm_args& p, f32x16 (&acc
 #pragma unroll
                 for (int e = 0; e < CW; ++e) {
                     v[e] = kc[e] ? v[e] : 0.f;       // masked hidden units: u = 0, gelu(u) = 0 (their K loop may be skipped)
-                    h[e] = kc[e] ? gelu_f(v[e]) : 0.f;
+                    h[e] = kc[e] ? (sizeof(T) == 2 ? gelu_fast(v[e]) : gelu_f(v[e])) : 0.f;
                 }
                 if (any) {
                     storew<TO, CW>(p.C, oidx, v, vec, mok[q], nvalid);
@@ -576,7 +508,7 @@ __device__ __forceinline__ void epilogue_lds(const vr_gemm_args& p, f32x16 (&acc
             } else {
 #pragma unroll
                 for (int e = 0; e < CW; ++e) {
-                    if constexpr (EPI == EPI_DGELU) v[e] *= dgelu_f(rv[q][e]);
+                    if constexpr (EPI == EPI_DGELU) v[e] *= (sizeof(T) == 2 ? dgelu_fast(rv[q][e]) : dgelu_f(rv[q][e]));
                     v[e] = kc[e] ? v[e] * sc[q] : 0.f;
                     if constexpr (EPI == EPI_STORE) v[e] += rv[q][e];
                 }
@@ -612,7 +544,16 @@ __global__ __launch_bounds__(TC::NTHR, 2) void gemm_kernel(const vr_gemm_args p)
     int m0 = 0, n0 = 0, z = 0, kbeg = 0, kend = 0, ntiles = 0, kmax = 0;
     bool n_any = true, want_bg = false;
 
-    auto setup = [&](int tile) {
+    // Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2): give XCD x one contiguous run of the
+    // n-fastest tile order, so that the tiles sharing an A row panel run on the same L2 instead of fetching it 8 times.
+    const int xq = total >> 3, xr = total & 7;
+    const bool xcd_map = !(p.sched & 2) && total >= 16;
+    auto setup = [&](int ptile) {
+        int tile = ptile;
+        if (xcd_map) {
+            const int x = ptile & 7, i = ptile >> 3;
+            tile = x * xq + min(x, xr) + i;
+        }
         const int tn = tile % tiles_n, rest = tile / tiles_n;
         const int tm = rest % tiles_m;
         z = rest / tiles_m;
@@ -761,7 +702,7 @@ void launch1(vr_gemm_args a, hipStream_t stream) {
     const int want_split = a.atomic ? max(1, min(a.K / 512, 1 << 16)) : 1;
     static const bool knob_big = !(std::getenv("VITRES_GEMM_BIG") && std::getenv("VITRES_GEMM_BIG")[0] == '0');
     static const bool knob_persist = !(std::getenv("VITRES_GEMM_PERSIST") && std::getenv("VITRES_GEMM_PERSIST")[0] == '0');
-    const bool shared = a.sched == 1;
+    const bool shared = (a.sched & 1) != 0;
     const bool big = knob_big && !shared && a.atomic && (a.M >= 192 && a.N >= 192) && big_tiles * want_split >= 192;
     const long long tiles = big ? big_tiles : (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (a.atomic && a.split_k <= 0) a.split_k = (int)max(1LL, min((long long)want_split, max(1LL, 1024 / tiles)));
@@ -787,8 +728,9 @@ int launch(const vr_gemm_args& a, hipStream_t stream) {
         if (a.b_trans || of32 != (sizeof(T) == 4)) return VR_EUNSUPPORTED;
         launch1<T, false, false, T, EPI_GELU>(a, stream);
     } else if (a.dact_u) {
-        if (!a.b_trans || of32 != (sizeof(T) == 4)) return VR_EUNSUPPORTED;
-        launch1<T, false, true, T, EPI_DGELU>(a, stream);
+        if (of32 != (sizeof(T) == 4)) return VR_EUNSUPPORTED;
+        if (a.b_trans) launch1<T, false, true, T, EPI_DGELU>(a, stream);
+        else launch1<T, false, false, T, EPI_DGELU>(a, stream);
     } else if (!a.b_trans) {
         if (of32) launch1<T, false, false, float, EPI_STORE>(a, stream);
         else launch1<T, false, false, bf16_t, EPI_STORE>(a, stream);
@@ -834,6 +776,11 @@ extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
         (a.dact_u && ((uintptr_t)a.dact_u & 15)))
         return VR_EALIGN;
     if (a.in_dtype == VR_F32 && a.out_dtype == VR_BF16) return VR_EUNSUPPORTED;
+    static const bool knob_nt = !(std::getenv("VITRES_GEMM_NT") && std::getenv("VITRES_GEMM_NT")[0] == '0');
+    if (knob_nt && !(a.sched & 4) && vr_gemm_nt_launch(a, (hipStream_t)stream)) {
+        VR_CHECK_LAUNCH();
+        return VR_OK;
+    }
     if (a.in_dtype == VR_BF16) return launch<bf16_t>(a, (hipStream_t)stream);
     return launch<float>(a, (hipStream_t)stream);
 }

@@ -1,0 +1,297 @@
+// bf16 GEMM fast path for K-contiguous operands:  C[M,N] = epilogue(A[M,K] * B[N,K]^T)
+//
+// Forward of every nn.Linear on the ViT-Res hot path (reference nets/supernet_blocks.py:37-52,102-119) and, with the
+// transposed bf16 weight shadow, their data gradients.  vr_gemm (gemm.hip) dispatches here; semantics of every
+// vr_gemm_args field are identical to the general kernel.
+//
+// Structure (gfx950): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2 each owning 64x64 = 4x4
+// v_mfma_f32_16x16x32_bf16 tiles (64 accumulator registers -> <= 128 VGPRs -> 4 workgroups per CU).  One K slice =
+// 64 bf16 = 128 B per row; both operand slices (32 KB) are moved global -> LDS by LDS-DMA (global_load_lds_dwordx4:
+// no staging registers, no ds_write pass).  The slice is single-buffered: the four resident workgroups of a CU are
+// what overlaps one workgroup's load latency with another's MFMAs -- at K = 256..1280 a tile is only 4..20 slices
+// long, and the general kernel's two workgroups per CU with one slice in flight each were latency bound
+// (~1.5 us per slice).
+//
+// LDS image: row r of a tile = 8 slots of 16 B; slot p holds k-chunk p ^ ((r >> 1) & 7).  LDS-DMA writes lane-linear
+// (wave base + lane * 16), so the permutation is applied to each lane's SOURCE address; the fragment reads apply the
+// same XOR.  A ds_read_b128 lane group (16 consecutive rows, one k-chunk) then covers all 16 slots of the 256-B bank
+// row: conflict free.
+//
+// The MFMAs compute the transposed tile (weights as the first operand): a lane owns one output row and 4 consecutive
+// columns per accumulator.  The epilogue parks 32 rows x 64 columns per wave in that wave's own 8 KB of the (now idle)
+// slice buffer -- XOR-swizzled, no workgroup barrier -- and reads it back as whole rows: every store instruction
+// writes 8 rows x 128 B (bf16) of full cache lines, side inputs (residual, GELU pre-activation, pos-embed) are loaded
+// with the same shape, all loads of a round before its first store (vmcnt counts stores).
+#include "common.h"
+#include "../../include/vitres_hip.h"
+#include "gemm_shared.h"
+
+namespace vr_gemm_nt {
+using namespace vr_gemm_shared;
+
+typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHR = 256;
+constexpr int TILE_BYTES = BM * BK * 2;   // 16 KB per operand slice
+
+__device__ const uint4 zero_chunk[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+
+// per-row epilogue metadata, computed once per tile by threads 0..127 while the first slice is in flight
+struct RowMeta {
+    int keep;      // kept output-column prefix of the row's sample (1 << 30: dense)
+    float scale;   // DropPath scale of the row's sample
+    int orow;      // output row after c_map, -1: row >= M
+    int mloc;      // row index inside its sample (pos-embed row)
+};
+
+// FAST: N % 8 == 0, ldc / ldu % 8 == 0, n_period % 8 == 0 (checked on the host) -- every lane's 8-column group is whole
+// or entirely outside the matrix, so the epilogue is branch-free 16-byte accesses.
+template <typename TO, int EPI, bool FAST>
+__global__ __launch_bounds__(NTHR, 4) void nt_kernel(const vr_gemm_args p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * TILE_BYTES];   // [A slice][B slice]; epilogue: 4 x 8 KB
+    __shared__ RowMeta rowmeta[BM];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int total = tiles_n * tiles_m;
+    // workgroup ids are dealt round-robin to the 8 XCDs: give each XCD one contiguous run of the n-fastest tile order
+    int tile = blockIdx.x;
+    if (total >= 16) {
+        const int xq = total >> 3, xr = total & 7, x = tile & 7;
+        tile = x * xq + min(x, xr) + (tile >> 3);
+    }
+    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const RowMap amap = {p.a_map.rpi, p.a_map.rps, p.a_map.off};
+    const RowMap bmap = {p.b_map.rpi, p.b_map.rps, p.b_map.off};
+
+    // ---- masked-work skipping (same rules as the general kernel) ----
+    int ntiles = (p.K + BK - 1) / BK;
+    if (p.sched & 8) ntiles = 0;      // ABLATION knob: bit 3 drops the K loop
+    int kmax = 1 << 30;
+    bool n_any = true;
+    if (p.keep_k || p.keep_n) {
+        int s_lo = 0, s_hi = 0;
+        if (p.rows_in > 0) { s_lo = m0 / p.rows_in; s_hi = (min(m0 + BM, p.M) - 1) / p.rows_in; }
+        kmax = max_keep(p.keep_k, s_lo, s_hi, 1 << 30);
+        const int nmax = max_keep(p.keep_n, s_lo, s_hi, 1 << 30);
+        n_any = range_has_kept(n0, BN, p.n_period, nmax);
+    }
+    auto slice_live = [&](int kt) -> bool {
+        return n_any && (p.keep_k == nullptr || range_has_kept(kt * BK, BK, p.k_period, kmax));
+    };
+    auto next_live = [&](int kt) -> int {
+        while (kt < ntiles && !slice_live(kt)) ++kt;
+        return kt;
+    };
+
+    // ---- LDS-DMA source addressing: piece h of this wave = tile rows wave*32 + 8h .. +8, lane -> (row, slot) ----
+    const char* gA[4];
+    const char* gB[4];
+    int chunk[4];                  // element offset of this lane's k-chunk inside a slice
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int r = wave * 32 + h * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int ma = min(m0 + r, p.M - 1), nb = min(n0 + r, p.N - 1);
+        gA[h] = reinterpret_cast<const char*>(p.A) + (map_row(amap, ma) * (long long)p.lda + c * 8) * 2;
+        gB[h] = reinterpret_cast<const char*>(p.B) + (map_row(bmap, nb) * (long long)p.ldb + c * 8) * 2;
+        chunk[h] = c * 8;
+    }
+    const char* zero = reinterpret_cast<const char*>(zero_chunk);
+    const bool ktail = (p.K % BK) != 0;
+
+    // ---- fragment read offsets: lane -> row (lane & 15) of a 16-row group, k-chunk 4 s + (lane >> 4) ----
+    const int frow = lane & 15, fswz = (frow >> 1) & 7;
+    const int slot0 = (((lane >> 4)) ^ fswz) << 4, slot1 = ((4 + (lane >> 4)) ^ fswz) << 4;
+    const char* As = smem + (wm * 64 + frow) * 128;
+    const char* Bs = smem + TILE_BYTES + (wn * 64 + frow) * 128;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int kt) {
+        const int k0 = kt * BK;
+        const long long kb = (long long)k0 * 2;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const bool in = !ktail || (k0 + chunk[h] < p.K);
+            const char* sa = in ? gA[h] + kb : zero;
+            const char* sb = in ? gB[h] + kb : zero;
+            __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(smem + (wave * 32 + h * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(smem + TILE_BYTES + (wave * 32 + h * 8) * 128), 16,
+                                             0, 0);
+        }
+    };
+
+    int kt = next_live(0);
+    if (kt < ntiles) issue(kt);
+    // row metadata (its loads overlap the first slice)
+    if (t < BM) {
+        const int m = m0 + t;
+        RowMeta rm;
+        rm.keep = 1 << 30; rm.scale = 1.0f; rm.orow = -1; rm.mloc = 0;
+        if (m < p.M) {
+            const int sample = p.rows_in > 0 ? m / p.rows_in : 0;
+            rm.mloc = p.rows_in > 0 ? m - sample * p.rows_in : m;
+            rm.orow = (int)map_row({p.c_map.rpi, p.c_map.rps, p.c_map.off}, m);
+            if (p.scale) rm.scale = p.scale[sample];
+            if (p.keep_n) rm.keep = p.keep_n[sample];
+        }
+        rowmeta[t] = rm;
+    }
+    if (kt >= ntiles) __syncthreads();
+    while (kt < ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int so = s == 0 ? slot0 : slot1;
+            bfv8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bfv8*>(As + i * 2048 + so);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bfv8*>(Bs + j * 2048 + so);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        kt = next_live(kt + 1);
+        if (kt < ntiles) issue(kt);
+    }
+
+    // ---- epilogue: lane owns C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) + 0..3] of the wave's 64 x 64 ----
+    constexpr int CW = 8;
+    float* park = reinterpret_cast<float*>(smem + wave * 8192);      // [32 rows][16 slots of 4 floats], slot ^= row & 15
+    const int n = n0 + wn * 64 + (lane & 7) * 8;                      // this lane's 8 columns
+    const int nvalid = min(CW, p.N - n);
+    const int nc = nvalid > 0 ? n : 0;
+    const int nv = nvalid > 0 ? nvalid : 1;
+    constexpr int OALIGN = sizeof(TO) == 2 ? 8 : 4;
+    const bool vec = FAST || (nvalid == CW && (p.ldc % OALIGN == 0) && (EPI != EPI_DGELU || p.ldu % 8 == 0));
+    const bool vecb = FAST || (nvalid == CW && (p.N % 4 == 0));
+    // prefix masks: the lane's 8 columns sit at ncp.. inside their period (periods are multiples of 8 on this path, so a
+    // group never wraps; other periods take the per-element test)
+    const bool grp = FAST || p.n_period <= 0 || (p.n_period & 7) == 0;
+    const int ncp = p.n_period > 0 ? nc % p.n_period : nc;
+    float bv[CW];
+#pragma unroll
+    for (int e = 0; e < CW; ++e) bv[e] = 0.f;
+    if ((EPI == EPI_STORE || EPI == EPI_GELU) && p.bias) loadw<float, CW>(p.bias, nc, bv, vecb, nv);
+    const bool has_pos = (EPI == EPI_STORE) && p.pos;
+    const bool has_res = (EPI == EPI_STORE) && p.resid;
+    const bool live = nvalid > 0 && !(p.sched & 16);                  // ABLATION knob: bit 4 drops the stores
+    const RowMeta* meta = rowmeta + wm * 64 + (lane >> 3);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ml = ii * 16 + (lane & 15);
+                const int slot = (4 * j + (lane >> 4)) ^ (lane & 15);
+                *reinterpret_cast<f32x4*>(park + ml * 64 + slot * 4) = acc[2 * rr + ii][j];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            RowMeta rm[2];
+            long long orow[2];
+            float rv[2][CW], pv[2][CW];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                rm[q] = meta[rr * 32 + (2 * qb + q) * 8];
+                orow[q] = rm[q].orow < 0 ? 0 : rm[q].orow;
+#pragma unroll
+                for (int e = 0; e < CW; ++e) { rv[q][e] = 0.f; pv[q][e] = 0.f; }
+                if constexpr (EPI == EPI_DGELU) loadw<bf16_t, CW>(p.dact_u, orow[q] * p.ldu + nc, rv[q], vec, nv);
+                if constexpr (EPI == EPI_STORE) {
+                    if (has_res) loadw<float, CW>(p.resid, orow[q] * p.ldc + nc, rv[q], vec, nv);
+                    if (has_pos) loadw<float, CW>(p.pos, (long long)rm[q].mloc * p.N + nc, pv[q], vecb, nv);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int rl = (2 * qb + q) * 8 + (lane >> 3);
+                const bool mok = rm[q].orow >= 0;
+                const int kn = rm[q].keep - ncp;
+                const float sc = rm[q].scale;
+                float v[CW];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int slot = (2 * (lane & 7) + h) ^ (rl & 15);
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(park + rl * 64 + slot * 4);
+                    v[4 * h] = a4[0]; v[4 * h + 1] = a4[1]; v[4 * h + 2] = a4[2]; v[4 * h + 3] = a4[3];
+                }
+                bool kc[CW];
+#pragma unroll
+                for (int e = 0; e < CW; ++e) {
+                    v[e] += bv[e] + pv[q][e];
+                    kc[e] = grp ? (e < kn) : kept_col(nc + e, p.n_period, rm[q].keep);
+                }
+                const bool any = mok && live;
+                const long long oidx = orow[q] * p.ldc + nc;
+                if constexpr (EPI == EPI_GELU) {
+                    float hh[CW];
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) {
+                        v[e] = kc[e] ? v[e] : 0.f;       // masked hidden units: u = 0, gelu(u) = 0 (their K loop may be skipped)
+                        hh[e] = kc[e] ? gelu_fast(v[e]) : 0.f;
+                    }
+                    if (any) {
+                        storew<TO, CW>(p.C, oidx, v, vec, mok, nvalid);
+                        storew<TO, CW>(p.C2, oidx, hh, vec, mok, nvalid);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) {
+                        if constexpr (EPI == EPI_DGELU) v[e] *= dgelu_fast(rv[q][e]);
+                        v[e] = kc[e] ? v[e] * sc : 0.f;
+                        if constexpr (EPI == EPI_STORE) v[e] += rv[q][e];
+                    }
+                    if (any) storew<TO, CW>(p.C, oidx, v, vec, mok, nvalid);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t stream) {
+    const long long total = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);
+    if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    else hipLaunchKernelGGL((nt_kernel<TO, EPI, false>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+}
+
+}  // namespace vr_gemm_nt
+
+// Called by vr_gemm after validation.  Returns false when the form is not covered here.
+bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream) {
+    using namespace vr_gemm_nt;
+    if (a.in_dtype != VR_BF16 || a.a_trans || a.b_trans || a.atomic || a.split_k > 1 || a.bias_grad) return false;
+    const bool of32 = a.out_dtype == VR_F32;
+    if (a.act == 1) {
+        if (of32) return false;
+        launch1<bf16_t, EPI_GELU>(a, stream);
+    } else if (a.dact_u) {
+        if (of32) return false;
+        launch1<bf16_t, EPI_DGELU>(a, stream);
+    } else if (of32) {
+        launch1<float, EPI_STORE>(a, stream);
+    } else {
+        launch1<bf16_t, EPI_STORE>(a, stream);
+    }
+    return true;
+}

@@ -1,0 +1,79 @@
+// Pieces shared by the GEMM kernels (gemm.hip: all forms, both precisions; gemm_nt.hip: bf16 K-contiguous fast path).
+#pragma once
+#include "common.h"
+
+namespace vr_gemm_shared {
+
+__device__ __forceinline__ bool kept_col(int n, int period, int keep) { return (period > 0 ? n % period : n) < keep; }
+// does [x0, x0 + len) contain an index with (x % period) < keep ?
+__device__ __forceinline__ bool range_has_kept(int x0, int len, int period, int keep) {
+    if (keep <= 0) return false;
+    if (period <= 0) return x0 < keep;
+    const int r = x0 % period;
+    return r < keep || r + len > period;
+}
+__device__ __forceinline__ int max_keep(const int* keep, int s_lo, int s_hi, int dense) {
+    if (!keep) return dense;
+    int mk = 0;
+    for (int s = s_lo; s <= s_hi; ++s) mk = max(mk, keep[s]);
+    return mk;
+}
+
+// Epilogue flavours (compile-time, keeps every instantiation small enough to unroll fully):
+//   EPI_STORE : (+bias)(+pos) -> keep mask -> scale -> (+resid) -> store TO
+//   EPI_GELU  : (+bias) -> C = u, C2 = gelu(u) masked by keep            (Mlp.fc1)
+//   EPI_DGELU : * gelu'(u) -> keep mask -> store TO                        (fc2 dgrad)
+//   EPI_ATOMIC: keep mask/scale -> atomicAdd fp32                          (split-K wgrad)
+enum { EPI_STORE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_ATOMIC = 3 };
+
+// CW consecutive elements (CW = 4 or 8): 16-byte accesses whenever the group is whole and aligned
+template <typename TI, int CW> __device__ __forceinline__ void loadw(const void* base, long long idx, float (&v)[CW], bool vec,
+                                                                     int nvalid) {
+    const TI* p = reinterpret_cast<const TI*>(base) + idx;
+    if (vec) {
+        if constexpr (sizeof(TI) == 4) {
+#pragma unroll
+            for (int h = 0; h < CW / 4; ++h) {
+                const float4 x = *reinterpret_cast<const float4*>(p + 4 * h);
+                v[4 * h] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
+            }
+        } else if constexpr (CW == 8) {
+            const uint4 u = *reinterpret_cast<const uint4*>(p);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                v[2 * h] = __uint_as_float(w[h] << 16);
+                v[2 * h + 1] = __uint_as_float(w[h] & 0xffff0000u);
+            }
+        } else {
+            const uint2 u = *reinterpret_cast<const uint2*>(p);
+            v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+            v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < CW; ++e) v[e] = Elem<TI>::ld(p + (e < nvalid ? e : 0));
+    }
+}
+template <typename TO, int CW> __device__ __forceinline__ void storew(void* base, long long idx, const float (&v)[CW], bool vec,
+                                                                      bool rowok, int nvalid) {
+    TO* p = reinterpret_cast<TO*>(base) + idx;
+    if (vec) {
+        if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+            for (int h = 0; h < CW / 4; ++h)
+                *reinterpret_cast<float4*>(p + 4 * h) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+        } else if constexpr (CW == 8) {
+            *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]),
+                                                      pack_bf2(v[6], v[7]));
+        } else {
+            *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < CW; ++e)
+            if (rowok && e < nvalid) Elem<TO>::st(p + e, v[e]);
+    }
+}
+
+}  // namespace vr_gemm_shared

@@ -20,6 +20,30 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
     }
 }
 
+// ---- batch of fp32 [rows, cols] -> bf16 [cols, ld] transposes (64 x 64 tiles through LDS, both sides coalesced) ----
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             const vr_tr_desc* __restrict__ descs) {
+    __shared__ float tile[64][65];
+    const vr_tr_desc d = descs[blockIdx.y];
+    const int tc = (d.cols + 63) / 64, tr = (d.rows + 63) / 64;
+    if ((int)blockIdx.x >= tc * tr) return;
+    const int r0 = ((int)blockIdx.x / tc) * 64, c0 = ((int)blockIdx.x % tc) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float* s = src + d.src_off;
+    bf16_t* o = dst + d.dst_off;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        tile[ty + 4 * i][tx] = (r < d.rows && c < d.cols) ? s[(long long)r * d.cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < d.cols && r < d.rows) o[(long long)c * d.ld_dst + r] = f2bf(tile[tx][ty + 4 * i]);
+    }
+}
+
 // ---- soft-target cross entropy: wave per row -----------------------------------------------------------
 __global__ __launch_bounds__(256) void softce_kernel(const float* __restrict__ x, const float* __restrict__ t,
                                                      float* __restrict__ loss, float* __restrict__ dx, int R, int K,
@@ -230,6 +254,15 @@ extern "C" int vr_cast_f32_bf16(const float* src, void* dst, int64_t n, vr_strea
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(cast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long long)n);
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_cast_transpose_batch(const float* src, void* dst, const vr_tr_desc* descs, int32_t n, int32_t max_tiles,
+                                       vr_stream_t stream) {
+    if (!src || !dst || !descs || n <= 0 || max_tiles <= 0) return VR_EINVAL;
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)max_tiles, (unsigned)n), dim3(256), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst, descs);
     VR_CHECK_LAUNCH();
     return VR_OK;
 }

@@ -29,33 +29,37 @@ def _split_k(tokens, n_out=128, k_in=128):
 # At ViT-Res shapes each alone leaves most of the chip idle in its prologue / epilogue / tail phases, so they are
 # issued on two streams (parallel branches once the step is captured into a hipGraph) with `sched=1` launches
 # (one workgroup per tile) so the hardware interleaves both kernels' workgroups on every CU.
-OVERLAP = True
+import os as _os
+OVERLAP = _os.environ.get('VITRES_OVERLAP', '1') != '0'
+DEFER_JOIN = _os.environ.get('VITRES_OVERLAP', '1') == '2'
 _side_streams = {}
 
 
-class _Side:
-    """`with _Side() as s:` runs the body on a side stream that first waits for everything queued on the current one;
-    call `.join()` (or leave the enclosing function through join_all) before tensors it reads are released."""
+_pending = []            # tensors the side stream may still be reading
 
-    def __init__(self):
-        self.main = torch.cuda.current_stream()
-        dev = self.main.device
-        if dev not in _side_streams:
-            _side_streams[dev] = torch.cuda.Stream(device=dev)
-        self.side = _side_streams[dev]
-        self.ctx = None
 
-    def __enter__(self):
-        self.side.wait_stream(self.main)
-        self.ctx = torch.cuda.stream(self.side)
-        self.ctx.__enter__()
-        return self
+def on_side(fn, *keepalive):
+    """Run fn() on the side stream after everything queued so far on the current stream; the tensors it reads are kept
+    alive (so the caching allocator cannot hand them out again) until join_side()."""
+    main = torch.cuda.current_stream()
+    dev = main.device
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        fn()
+    _pending.extend(keepalive)
 
-    def __exit__(self, *a):
-        self.ctx.__exit__(*a)
 
-    def join(self):
-        self.main.wait_stream(self.side)
+def join_side():
+    """Current stream waits for all side-stream work issued so far."""
+    if _pending or _side_streams:
+        main = torch.cuda.current_stream()
+        side = _side_streams.get(main.device)
+        if side is not None:
+            main.wait_stream(side)
+    _pending.clear()
 
 
 def _overlap(x):
@@ -64,10 +68,20 @@ def _overlap(x):
 
 class Weights:
     """Per-forward view of one Linear-like parameter pair in the compute dtype."""
-    __slots__ = ("w", "b", "w_c", "ld")
+    __slots__ = ("w", "b", "w_c", "ld", "w_t", "ld_t")
 
-    def __init__(self, w, b, w_c, ld):
+    def __init__(self, w, b, w_c, ld, w_t=None, ld_t=0):
         self.w, self.b, self.w_c, self.ld = w, b, w_c, ld   # fp32 param, fp32 bias, compute-dtype matrix [out, ld]
+        self.w_t, self.ld_t = w_t, ld_t                     # transposed bf16 shadow [in, ld_t] (None: fp32 / absent)
+
+
+def linear_dgrad(dy, W, dx, M, N_in, K_out, lddy, lddx, **kw):
+    """dx[M, N_in] = epilogue(dy[M, K_out] @ W[K_out, N_in]).  With the transposed shadow both operands are
+    K-contiguous (the LDS-DMA kernel); otherwise W is read contraction-major by the general kernel."""
+    if W.w_t is not None and lddy % 8 == 0:
+        K.gemm(dy, W.w_t, dx, M=M, N=N_in, K=K_out, lda=lddy, ldb=W.ld_t, ldc=lddx, **kw)
+    else:
+        K.gemm(dy, W.w_c, dx, M=M, N=N_in, K=K_out, lda=lddy, ldb=W.ld, ldc=lddx, b_trans=True, **kw)
 
 
 def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None, db=None, keep_rows=None,
@@ -114,32 +128,27 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     def wgrad_proj():
         linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"], keep_rows=out_keep, keep_cols=attn_keep,
                      tokens_per_sample=N, sched=sch)
-    side = None
     if ov:
-        side = _Side()
-        with side:
-            wgrad_proj()
+        on_side(wgrad_proj, gt)
     else:
         wgrad_proj()
     d_o = torch.empty((B, N, HD), dtype=dt, device=x.device)
-    K.gemm(gt, p["proj"].w_c, d_o, M=M, N=HD, K=C, lda=C, ldb=p["proj"].ld, ldc=HD, b_trans=True, keep_n=attn_keep,
-           rows_in=N, keep_k=out_keep, sched=sch)
+    linear_dgrad(gt, p["proj"], d_o, M, HD, C, C, HD, keep_n=attn_keep, rows_in=N, keep_k=out_keep, sched=sch)
     dqkv = K.attn_bwd(qkv, o, d_o, lse, attn_keep, B, N, H, D, cfg["scale"])
 
     def wgrad_qkv():
         linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C, db=grads["qkv.b"], keep_rows=attn_keep,
                      keep_cols=embed_keep, row_period=HD, tokens_per_sample=N, sched=sch)
     if ov:
-        with side:
-            wgrad_qkv()
+        on_side(wgrad_qkv, dqkv)
     else:
         wgrad_qkv()
     dy = torch.empty((B, N, C), dtype=dt, device=x.device)
-    K.gemm(dqkv, p["qkv"].w_c, dy, M=M, N=C, K=3 * HD, lda=3 * HD, ldb=p["qkv"].ld, ldc=C, b_trans=True, rows_in=N,
-           keep_k=attn_keep, k_period=HD, keep_n=embed_keep, sched=sch)
+    linear_dgrad(dqkv, p["qkv"], dy, M, C, 3 * HD, 3 * HD, C, rows_in=N, keep_k=attn_keep, k_period=HD, keep_n=embed_keep,
+                 sched=sch)
     out = K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, grads["n1w"], grads["n1b"])
-    if ov:
-        side.join()
+    if ov and not DEFER_JOIN:
+        join_side()
     return out
 
 
@@ -173,31 +182,25 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     def wgrad_fc2():
         linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"], keep_rows=out_keep, keep_cols=mlp_keep,
                      tokens_per_sample=N, sched=sch)
-    side = None
     if ov:
-        side = _Side()
-        with side:
-            wgrad_fc2()
+        on_side(wgrad_fc2, gt)
     else:
         wgrad_fc2()
     du = torch.empty((B, N, F), dtype=dt, device=x.device)
-    K.gemm(gt, p["fc2"].w_c, du, M=M, N=F, K=C, lda=C, ldb=p["fc2"].ld, ldc=F, b_trans=True, dact_u=u, ldu=F,
-           keep_n=mlp_keep, rows_in=N, keep_k=out_keep, sched=sch)
+    linear_dgrad(gt, p["fc2"], du, M, F, C, C, F, dact_u=u, ldu=F, keep_n=mlp_keep, rows_in=N, keep_k=out_keep, sched=sch)
 
     def wgrad_fc1():
         linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"], keep_rows=mlp_keep, keep_cols=embed_keep,
                      tokens_per_sample=N, sched=sch)
     if ov:
-        with side:
-            wgrad_fc1()
+        on_side(wgrad_fc1, du)
     else:
         wgrad_fc1()
     dy = torch.empty((B, N, C), dtype=dt, device=x.device)
-    K.gemm(du, p["fc1"].w_c, dy, M=M, N=C, K=F, lda=F, ldb=p["fc1"].ld, ldc=C, b_trans=True, rows_in=N, keep_k=mlp_keep,
-           keep_n=embed_keep, sched=sch)
+    linear_dgrad(du, p["fc1"], dy, M, C, F, F, C, rows_in=N, keep_k=mlp_keep, keep_n=embed_keep, sched=sch)
     out = K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"])
-    if ov:
-        side.join()
+    if ov and not DEFER_JOIN:
+        join_side()
     return out
 
 
@@ -241,12 +244,10 @@ def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep):
     K.batchsum(gout, grads["pos_sum"])                                      # [No, Co]; rows 1.. are d pos_embed
     linear_wgrad(gt, col, grads["reduce.w"], B * P, Co, 9 * C, Co, 9 * C, a_map=(P, No, 1), db=grads["reduce.b"])
     dcol = torch.empty((B * P, 9 * C), dtype=dt, device=x.device)
-    K.gemm(gt, p["reduce"].w_c, dcol, M=B * P, N=9 * C, K=Co, lda=Co, ldb=p["reduce"].ld, ldc=9 * C, b_trans=True,
-           a_map=(P, No, 1), rows_in=P)
+    linear_dgrad(gt, p["reduce"], dcol, B * P, 9 * C, Co, Co, 9 * C, a_map=(P, No, 1), rows_in=P)
     dy = torch.empty((B, Ni, C), dtype=dt, device=x.device)
     K.sr_col2im(dcol, dy, B, g, C)
-    K.gemm(gt, p["token"].w_c, dy, M=B, N=C, K=Co, lda=Co, ldb=p["token"].ld, ldc=C, b_trans=True, a_map=(1, No, 0),
-           c_map=(1, Ni, 0), rows_in=1)
+    linear_dgrad(gt, p["token"], dy, B, C, Co, Co, C, a_map=(1, No, 0), c_map=(1, Ni, 0), rows_in=1)
     gres = K.sr_resid_bwd(gout, B, g, C, Co)
     return K.ln_bwd(dy, x, p["nw"], mean, rstd, embed_keep, Ni, gres, grads["nw"], grads["nb"])
 
@@ -312,11 +313,10 @@ def head_bwd(dcls, dpat, saved, p, grads, cfg, keep):
     if dcls is not None:
         gc = padded(dcls.reshape(B, nc))
         linear_wgrad(gc, y, grads["cls.w"], B, nc, C, ldp, C, b_map=(1, N, 0), db=grads["cls.b"])
-        K.gemm(gc, p["cls"].w_c, dy, M=B, N=C, K=nc, lda=ldp, ldb=p["cls"].ld, ldc=C, b_trans=True, c_map=(1, N, 0))
+        linear_dgrad(gc, p["cls"], dy, B, C, nc, ldp, C, c_map=(1, N, 0))
     if dpat is not None:
         R = B * (N - 1)
         gp = padded(dpat.reshape(R, nc))
         linear_wgrad(gp, y, grads["patch.w"], R, nc, C, ldp, C, b_map=(N - 1, N, 1), db=grads["patch.b"])
-        K.gemm(gp, p["patch"].w_c, dy, M=R, N=C, K=nc, lda=ldp, ldb=p["patch"].ld, ldc=C, b_trans=True,
-               c_map=(N - 1, N, 1))
+        linear_dgrad(gp, p["patch"], dy, R, C, nc, ldp, C, c_map=(N - 1, N, 1))
     return K.ln_bwd(dy, x, p["nw"], mean, rstd, keep, N, None, grads["nw"], grads["nb"])

@@ -104,6 +104,25 @@ def cast_bf16(src, dst):
     return dst
 
 
+def tr_descs(entries, device):
+    """entries: [(src_off, dst_off, rows, cols, ld_dst)] -> (device descriptor array for cast_transpose_batch, max tiles)."""
+    import numpy as np
+    arr = np.zeros(len(entries), dtype=np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("rows", "<i4"), ("cols", "<i4"),
+                                                 ("ld_dst", "<i4"), ("reserved", "<i4")]))
+    for i, (so, do, r, c, ld) in enumerate(entries):
+        arr[i] = (so, do, r, c, ld, 0)
+    max_tiles = max(((r + 63) // 64) * ((c + 63) // 64) for _, _, r, c, _ in entries)
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), max_tiles, list(entries)
+
+
+def cast_transpose_batch(src, dst, descs):
+    """dst (bf16, pre-zeroed pads) <- transposed bf16 copies of the fp32 matrices described by tr_descs()."""
+    dev, max_tiles, entries = descs
+    _lib.check(_lib.lib().vr_cast_transpose_batch(_p(src), _p(dst), _p(dev), len(entries), max_tiles, _stream()),
+               "vr_cast_transpose_batch")
+    return dst
+
+
 def ln_fwd(x, w, b, keep, rows_per_sample, eps, out_dtype):
     M, C = x.numel() // x.shape[-1], x.shape[-1]
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)

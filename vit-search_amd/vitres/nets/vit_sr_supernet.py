@@ -307,7 +307,22 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 flat[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = flat[off:off + n].view(p.shape)
         a = {"flat": flat, "params": params, "offsets": offsets, "index": {id(p): i for i, p in enumerate(params)},
-             "shadow": torch.empty(total, dtype=torch.bfloat16, device=device), "gflat": None}
+             "shadow": torch.empty(total, dtype=torch.bfloat16, device=device), "gflat": None, "tmap": {}, "tr": None}
+        # transposed bf16 shadows W^T [in, roundup(out, 8)] of every nn.Linear weight: the data-gradient GEMMs then read
+        # their weights K-contiguous, like the forward (one batched transposing cast per step)
+        if self.compute_dtype == torch.bfloat16:
+            entries, tot_t = [], 0
+            for mod in self.modules():
+                if isinstance(mod, nn.Linear) and id(mod.weight) in a["index"]:
+                    w = mod.weight
+                    out_f, in_f = w.shape
+                    ld_t = (out_f + 7) // 8 * 8
+                    a["tmap"][id(w)] = (tot_t, ld_t)
+                    entries.append((offsets[a["index"][id(w)]][0], tot_t, out_f, in_f, ld_t))
+                    tot_t += in_f * ld_t
+            if entries:
+                a["shadow_t"] = torch.zeros(tot_t, dtype=torch.bfloat16, device=device)
+                a["tr"] = K.tr_descs(entries, device)
         self._arena = a
         return a
 
@@ -322,7 +337,12 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
 
     def _lin(self, m, wkey=None):
         w = self._wc(m.weight)
-        return Fn.Weights(m.weight, m.bias.detach() if m.bias is not None else None, w, w.shape[1])
+        a = self._arena
+        w_t, ld_t = None, 0
+        if id(m.weight) in a["tmap"]:
+            off_t, ld_t = a["tmap"][id(m.weight)]
+            w_t = a["shadow_t"][off_t:off_t + m.weight.shape[1] * ld_t].view(m.weight.shape[1], ld_t)
+        return Fn.Weights(m.weight, m.bias.detach() if m.bias is not None else None, w, w.shape[1], w_t, ld_t)
 
     def _gview(self, p):
         a = self._arena
@@ -455,8 +475,10 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         if isinstance(blk, SpatialReductionPatchEmbedding):
             w = blk.patch_reduce.weight
             wperm = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(self.compute_dtype).contiguous()
+            wperm_t = wperm.t().contiguous() if self.compute_dtype == torch.bfloat16 and wperm.shape[0] % 8 == 0 else None
             return {"nw": blk.norm.weight.detach(), "nb": blk.norm.bias.detach(),
-                    "reduce": Fn.Weights(w, blk.patch_reduce.bias.detach(), wperm, wperm.shape[1]),
+                    "reduce": Fn.Weights(w, blk.patch_reduce.bias.detach(), wperm, wperm.shape[1], wperm_t,
+                                         wperm.shape[0]),
                     "token": self._lin(blk.token_transform), "pos": blk.pos_embed.detach()[0]}
         return None
 
@@ -489,6 +511,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         a = self._arena
         if self.compute_dtype == torch.bfloat16:
             K.cast_bf16(a["flat"], a["shadow"])
+            if a["tr"] is not None and save:
+                K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"])
         B = x.shape[0]
         tape = [] if save else None
         ecfg = {"dtype": self.compute_dtype, "patch": self.patch_size, "patches": self.patch_embed.num_patches,
@@ -593,6 +617,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                     from .. import stem
                     stem.embed_conv_bwd(self, g, sv, ep, ecfg, ekeep, gv)
                 gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:1, :])
+        Fn.join_side()                     # weight-gradient GEMMs trail on the side stream (functional.on_side)
         return [gv(p) for p in params]
 
 
