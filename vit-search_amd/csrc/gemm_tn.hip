@@ -1,0 +1,200 @@
+// bf16 weight-gradient GEMM:  C[M,N] += A[T,M]^T * B[T,N]   (fp32 atomics, split over the tokens T)
+//
+// Weight gradient of every nn.Linear on the ViT-Res hot path (autograd of F.linear, reference
+// nets/supernet_blocks.py:41,110): A = dY [tokens, out], B = X [tokens, in], both as the forward/backward kernels left
+// them (channel-contiguous, token-major).  vr_gemm (gemm.hip) dispatches here for a_trans && b_trans && atomic;
+// the meaning of every vr_gemm_args field is unchanged.
+//
+// Same skeleton as gemm_nt.hip (128x128 tile, 4 waves of 64x64 = 4x4 v_mfma_f32_16x16x32_bf16, one 32 KB slice of
+// 64 tokens moved by LDS-DMA, single-buffered, 4 workgroups per CU), but the MFMA fragments need 8 consecutive TOKENS
+// of one channel while LDS holds [token][channel]: they are read with the gfx950 transposing LDS read
+// ds_read_b64_tr_b16 -- a 16-lane group reads a [4 tokens][16 channels] block, lane i supplying the address of token
+// i/4, channels 4 (i%4).., and receives channel i of the four tokens (semantics pinned by tools/probes/tr_probe.hip).
+// Two such reads give the 8-token fragment of v_mfma_f32_16x16x32_bf16.
+//
+// LDS image: a piece of LDS-DMA (1 KB) = 4 tokens x 128 channels; token row = 16 slots of 16 B; slot p of token t holds
+// channel chunk p ^ ((t & 3) << 1) (applied on the SOURCE address, like gemm_nt.hip): the 4 tokens x 2 chunks a lane
+// group reads then sit in 8 different slots of the 256-B bank row.
+//
+// The Linear's bias gradient (column sums of dY) is one more MFMA per A fragment against an all-ones B fragment, done
+// by the workgroups of the first column tile only.
+#include "common.h"
+#include "../../include/vitres_hip.h"
+#include "gemm_shared.h"
+
+namespace vr_gemm_tn {
+using namespace vr_gemm_shared;
+
+typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef short s8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) s4 lds_s4;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+constexpr int BM = 128, BN = 128, BT = 64, NTHR = 256;   // BT: tokens per slice
+constexpr int TILE_BYTES = BT * BM * 2;                  // 16 KB per operand slice
+
+__device__ const uint4 zero_chunk[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+
+__device__ __forceinline__ bfv8 tr_frag(const char* p) {
+    // tokens +0..3 and +4..7 (4 token rows = 1 KB further) of this lane's channel
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p + 4 * 256));
+    const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bfv8, v);
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * TILE_BYTES];   // [A slice][B slice]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int total = tiles_n * tiles_m * p.split_k;
+    int tile = blockIdx.x;
+    if (total >= 16) {   // XCD-aware order (see gemm_nt.hip)
+        const int xq = total >> 3, xr = total & 7, x = tile & 7;
+        tile = x * xq + min(x, xr) + (tile >> 3);
+    }
+    const int tn = tile % tiles_n, rest = tile / tiles_n;
+    const int tm = rest % tiles_m, z = rest / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kper = ((p.K + p.split_k - 1) / p.split_k + BT - 1) / BT * BT;
+    const int kbeg = z * kper, kend = min(p.K, kbeg + kper);
+    int ntiles = kbeg < kend ? (kend - kbeg + BT - 1) / BT : 0;
+    // masked-work skipping: keep_k bounds the kept output rows (dY channels), keep_n the kept columns (X channels) of
+    // the samples this token range touches; a tile without kept rows or columns adds exactly zero
+    if ((p.keep_k || p.keep_n) && ntiles > 0) {
+        int s_lo = 0, s_hi = 0;
+        if (p.rows_in > 0) { s_lo = kbeg / p.rows_in; s_hi = (kend - 1) / p.rows_in; }
+        const int kmax = max_keep(p.keep_k, s_lo, s_hi, 1 << 30);
+        const int nmax = max_keep(p.keep_n, s_lo, s_hi, 1 << 30);
+        if (!range_has_kept(n0, BN, p.n_period, nmax) || !range_has_kept(m0, BM, p.k_period, kmax)) ntiles = 0;
+    }
+    if (ntiles == 0) return;
+
+    // ---- LDS-DMA source addressing: piece h of this wave = slice tokens (wave*4 + h)*4 .. +4; lane -> (token, slot) ----
+    const char* gA[4];
+    const char* gB[4];
+    int tok[4];
+    const long long strideA = (long long)BT * p.lda * 2, strideB = (long long)BT * p.ldb * 2;
+    const char* zero = reinterpret_cast<const char*>(zero_chunk);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int tk = (wave * 4 + h) * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ ((tk & 3) << 1);
+        // channel chunks past the matrix edge read the row's own padding (lda, ldb >= roundup(M / N, 8)) or, past that,
+        // the zero page; their products only reach outputs that are not stored
+        const bool aok = m0 + c * 8 + 8 <= p.lda, bok = n0 + c * 8 + 8 <= p.ldb;
+        tok[h] = tk;
+        gA[h] = aok ? reinterpret_cast<const char*>(p.A) + ((long long)(kbeg + tk) * p.lda + m0 + c * 8) * 2 : nullptr;
+        gB[h] = bok ? reinterpret_cast<const char*>(p.B) + ((long long)(kbeg + tk) * p.ldb + n0 + c * 8) * 2 : nullptr;
+    }
+
+    // ---- fragment addresses: lane (g = lane >> 4, li = lane & 15) -> token 8 g + (li >> 2) (+ 32 s, + 4 for the second
+    //      read), channel 64 w + 16 i + 4 (li & 3); slot = chunk ^ ((token & 3) << 1) ----
+    const int li = lane & 15, g = lane >> 4;
+    const int xr2 = (li >> 2) << 1;
+    const int rowoff = (8 * g + (li >> 2)) * 256 + (li & 1) * 8;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ca = (8 * wm + 2 * i + ((li & 3) >> 1)) ^ xr2;
+        const int cb = (8 * wn + 2 * i + ((li & 3) >> 1)) ^ xr2;
+        offA[i] = rowoff + ca * 16;
+        offB[i] = TILE_BYTES + rowoff + cb * 16;
+    }
+
+    f32x4 acc[4][4];
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool want_bg = BIAS && tn == 0 && wn == 0;
+    const s8 ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
+    const bfv8 ones = __builtin_bit_cast(bfv8, ones_bits);
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kbeg + kt * BT;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const bool in = k0 + tok[h] < kend;
+            const char* sa = (in && gA[h]) ? gA[h] + kt * strideA : zero;
+            const char* sb = (in && gB[h]) ? gB[h] + kt * strideB : zero;
+            __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(smem + (wave * 4 + h) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(smem + TILE_BYTES + (wave * 4 + h) * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bfv8 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = tr_frag(smem + offA[i] + s * 32 * 256);
+            if (want_bg) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bfv8 b = tr_frag(smem + offB[j] + s * 32 * 256);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m = 16 i + 4 (lane >> 4) + r][n = 16 j + (lane & 15)]: 16 consecutive columns (64 B)
+    //      of 4 rows per atomic instruction ----
+    float* C = reinterpret_cast<float*>(p.C);
+    const RowMap cm = {p.c_map.rpi, p.c_map.rps, p.c_map.off};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 64 + 16 * i + 4 * g + r;
+            if (m >= p.M) continue;
+            float* crow = C + map_row(cm, m) * (long long)p.ldc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + 16 * j + li;
+                if (n < p.N) atomicAdd(crow + n, acc[i][j][r]);
+            }
+            if (want_bg && li == 0) atomicAdd(p.bias_grad + m, accb[i][r]);
+        }
+}
+
+}  // namespace vr_gemm_tn
+
+// Called by vr_gemm after validation.  Returns false when the form is not covered here (row-mapped operands, odd
+// leading dimensions): the general kernel takes those.
+bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
+    using namespace vr_gemm_tn;
+    if (a0.in_dtype != VR_BF16 || !a0.a_trans || !a0.b_trans || !a0.atomic || a0.out_dtype != VR_F32) return false;
+    if (a0.a_map.rpi != 0 || a0.b_map.rpi != 0) return false;
+    if (a0.lda % 8 || a0.ldb % 8 || ((uintptr_t)a0.A & 15) || ((uintptr_t)a0.B & 15)) return false;
+    if (a0.lda < (a0.M + 7) / 8 * 8 || a0.ldb < (a0.N + 7) / 8 * 8) return false;
+    vr_gemm_args a = a0;
+    const long long tiles = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    if (a.split_k <= 0) {
+        // Every workgroup pays 64 KB of fp32 atomics whatever its share of the tokens, so the split is as coarse as the
+        // chip allows (measured on MI355X, tools/gemm_bench.py): 32 slices of tokens per workgroup when that still yields
+        // >= 1.5 workgroups per CU, else 16; never more than 4 workgroups per CU.
+        const long long slices = (a.K + BT - 1) / BT;
+        const long long s32 = (slices + 31) / 32, s16 = (slices + 15) / 16;
+        long long s = (tiles * s32 * 2 >= 3LL * n_cu) ? s32 : s16;
+        const long long by_fill = (4LL * n_cu + tiles - 1) / tiles;
+        if (s > by_fill) s = by_fill;
+        a.split_k = (int)(s < 1 ? 1 : s);
+    }
+    const long long total = tiles * a.split_k;
+    if (a.bias_grad) hipLaunchKernelGGL((tn_kernel<true>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    else hipLaunchKernelGGL((tn_kernel<false>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    return true;
+}
