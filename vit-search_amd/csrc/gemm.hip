@@ -24,7 +24,7 @@
 #include "../../include/vitres_hip.h"
 #include "gemm_shared.h"
 
-bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream);   // gemm_nt.hip
+bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);   // gemm_nt.hip
 bool vr_gemm_tn_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);   // gemm_tn.hip
 
 namespace {
@@ -778,7 +778,7 @@ extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
         return VR_EALIGN;
     if (a.in_dtype == VR_F32 && a.out_dtype == VR_BF16) return VR_EUNSUPPORTED;
     static const bool knob_nt = !(std::getenv("VITRES_GEMM_NT") && std::getenv("VITRES_GEMM_NT")[0] == '0');
-    if (knob_nt && !(a.sched & 4) && vr_gemm_nt_launch(a, (hipStream_t)stream)) {
+    if (knob_nt && !(a.sched & 4) && vr_gemm_nt_launch(a, (hipStream_t)stream, cu_count())) {
         VR_CHECK_LAUNCH();
         return VR_OK;
     }

@@ -22,6 +22,8 @@
 // slice buffer -- XOR-swizzled, no workgroup barrier -- and reads it back as whole rows: every store instruction
 // writes 8 rows x 128 B (bf16) of full cache lines, side inputs (residual, GELU pre-activation, pos-embed) are loaded
 // with the same shape, all loads of a round before its first store (vmcnt counts stores).
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/vitres_hip.h"
 #include "gemm_shared.h"
@@ -33,8 +35,8 @@ typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
-constexpr int BM = 128, BN = 128, BK = 64, NTHR = 256;
-constexpr int TILE_BYTES = BM * BK * 2;   // 16 KB per operand slice
+constexpr int BN = 128, BK = 64, NTHR = 256;
+constexpr int B_BYTES = BN * BK * 2;      // 16 KB per weight slice
 
 __device__ const uint4 zero_chunk[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 
@@ -48,9 +50,13 @@ struct RowMeta {
 
 // FAST: N % 8 == 0, ldc / ldu % 8 == 0, n_period % 8 == 0 (checked on the host) -- every lane's 8-column group is whole
 // or entirely outside the matrix, so the epilogue is branch-free 16-byte accesses.
-template <typename TO, int EPI, bool FAST>
-__global__ __launch_bounds__(NTHR, 4) void nt_kernel(const vr_gemm_args p) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * TILE_BYTES];   // [A slice][B slice]; epilogue: 4 x 8 KB
+// MI = 16-row fragments per wave along M: 4 -> 128-row tile (4 workgroups / CU), 2 -> 64-row tile (5 / CU; more, smaller
+// workgroups for GEMMs that would leave the 128-row grid a partial last round)
+template <typename TO, int EPI, bool FAST, int MI>
+__global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm_args p) {
+    constexpr int BM = 32 * MI, WROWS = 16 * MI;      // tile rows, rows per wave
+    constexpr int A_BYTES = BM * BK * 2, AP = MI;     // A slice bytes, LDS-DMA pieces of A per wave
+    __shared__ __attribute__((aligned(1024))) char smem[A_BYTES + B_BYTES];   // [A slice][B slice]; epilogue: 4 x 4 KB
     __shared__ RowMeta rowmeta[BM];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -89,17 +95,24 @@ __global__ __launch_bounds__(NTHR, 4) void nt_kernel(const vr_gemm_args p) {
     };
 
     // ---- LDS-DMA source addressing: piece h of this wave = tile rows wave*32 + 8h .. +8, lane -> (row, slot) ----
-    const char* gA[4];
+    const char* gA[AP];
     const char* gB[4];
-    int chunk[4];                  // element offset of this lane's k-chunk inside a slice
+    int chunkA[AP], chunkB[4];     // element offset of this lane's k-chunk inside a slice
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const int r = wave * 32 + h * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const int ma = min(m0 + r, p.M - 1), nb = min(n0 + r, p.N - 1);
-        gA[h] = reinterpret_cast<const char*>(p.A) + (map_row(amap, ma) * (long long)p.lda + c * 8) * 2;
+        const int nb = min(n0 + r, p.N - 1);
         gB[h] = reinterpret_cast<const char*>(p.B) + (map_row(bmap, nb) * (long long)p.ldb + c * 8) * 2;
-        chunk[h] = c * 8;
+        chunkB[h] = c * 8;
+    }
+#pragma unroll
+    for (int h = 0; h < AP; ++h) {
+        const int r = wave * (8 * AP) + h * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int ma = min(m0 + r, p.M - 1);
+        gA[h] = reinterpret_cast<const char*>(p.A) + (map_row(amap, ma) * (long long)p.lda + c * 8) * 2;
+        chunkA[h] = c * 8;
     }
     const char* zero = reinterpret_cast<const char*>(zero_chunk);
     const bool ktail = (p.K % BK) != 0;
@@ -107,12 +120,12 @@ __global__ __launch_bounds__(NTHR, 4) void nt_kernel(const vr_gemm_args p) {
     // ---- fragment read offsets: lane -> row (lane & 15) of a 16-row group, k-chunk 4 s + (lane >> 4) ----
     const int frow = lane & 15, fswz = (frow >> 1) & 7;
     const int slot0 = (((lane >> 4)) ^ fswz) << 4, slot1 = ((4 + (lane >> 4)) ^ fswz) << 4;
-    const char* As = smem + (wm * 64 + frow) * 128;
-    const char* Bs = smem + TILE_BYTES + (wn * 64 + frow) * 128;
+    const char* As = smem + (wm * WROWS + frow) * 128;
+    const char* Bs = smem + A_BYTES + (wn * 64 + frow) * 128;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -120,13 +133,14 @@ __global__ __launch_bounds__(NTHR, 4) void nt_kernel(const vr_gemm_args p) {
         const int k0 = kt * BK;
         const long long kb = (long long)k0 * 2;
 #pragma unroll
+        for (int h = 0; h < AP; ++h) {
+            const char* sa = (!ktail || (k0 + chunkA[h] < p.K)) ? gA[h] + kb : zero;
+            __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(smem + (wave * (8 * AP) + h * 8) * 128), 16, 0, 0);
+        }
+#pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const bool in = !ktail || (k0 + chunk[h] < p.K);
-            const char* sa = in ? gA[h] + kb : zero;
-            const char* sb = in ? gB[h] + kb : zero;
-            __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(smem + (wave * 32 + h * 8) * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(smem + TILE_BYTES + (wave * 32 + h * 8) * 128), 16,
-                                             0, 0);
+            const char* sb = (!ktail || (k0 + chunkB[h] < p.K)) ? gB[h] + kb : zero;
+            __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(smem + A_BYTES + (wave * 32 + h * 8) * 128), 16, 0, 0);
         }
     };
 
@@ -153,13 +167,13 @@ __global__ __launch_bounds__(NTHR, 4) void nt_kernel(const vr_gemm_args p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int so = s == 0 ? slot0 : slot1;
-            bfv8 a[4], b[4];
+            bfv8 a[MI], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bfv8*>(As + i * 2048 + so);
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bfv8*>(As + i * 2048 + so);
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bfv8*>(Bs + j * 2048 + so);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(NTHR, 4) void nt_kernel(const vr_gemm_args p) {
 
     // ---- epilogue: lane owns C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) + 0..3] of the wave's 64 x 64 ----
     constexpr int CW = 8;
-    float* park = reinterpret_cast<float*>(smem + wave * 8192);      // [32 rows][16 slots of 4 floats], slot ^= row & 15
+    float* park = reinterpret_cast<float*>(smem + wave * 4096);      // [16 rows][16 slots of 4 floats], slot ^= row
     const int n = n0 + wn * 64 + (lane & 7) * 8;                      // this lane's 8 columns
     const int nvalid = min(CW, p.N - n);
     const int nc = nvalid > 0 ? n : 0;
@@ -190,77 +204,72 @@ __global__ __launch_bounds__(NTHR, 4) void nt_kernel(const vr_gemm_args p) {
     const bool has_pos = (EPI == EPI_STORE) && p.pos;
     const bool has_res = (EPI == EPI_STORE) && p.resid;
     const bool live = nvalid > 0 && !(p.sched & 16);                  // ABLATION knob: bit 4 drops the stores
-    const RowMeta* meta = rowmeta + wm * 64 + (lane >> 3);
+    const RowMeta* meta = rowmeta + wm * WROWS + (lane >> 3);
+    // one round per 16-row fragment: park [16 rows][64 columns] (4 KB per wave), read back as rows
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ml = ii * 16 + (lane & 15);
-                const int slot = (4 * j + (lane >> 4)) ^ (lane & 15);
-                *reinterpret_cast<f32x4*>(park + ml * 64 + slot * 4) = acc[2 * rr + ii][j];
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int slot = (4 * j + (lane >> 4)) ^ (lane & 15);
+            *reinterpret_cast<f32x4*>(park + (lane & 15) * 64 + slot * 4) = acc[i][j];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        RowMeta rm[2];
+        long long orow[2];
+        float rv[2][CW], pv[2][CW];
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            RowMeta rm[2];
-            long long orow[2];
-            float rv[2][CW], pv[2][CW];
+        for (int q = 0; q < 2; ++q) {
+            rm[q] = meta[i * 16 + q * 8];
+            orow[q] = rm[q].orow < 0 ? 0 : rm[q].orow;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                rm[q] = meta[rr * 32 + (2 * qb + q) * 8];
-                orow[q] = rm[q].orow < 0 ? 0 : rm[q].orow;
-#pragma unroll
-                for (int e = 0; e < CW; ++e) { rv[q][e] = 0.f; pv[q][e] = 0.f; }
-                if constexpr (EPI == EPI_DGELU) loadw<bf16_t, CW>(p.dact_u, orow[q] * p.ldu + nc, rv[q], vec, nv);
-                if constexpr (EPI == EPI_STORE) {
-                    if (has_res) loadw<float, CW>(p.resid, orow[q] * p.ldc + nc, rv[q], vec, nv);
-                    if (has_pos) loadw<float, CW>(p.pos, (long long)rm[q].mloc * p.N + nc, pv[q], vecb, nv);
-                }
+            for (int e = 0; e < CW; ++e) { rv[q][e] = 0.f; pv[q][e] = 0.f; }
+            if constexpr (EPI == EPI_DGELU) loadw<bf16_t, CW>(p.dact_u, orow[q] * p.ldu + nc, rv[q], vec, nv);
+            if constexpr (EPI == EPI_STORE) {
+                if (has_res) loadw<float, CW>(p.resid, orow[q] * p.ldc + nc, rv[q], vec, nv);
+                if (has_pos) loadw<float, CW>(p.pos, (long long)rm[q].mloc * p.N + nc, pv[q], vecb, nv);
             }
+        }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int rl = (2 * qb + q) * 8 + (lane >> 3);
-                const bool mok = rm[q].orow >= 0;
-                const int kn = rm[q].keep - ncp;
-                const float sc = rm[q].scale;
-                float v[CW];
+        for (int q = 0; q < 2; ++q) {
+            const int rl = q * 8 + (lane >> 3);
+            const bool mok = rm[q].orow >= 0;
+            const int kn = rm[q].keep - ncp;
+            const float sc = rm[q].scale;
+            float v[CW];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int slot = (2 * (lane & 7) + h) ^ (rl & 15);
-                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(park + rl * 64 + slot * 4);
-                    v[4 * h] = a4[0]; v[4 * h + 1] = a4[1]; v[4 * h + 2] = a4[2]; v[4 * h + 3] = a4[3];
-                }
-                bool kc[CW];
+            for (int h = 0; h < 2; ++h) {
+                const int slot = (2 * (lane & 7) + h) ^ rl;
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(park + rl * 64 + slot * 4);
+                v[4 * h] = a4[0]; v[4 * h + 1] = a4[1]; v[4 * h + 2] = a4[2]; v[4 * h + 3] = a4[3];
+            }
+            bool kc[CW];
+#pragma unroll
+            for (int e = 0; e < CW; ++e) {
+                v[e] += bv[e] + pv[q][e];
+                kc[e] = grp ? (e < kn) : kept_col(nc + e, p.n_period, rm[q].keep);
+            }
+            const bool any = mok && live;
+            const long long oidx = orow[q] * p.ldc + nc;
+            if constexpr (EPI == EPI_GELU) {
+                float hh[CW];
 #pragma unroll
                 for (int e = 0; e < CW; ++e) {
-                    v[e] += bv[e] + pv[q][e];
-                    kc[e] = grp ? (e < kn) : kept_col(nc + e, p.n_period, rm[q].keep);
+                    v[e] = kc[e] ? v[e] : 0.f;       // masked hidden units: u = 0, gelu(u) = 0 (their K loop may be skipped)
+                    hh[e] = kc[e] ? gelu_fast(v[e]) : 0.f;
                 }
-                const bool any = mok && live;
-                const long long oidx = orow[q] * p.ldc + nc;
-                if constexpr (EPI == EPI_GELU) {
-                    float hh[CW];
-#pragma unroll
-                    for (int e = 0; e < CW; ++e) {
-                        v[e] = kc[e] ? v[e] : 0.f;       // masked hidden units: u = 0, gelu(u) = 0 (their K loop may be skipped)
-                        hh[e] = kc[e] ? gelu_fast(v[e]) : 0.f;
-                    }
-                    if (any) {
-                        storew<TO, CW>(p.C, oidx, v, vec, mok, nvalid);
-                        storew<TO, CW>(p.C2, oidx, hh, vec, mok, nvalid);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < CW; ++e) {
-                        if constexpr (EPI == EPI_DGELU) v[e] *= dgelu_fast(rv[q][e]);
-                        v[e] = kc[e] ? v[e] * sc : 0.f;
-                        if constexpr (EPI == EPI_STORE) v[e] += rv[q][e];
-                    }
-                    if (any) storew<TO, CW>(p.C, oidx, v, vec, mok, nvalid);
+                if (any) {
+                    storew<TO, CW>(p.C, oidx, v, vec, mok, nvalid);
+                    storew<TO, CW>(p.C2, oidx, hh, vec, mok, nvalid);
                 }
+            } else {
+#pragma unroll
+                for (int e = 0; e < CW; ++e) {
+                    if constexpr (EPI == EPI_DGELU) v[e] *= dgelu_fast(rv[q][e]);
+                    v[e] = kc[e] ? v[e] * sc : 0.f;
+                    if constexpr (EPI == EPI_STORE) v[e] += rv[q][e];
+                }
+                if (any) storew<TO, CW>(p.C, oidx, v, vec, mok, nvalid);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -268,30 +277,39 @@ __global__ __launch_bounds__(NTHR, 4) void nt_kernel(const vr_gemm_args p) {
     }
 }
 
-template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t stream) {
-    const long long total = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
+    const long long tn = (a.N + BN - 1) / BN;
+    const long long t128 = (long long)((a.M + 127) / 128) * tn, t64 = (long long)((a.M + 63) / 64) * tn;
     const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);
-    if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
-    else hipLaunchKernelGGL((nt_kernel<TO, EPI, false>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    static const int knob_mi = std::getenv("VITRES_NT_MI") ? std::atoi(std::getenv("VITRES_NT_MI")) : 0;
+    // 64-row tiles when the 128-row grid would give a CU fewer than two workgroups (measured crossover, tools/gemm_bench.py)
+    const bool small = knob_mi ? knob_mi == 2 : t128 < 2LL * n_cu;
+    if (small) {
+        if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true, 2>), dim3((unsigned)t64), dim3(NTHR), 0, stream, a);
+        else hipLaunchKernelGGL((nt_kernel<TO, EPI, false, 2>), dim3((unsigned)t64), dim3(NTHR), 0, stream, a);
+    } else {
+        if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true, 4>), dim3((unsigned)t128), dim3(NTHR), 0, stream, a);
+        else hipLaunchKernelGGL((nt_kernel<TO, EPI, false, 4>), dim3((unsigned)t128), dim3(NTHR), 0, stream, a);
+    }
 }
 
 }  // namespace vr_gemm_nt
 
 // Called by vr_gemm after validation.  Returns false when the form is not covered here.
-bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream) {
+bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_nt;
     if (a.in_dtype != VR_BF16 || a.a_trans || a.b_trans || a.atomic || a.split_k > 1 || a.bias_grad) return false;
     const bool of32 = a.out_dtype == VR_F32;
     if (a.act == 1) {
         if (of32) return false;
-        launch1<bf16_t, EPI_GELU>(a, stream);
+        launch1<bf16_t, EPI_GELU>(a, stream, n_cu);
     } else if (a.dact_u) {
         if (of32) return false;
-        launch1<bf16_t, EPI_DGELU>(a, stream);
+        launch1<bf16_t, EPI_DGELU>(a, stream, n_cu);
     } else if (of32) {
-        launch1<float, EPI_STORE>(a, stream);
+        launch1<float, EPI_STORE>(a, stream, n_cu);
     } else {
-        launch1<bf16_t, EPI_STORE>(a, stream);
+        launch1<bf16_t, EPI_STORE>(a, stream, n_cu);
     }
     return true;
 }

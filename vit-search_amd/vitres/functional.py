@@ -32,6 +32,7 @@ def _split_k(tokens, n_out=128, k_in=128):
 import os as _os
 OVERLAP = _os.environ.get('VITRES_OVERLAP', '1') != '0'
 DEFER_JOIN = _os.environ.get('VITRES_OVERLAP', '1') == '2'
+JOIN_PER_BLOCK = _os.environ.get('VITRES_OVERLAP', '1') == '3'
 _side_streams = {}
 
 
@@ -199,7 +200,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     dy = torch.empty((B, N, C), dtype=dt, device=x.device)
     linear_dgrad(du, p["fc1"], dy, M, C, F, F, C, rows_in=N, keep_k=mlp_keep, keep_n=embed_keep, sched=sch)
     out = K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"])
-    if ov and not DEFER_JOIN:
+    if ov and not DEFER_JOIN and not JOIN_PER_BLOCK:
         join_side()
     return out
 
