@@ -205,22 +205,46 @@ def main():
             a[3] += 1
             a[4] += dense
         K.PROFILE = None
-        names = {(0, 0): "gemm_kernel<T,false,false,..> (forward)", (0, 1): "gemm_kernel<T,false,true,..> (dgrad)",
-                 (1, 1): "gemm_kernel<T,true,true,float,EPI_ATOMIC,..> (wgrad)"}
-        kind, (sec, fl, by, n, dense) = max(agg.items(), key=lambda kv: kv[1][0])
-        peak = MFMA_PEAK[kind[0]]
+        def kname(k):
+            dt_, at, bt, mapped = k
+            if dt_ == "bf16" and not at and not bt:
+                return "vr_gemm_nt::nt_kernel (forward+dgrad)"
+            if dt_ == "bf16" and at and bt and not mapped:
+                return "vr_gemm_tn::tn_kernel (wgrad)"
+            if at:
+                return "gemm_kernel<%s,true,true,float,EPI_ATOMIC> (row-mapped wgrad)" % dt_
+            return "gemm_kernel<%s,false,%s> (%s)" % (dt_, "true" if bt else "false", "dgrad, contraction-major W" if bt
+                                                      else "forward")
+        byname = {}
+        for k, v in agg.items():
+            a = byname.setdefault(kname(k), [0.0, 0.0, 0.0, 0, 0.0, k[0]])
+            for i in range(5):
+                a[i] += v[i]
+        dom, (sec, fl, by, n, dense, dom_dt) = max(byname.items(), key=lambda kv: kv[1][0])
+        peak = MFMA_PEAK[dom_dt]
         ach = fl / sec / 1e12
         gemm_sec = sum(v[0] for v in agg.values()) / args.profile_steps
-        roof = {"bound": "mfma", "kernel": names[(kind[1], kind[2])].replace("T", kind[0], 1), "achieved": round(ach, 2),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+        traffic, traffic_note = None, None
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tfile) and args.workload == "sr_tiny_supernet":
+            tj = json.load(open(tfile))
+            for fam, tv in tj["kernels"].items():
+                if dom.startswith(fam):
+                    traffic = round(tv["read_bytes_per_launch"] + tv["write_bytes_per_launch"], 1)
+                    traffic_note = "HBM bytes per launch (read + write) of %s from profiles/r01_hbm_traffic.json: %s" % (
+                        fam, tj["source"])
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "launches_per_step": n // args.profile_steps, "avg_launch_us": round(sec / n * 1e6, 2),
                 "flops_per_launch": fl / n, "dense_flops_per_launch": dense / n, "algorithmic_bytes_per_launch": by / n,
-                "note": "FLOPs = kept (un-masked) sub-problems only; HIP events around every vr_gemm launch of %d extra eager "
-                        "steps after the timed region" % args.profile_steps,
+                "hbm_bound_check": {"algorithmic_GBps": round(by / sec / 1e9, 1), "peak_GBps": 8000.0},
+                "note": "FLOPs = kept (un-masked) sub-problems only; HIP events (recorded on the stream each kernel is launched "
+                        "on) around every vr_gemm launch of %d extra eager steps after the timed region" % args.profile_steps,
                 "all_gemm_ms_per_step": round(gemm_sec * 1e3, 3),
-                "all_gemm_kinds": {names[(k[1], k[2])].split(" ")[-1].strip("()"): {
+                "all_gemm_kinds": {k: {
                     "tflops_kept": round(v[1] / v[0] / 1e12, 2), "tflops_dense_equiv": round(v[4] / v[0] / 1e12, 2),
-                    "ms_per_step": round(v[0] / args.profile_steps * 1e3, 3)} for k, v in agg.items()}}
+                    "algorithmic_GBps": round(v[2] / v[0] / 1e9, 1), "ms_per_step": round(v[0] / args.profile_steps * 1e3, 3)}
+                    for k, v in byname.items()}}
     cpu = None if args.no_cpu_baseline else cpu_baseline(args.workload)
     from vitres.network_utils.compute_flop_mac import train_flops_per_image
     dense_flops = train_flops_per_image(nd)

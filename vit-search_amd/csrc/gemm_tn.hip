@@ -13,8 +13,9 @@
 // Two such reads give the 8-token fragment of v_mfma_f32_16x16x32_bf16.
 //
 // LDS image: a piece of LDS-DMA (1 KB) = 4 tokens x 128 channels; token row = 16 slots of 16 B; slot p of token t holds
-// channel chunk p ^ ((t & 3) << 1) (applied on the SOURCE address, like gemm_nt.hip): the 4 tokens x 2 chunks a lane
-// group reads then sit in 8 different slots of the 256-B bank row.
+// channel chunk p ^ ((t & 3) << 1) ^ (((t >> 3) & 1) << 3) (applied on the SOURCE address, like gemm_nt.hip): the transposing
+// read is serviced in two 32-lane halves, each covering tokens {0..3, 8..11} (+ const) x 2 chunks = 16 different slots of
+// the 256-B bank row.
 //
 // The Linear's bias gradient (column sums of dY) is one more MFMA per A fragment against an all-ones B fragment, done
 // by the workgroups of the first column tile only.
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const int tk = (wave * 4 + h) * 4 + (lane >> 4);
-        const int c = (lane & 15) ^ ((tk & 3) << 1);
+        const int c = (lane & 15) ^ ((tk & 3) << 1) ^ (((tk >> 3) & 1) << 3);
         // channel chunks past the matrix edge read the row's own padding (lda, ldb >= roundup(M / N, 8)) or, past that,
         // the zero page; their products only reach outputs that are not stored
         const bool aok = m0 + c * 8 + 8 <= p.lda, bok = n0 + c * 8 + 8 <= p.ldb;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
     // ---- fragment addresses: lane (g = lane >> 4, li = lane & 15) -> token 8 g + (li >> 2) (+ 32 s, + 4 for the second
     //      read), channel 64 w + 16 i + 4 (li & 3); slot = chunk ^ ((token & 3) << 1) ----
     const int li = lane & 15, g = lane >> 4;
-    const int xr2 = (li >> 2) << 1;
+    const int xr2 = ((li >> 2) << 1) | ((g & 1) << 3);
     const int rowoff = (8 * g + (li >> 2)) * 256 + (li & 1) * 8;
     int offA[4], offB[4];
 #pragma unroll

@@ -94,7 +94,8 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
     e1.record()
     esz = a.element_size()
-    PROFILE.append((("bf16" if args.in_dtype == VR_BF16 else "f32", int(a_trans), int(b_trans)), flops, 2.0 * M * N * K,
+    PROFILE.append((("bf16" if args.in_dtype == VR_BF16 else "f32", int(a_trans), int(b_trans),
+                     int(a_map is not None or b_map is not None)), flops, 2.0 * M * N * K,
                     float((M * K + N * K) * esz + M * N * out.element_size()), e0, e1))
     return out
 
