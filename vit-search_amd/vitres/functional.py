@@ -240,17 +240,28 @@ def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep):
     dt = cfg["dtype"]
     gt = K.scale_mask_cast(gout, None, new_keep, No, dt)                    # [B, No, Co]
     # token_transform (row 0 of every sample)
-    linear_wgrad(gt, y, grads["token.w"], B, Co, C, Co, C, a_map=(1, No, 0), b_map=(1, Ni, 0), db=grads["token.b"])
-    # patch_reduce (rows 1..)
-    K.batchsum(gout, grads["pos_sum"])                                      # [No, Co]; rows 1.. are d pos_embed
-    linear_wgrad(gt, col, grads["reduce.w"], B * P, Co, 9 * C, Co, 9 * C, a_map=(P, No, 1), db=grads["reduce.b"])
+    def wgrads():
+        linear_wgrad(gt, y, grads["token.w"], B, Co, C, Co, C, a_map=(1, No, 0), b_map=(1, Ni, 0), db=grads["token.b"])
+        # patch_reduce (rows 1..)
+        K.batchsum(gout, grads["pos_sum"])                                  # [No, Co]; rows 1.. are d pos_embed
+        linear_wgrad(gt, col, grads["reduce.w"], B * P, Co, 9 * C, Co, 9 * C, a_map=(P, No, 1), db=grads["reduce.b"],
+                     sched=1 if _overlap(gout) else 0)
+        if "finish" in grads:
+            grads["finish"]()                                               # re-layout of the conv weight gradient
+    if _overlap(gout):
+        on_side(wgrads, gt, gout)
+    else:
+        wgrads()
     dcol = torch.empty((B * P, 9 * C), dtype=dt, device=x.device)
     linear_dgrad(gt, p["reduce"], dcol, B * P, 9 * C, Co, Co, 9 * C, a_map=(P, No, 1), rows_in=P)
     dy = torch.empty((B, Ni, C), dtype=dt, device=x.device)
     K.sr_col2im(dcol, dy, B, g, C)
     linear_dgrad(gt, p["token"], dy, B, C, Co, Co, C, a_map=(1, No, 0), c_map=(1, Ni, 0), rows_in=1)
     gres = K.sr_resid_bwd(gout, B, g, C, Co)
-    return K.ln_bwd(dy, x, p["nw"], mean, rstd, embed_keep, Ni, gres, grads["nw"], grads["nb"])
+    out = K.ln_bwd(dy, x, p["nw"], mean, rstd, embed_keep, Ni, gres, grads["nw"], grads["nb"])
+    if _overlap(gout):
+        join_side()
+    return out
 
 
 # --------------------------------------------------------------------------------------------------

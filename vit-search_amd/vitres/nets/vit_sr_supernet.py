@@ -510,9 +510,15 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
     def _run_forward(self, x, plan, with_patch, save):
         a = self._arena
         if self.compute_dtype == torch.bfloat16:
+            if Fn.OVERLAP and a["flat"].is_cuda:
+                Fn.join_side()             # a previous forward's side work (if its backward never ran)
             K.cast_bf16(a["flat"], a["shadow"])
             if a["tr"] is not None and save:
-                K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"])
+                # only the backward needs W^T: refresh it beside the forward (joined at the start of _run_backward)
+                if Fn.OVERLAP and a["flat"].is_cuda:
+                    Fn.on_side(lambda: K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"]))
+                else:
+                    K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"])
         B = x.shape[0]
         tape = [] if save else None
         ecfg = {"dtype": self.compute_dtype, "patch": self.patch_size, "patches": self.patch_embed.num_patches,
@@ -571,6 +577,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         gv = self._gview
         dev = a["flat"].device
         g = None
+        Fn.join_side()                     # transposed weight shadows (issued beside the forward)
         for entry in reversed(tape):
             kind = entry[0]
             if kind == "head":
@@ -594,12 +601,13 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 co, ci = blk.patch_reduce.weight.shape[0], blk.patch_reduce.weight.shape[1]
                 wtmp = torch.zeros((co, 9 * ci), dtype=torch.float32, device=dev)
                 ptmp = torch.empty((1 + blk.num_patches, co), dtype=torch.float32, device=dev)
+                def finish(blk=blk, wtmp=wtmp, ptmp=ptmp, co=co, ci=ci):     # runs on the stream of the weight gradients
+                    gv(blk.patch_reduce.weight).copy_(wtmp.view(co, 3, 3, ci).permute(0, 3, 1, 2))
+                    gv(blk.pos_embed).copy_(ptmp[1:].unsqueeze(0))
                 grads = {"nw": gv(blk.norm.weight), "nb": gv(blk.norm.bias), "token.w": gv(blk.token_transform.weight),
                          "token.b": gv(blk.token_transform.bias), "reduce.b": gv(blk.patch_reduce.bias),
-                         "reduce.w": wtmp, "pos_sum": ptmp}
+                         "reduce.w": wtmp, "pos_sum": ptmp, "finish": finish}
                 g = Fn.sr_bwd(g, sv, p, grads, cfg, ek, nk)
-                gv(blk.patch_reduce.weight).copy_(wtmp.view(co, 3, 3, ci).permute(0, 3, 1, 2))
-                gv(blk.pos_embed).copy_(ptmp[1:].unsqueeze(0))
             elif kind == "embed":
                 _, ep, ecfg, sv = entry
                 ekeep = plan.k(plan.layers[0]["embed"])
