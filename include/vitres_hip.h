@@ -132,9 +132,13 @@ int vr_ln_fwd(const float* x, const float* w, const float* b, void* y, float* me
 /*
  * Masked LayerNorm backward (nets/masked_layer_norm.py:55-88).  dx_out = (dx_in ? dx_in : 0) + dLN/dx;
  * dw/db (fp32 [C]) are accumulated with atomics (caller zeroes them).  dy has dtype `dy_dtype`.
+ * gt_out (optional, dtype `dy_dtype`, [M,C]): the gradient entering the NEXT backward branch, written in the same pass --
+ *   gt_out[m,c] = c < gt_keep[s] ? dx_out[m,c] * gt_scale[s] : 0   (s = m / rows_per_sample; NULL scale = 1, NULL keep = C)
+ * i.e. what vr_scale_mask_cast would produce from dx_out (DropPath nets/drop.py:11-26 + ChannelDrop mask backward).
  */
 int vr_ln_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
               const int32_t* keep, const float* dx_in, float* dx_out, float* dw, float* db,
+              void* gt_out, const float* gt_scale, const int32_t* gt_keep,
               int32_t M, int32_t C, int32_t rows_per_sample, int32_t dy_dtype, vr_stream_t stream);
 
 /*

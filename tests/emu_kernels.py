@@ -111,7 +111,7 @@ def ln_fwd(x, w, b, keep, rows_per_sample, eps, out_dtype):
     return y.view(x.shape).to(out_dtype), mu, rstd
 
 
-def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db):
+def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db, next_cast=None):
     C = x.shape[-1]
     X = x.reshape(-1, C).float()
     G = dy.reshape(-1, C).float()
@@ -128,7 +128,10 @@ def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db):
     dx = dx * mask
     dw += (G * z).sum(0)
     db += G.sum(0)
-    return dx.view(x.shape)
+    dx = dx.view(x.shape)
+    if next_cast is None:
+        return dx
+    return dx, scale_mask_cast(dx, next_cast[0], next_cast[1], rows_per_sample, dy.dtype)
 
 
 def attn_fwd(qkv, keep_hd, B, N, H, D, scale):

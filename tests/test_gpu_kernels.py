@@ -171,6 +171,16 @@ def test_layernorm_fwd_bwd(out_dtype, C, masked):
     dx = K.ln_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, None if keep is None else keep.to(DEV), N, gin.to(DEV), dw, db)
     assert relerr(dx, dxr) < 3e-5
     assert relerr(dw, dwr) < 3e-5 and relerr(db, dbr) < 3e-5
+    # fused second output: the next backward branch's gradient (DropPath scale, its own prefix mask, compute dtype)
+    keep2 = torch.tensor([C // 2, C, 4, C, C - 8], dtype=torch.int32)
+    scale2 = torch.tensor([1.0, 0.0, 1.25, 1.25, 1.0])
+    for sc, kp in ((scale2, keep2), (None, keep2), (scale2, None), (None, None)):
+        dw2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dx2, gt = K.ln_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, None if keep is None else keep.to(DEV), N, gin.to(DEV),
+                           dw2, db2, next_cast=(None if sc is None else sc.to(DEV), None if kp is None else kp.to(DEV)))
+        assert torch.equal(dx2, dx) and gt.dtype == dy.dtype
+        ref = E.scale_mask_cast(dx.cpu(), sc, kp, N, dy.dtype)
+        assert torch.equal(gt.cpu(), ref)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

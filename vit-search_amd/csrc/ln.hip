@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TI* __restrict__ dy, 
                                                      const float* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const int* __restrict__ keep,
                                                      const float* __restrict__ dx_in, float* __restrict__ dx_out,
-                                                     float* __restrict__ dw, float* __restrict__ db, int M, int C, int rps, int BWD_ROWS) {
+                                                     float* __restrict__ dw, float* __restrict__ db, TI* __restrict__ gt_out,
+                                                     const float* __restrict__ gt_scale, const int* __restrict__ gt_keep,
+                                                     int M, int C, int rps, int BWD_ROWS) {
     __shared__ float red[2][4][64 * 4];  // [dw|db][wave][lane*4+e], reused per j
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 gw[MAXV], gb[MAXV], ww[MAXV];
@@ -111,8 +113,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TI* __restrict__ dy, 
     constexpr int RU = MAXV == 1 ? 4 : (MAXV <= 2 ? 2 : 1);           // rows in flight per wave: all their loads are issued before any reduction
     for (int rr = wave; rr < BWD_ROWS; rr += 4 * RU) {
         float4 gv[RU][MAXV], xv[RU][MAXV], rv[RU][MAXV];
-        int kc[RU];
-        float mu[RU], rs[RU];
+        int kc[RU], k2[RU];
+        float mu[RU], rs[RU], sc2[RU];
         bool rok[RU];
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
@@ -120,6 +122,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TI* __restrict__ dy, 
             rok[u] = (rr + 4 * u < BWD_ROWS) && (m < M);
             const int mc = rok[u] ? m : 0;
             kc[u] = keep ? keep[mc / rps] : C;
+            k2[u] = (gt_out && gt_keep) ? gt_keep[mc / rps] : C;
+            sc2[u] = (gt_out && gt_scale) ? gt_scale[mc / rps] : 1.0f;
             mu[u] = mean[mc];
             rs[u] = rstd[mc];
 #pragma unroll
@@ -168,6 +172,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TI* __restrict__ dy, 
                     o.z = (c + 2 < kc[u]) ? (g[j].z - (s1 + z[j].z * s2)) * rs[u] + r.z : 0.f;
                     o.w = (c + 3 < kc[u]) ? (g[j].w - (s1 + z[j].w * s2)) * rs[u] + r.w : 0.f;
                     *reinterpret_cast<float4*>(dx_out + (long long)m * C + c) = o;
+                    if (gt_out) {       // the gradient entering the next backward branch: DropPath scale, prefix mask, cast
+                        float4 t;
+                        t.x = (c + 0 < k2[u]) ? o.x * sc2[u] : 0.f;
+                        t.y = (c + 1 < k2[u]) ? o.y * sc2[u] : 0.f;
+                        t.z = (c + 2 < k2[u]) ? o.z * sc2[u] : 0.f;
+                        t.w = (c + 3 < k2[u]) ? o.w * sc2[u] : 0.f;
+                        if constexpr (sizeof(TI) == 4) *reinterpret_cast<float4*>(gt_out + (long long)m * C + c) = t;
+                        else *reinterpret_cast<uint2*>(gt_out + (long long)m * C + c) = make_uint2(pack_bf2(t.x, t.y), pack_bf2(t.z, t.w));
+                    }
                 }
             }
         }
@@ -224,8 +237,9 @@ extern "C" int vr_ln_fwd(const float* x, const float* w, const float* b, void* y
 }
 
 extern "C" int vr_ln_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                         const int32_t* keep, const float* dx_in, float* dx_out, float* dw, float* db, int32_t M,
-                         int32_t C, int32_t rows_per_sample, int32_t dy_dtype, vr_stream_t stream) {
+                         const int32_t* keep, const float* dx_in, float* dx_out, float* dw, float* db, void* gt_out,
+                         const float* gt_scale, const int32_t* gt_keep, int32_t M, int32_t C, int32_t rows_per_sample,
+                         int32_t dy_dtype, vr_stream_t stream) {
     if (!dy || !x || !w || !mean || !rstd || !dx_out || !dw || !db || M <= 0 || C <= 0) return VR_EINVAL;
     if (C % 4 || C > 64 * 4 * MAXV_LIMIT) return VR_EUNSUPPORTED;
     if (dy_dtype != VR_F32 && dy_dtype != VR_BF16) return VR_EUNSUPPORTED;
@@ -236,10 +250,10 @@ extern "C" int vr_ln_bwd(const void* dy, const float* x, const float* w, const f
 #define VR_LN_BWD(NV)                                                                                                  \
     if (dy_dtype == VR_F32)                                                                                            \
         hipLaunchKernelGGL((ln_bwd_kernel<float, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, x, w, \
-                           mean, rstd, keep, dx_in, dx_out, dw, db, M, C, rows_per_sample, BWD_ROWS);                  \
+                           mean, rstd, keep, dx_in, dx_out, dw, db, (float*)gt_out, gt_scale, gt_keep, M, C, rows_per_sample, BWD_ROWS); \
     else                                                                                                               \
         hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, \
-                           w, mean, rstd, keep, dx_in, dx_out, dw, db, M, C, rows_per_sample, BWD_ROWS);
+                           w, mean, rstd, keep, dx_in, dx_out, dw, db, (bf16_t*)gt_out, gt_scale, gt_keep, M, C, rows_per_sample, BWD_ROWS);
     switch (nv) {
         case 1: VR_LN_BWD(1) break;
         case 2: VR_LN_BWD(2) break;

@@ -33,6 +33,8 @@ import os as _os
 OVERLAP = _os.environ.get('VITRES_OVERLAP', '1') != '0'
 DEFER_JOIN = _os.environ.get('VITRES_OVERLAP', '1') == '2'
 JOIN_PER_BLOCK = _os.environ.get('VITRES_OVERLAP', '1') == '3'
+FUSE_CAST = _os.environ.get('VITRES_FUSE_CAST', '1') != '0'      # LayerNorm backward also emits the next branch's gradient
+STEM_SIDE = _os.environ.get('VITRES_STEM_SIDE', '0') != '0'      # conv-stem weight gradients on the side stream: measured slower
 _side_streams = {}
 
 
@@ -115,7 +117,9 @@ def attn_branch_fwd(x, p, cfg, embed_keep, attn_keep, out_keep, scale, save):
     return x1, saved
 
 
-def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, scale):
+def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, scale, gt=None, next_cast=None):
+    """gt: scale_mask_cast(g, scale, out_keep) when the producer of g already made it (ln_bwd's fused second output);
+    next_cast: (scale, keep) of the branch that will consume this function's result -> returns (g_out, gt_next)."""
     x, mean, rstd, y, qkv, o, lse = saved
     B, N, C = x.shape
     M = B * N
@@ -124,7 +128,8 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     dt = cfg["dtype"]
     ov = _overlap(g)
     sch = 1 if ov else 0
-    gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                       # d(branch output), compute dtype
+    if gt is None:
+        gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                   # d(branch output), compute dtype
 
     def wgrad_proj():
         linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"], keep_rows=out_keep, keep_cols=attn_keep,
@@ -147,7 +152,7 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     dy = torch.empty((B, N, C), dtype=dt, device=x.device)
     linear_dgrad(dqkv, p["qkv"], dy, M, C, 3 * HD, 3 * HD, C, rows_in=N, keep_k=attn_keep, k_period=HD, keep_n=embed_keep,
                  sched=sch)
-    out = K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, grads["n1w"], grads["n1b"])
+    out = K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, grads["n1w"], grads["n1b"], next_cast=next_cast)
     if ov and not DEFER_JOIN:
         join_side()
     return out
@@ -170,7 +175,7 @@ def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save):
     return x2, saved
 
 
-def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scale):
+def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scale, gt=None, next_cast=None):
     x, mean, rstd, y, u, h = saved
     B, N, C = x.shape
     M = B * N
@@ -178,7 +183,8 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     dt = cfg["dtype"]
     ov = _overlap(g)
     sch = 1 if ov else 0
-    gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
+    if gt is None:
+        gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
 
     def wgrad_fc2():
         linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"], keep_rows=out_keep, keep_cols=mlp_keep,
@@ -199,7 +205,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
         wgrad_fc1()
     dy = torch.empty((B, N, C), dtype=dt, device=x.device)
     linear_dgrad(du, p["fc1"], dy, M, C, F, F, C, rows_in=N, keep_k=mlp_keep, keep_n=embed_keep, sched=sch)
-    out = K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"])
+    out = K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"], next_cast=next_cast)
     if ov and not DEFER_JOIN and not JOIN_PER_BLOCK:
         join_side()
     return out
@@ -229,7 +235,7 @@ def sr_fwd(x, p, cfg, embed_keep, new_keep, save):
     return out, saved
 
 
-def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep):
+def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep, gt=None, next_cast=None):
     x, mean, rstd, y, col = saved
     B, Ni, C = x.shape
     g = cfg["grid"]
@@ -238,7 +244,8 @@ def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep):
     No = 1 + P
     Co = cfg["cout"]
     dt = cfg["dtype"]
-    gt = K.scale_mask_cast(gout, None, new_keep, No, dt)                    # [B, No, Co]
+    if gt is None:
+        gt = K.scale_mask_cast(gout, None, new_keep, No, dt)                # [B, No, Co]
     # token_transform (row 0 of every sample)
     def wgrads():
         linear_wgrad(gt, y, grads["token.w"], B, Co, C, Co, C, a_map=(1, No, 0), b_map=(1, Ni, 0), db=grads["token.b"])
@@ -258,7 +265,7 @@ def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep):
     K.sr_col2im(dcol, dy, B, g, C)
     linear_dgrad(gt, p["token"], dy, B, C, Co, Co, C, a_map=(1, No, 0), c_map=(1, Ni, 0), rows_in=1)
     gres = K.sr_resid_bwd(gout, B, g, C, Co)
-    out = K.ln_bwd(dy, x, p["nw"], mean, rstd, embed_keep, Ni, gres, grads["nw"], grads["nb"])
+    out = K.ln_bwd(dy, x, p["nw"], mean, rstd, embed_keep, Ni, gres, grads["nw"], grads["nb"], next_cast=next_cast)
     if _overlap(gout):
         join_side()
     return out
@@ -280,13 +287,14 @@ def embed0_fwd(img, p, cfg, keep, save):
     return x, ((col,) if save else None)
 
 
-def embed0_bwd(g, saved, p, grads, cfg, keep):
+def embed0_bwd(g, saved, p, grads, cfg, keep, gt=None):
     (col,) = saved
     B, N, C = g.shape
     P = N - 1
     dt = cfg["dtype"]
     ldk = p["proj"].ld
-    gt = K.scale_mask_cast(g, None, keep, N, dt)
+    if gt is None:
+        gt = K.scale_mask_cast(g, None, keep, N, dt)
     linear_wgrad(gt, col, grads["proj.w"], B * P, C, ldk, C, ldk, a_map=(P, N, 1), db=grads["proj.b"])
     K.batchsum(g, grads["pos"])                                             # d pos_embed [N, C] (row 0 also = d tokens)
 
@@ -310,7 +318,7 @@ def head_fwd(x, p, cfg, keep, with_patch, save):
     return cls, pat, saved
 
 
-def head_bwd(dcls, dpat, saved, p, grads, cfg, keep):
+def head_bwd(dcls, dpat, saved, p, grads, cfg, keep, next_cast=None):
     x, mean, rstd, y = saved
     B, N, C = x.shape
     dt = cfg["dtype"]
@@ -331,4 +339,4 @@ def head_bwd(dcls, dpat, saved, p, grads, cfg, keep):
         gp = padded(dpat.reshape(R, nc))
         linear_wgrad(gp, y, grads["patch.w"], R, nc, C, ldp, C, b_map=(N - 1, N, 1), db=grads["patch.b"])
         linear_dgrad(gp, p["patch"], dy, R, C, nc, ldp, C, c_map=(N - 1, N, 1))
-    return K.ln_bwd(dy, x, p["nw"], mean, rstd, keep, N, None, grads["nw"], grads["nb"])
+    return K.ln_bwd(dy, x, p["nw"], mean, rstd, keep, N, None, grads["nw"], grads["nb"], next_cast=next_cast)

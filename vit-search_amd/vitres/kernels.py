@@ -134,12 +134,16 @@ def ln_fwd(x, w, b, keep, rows_per_sample, eps, out_dtype):
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db):
+def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db, next_cast=None):
+    """next_cast = (scale or None, keep or None): also return scale_mask_cast(dx, scale, keep) in dy's dtype (the gradient
+    entering the next backward branch), produced in the same pass."""
     M, C = x.numel() // x.shape[-1], x.shape[-1]
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    gt = torch.empty(x.shape, dtype=dy.dtype, device=x.device) if next_cast is not None else None
+    sc, kp = next_cast if next_cast is not None else (None, None)
     _lib.check(_lib.lib().vr_ln_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(keep), _p(dx_in), _p(dx), _p(dw), _p(db),
-                                    M, C, rows_per_sample, _dt(dy), _stream()), "vr_ln_bwd")
-    return dx
+                                    _p(gt), _p(sc), _p(kp), M, C, rows_per_sample, _dt(dy), _stream()), "vr_ln_bwd")
+    return dx if next_cast is None else (dx, gt)
 
 
 def attn_fwd(qkv, keep_hd, B, N, H, D, scale):

@@ -578,7 +578,24 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         dev = a["flat"].device
         g = None
         Fn.join_side()                     # transposed weight shadows (issued beside the forward)
-        for entry in reversed(tape):
+        rtape = list(reversed(tape))
+        ekeep0 = plan.k(plan.layers[0]["embed"])
+
+        def consumer_cast(i):
+            """(DropPath scale, prefix keep) with which the entry after rtape[i] turns the gradient it receives into its
+            compute-dtype branch gradient: LayerNorm backward emits that tensor in the same pass (vr_ln_bwd gt_out)."""
+            if i + 1 >= len(rtape) or not Fn.FUSE_CAST:
+                return None
+            e = rtape[i + 1]
+            if e[0] == "block":
+                return (e[4][5], e[4][3])
+            if e[0] == "sr":
+                return (None, e[4][1])
+            if e[0] == "embed":
+                return (None, ekeep0)
+            return None
+        gt = None
+        for ti, entry in enumerate(rtape):
             kind = entry[0]
             if kind == "head":
                 _, hp, hcfg, hk, sv = entry
@@ -586,7 +603,9 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                          "cls.b": gv(self.cls_head.bias)}
                 if self.patch_head is not None:
                     grads["patch.w"], grads["patch.b"] = gv(self.patch_head.weight), gv(self.patch_head.bias)
-                g = Fn.head_bwd(dcls, dpat, sv, hp, grads, hcfg, hk)
+                nc = consumer_cast(ti)
+                g = Fn.head_bwd(dcls, dpat, sv, hp, grads, hcfg, hk, next_cast=nc)
+                g, gt = g if nc is not None else (g, None)
             elif kind == "block":
                 _, blk, p, cfg, (ek, ka, km, ko, s1, s2), sa, sm = entry
                 grads = {"n1w": gv(blk.norm1.weight), "n1b": gv(blk.norm1.bias), "n2w": gv(blk.norm2.weight),
@@ -594,8 +613,10 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                          "proj.w": gv(blk.attn.proj.weight), "proj.b": gv(blk.attn.proj.bias),
                          "fc1.w": gv(blk.mlp.fc1.weight), "fc1.b": gv(blk.mlp.fc1.bias),
                          "fc2.w": gv(blk.mlp.fc2.weight), "fc2.b": gv(blk.mlp.fc2.bias)}
-                g = Fn.mlp_branch_bwd(g, sm, p, grads, cfg, ek, km, ko, s2)
-                g = Fn.attn_branch_bwd(g, sa, p, grads, cfg, ek, ka, ko, s1)
+                g, gt = Fn.mlp_branch_bwd(g, sm, p, grads, cfg, ek, km, ko, s2, gt=gt, next_cast=(s1, ko))      # gt: attention branch's
+                nc = consumer_cast(ti)
+                g = Fn.attn_branch_bwd(g, sa, p, grads, cfg, ek, ka, ko, s1, gt=gt, next_cast=nc)
+                g, gt = g if nc is not None else (g, None)
             elif kind == "sr":
                 _, blk, p, cfg, (ek, nk), sv = entry
                 co, ci = blk.patch_reduce.weight.shape[0], blk.patch_reduce.weight.shape[1]
@@ -607,7 +628,9 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 grads = {"nw": gv(blk.norm.weight), "nb": gv(blk.norm.bias), "token.w": gv(blk.token_transform.weight),
                          "token.b": gv(blk.token_transform.bias), "reduce.b": gv(blk.patch_reduce.bias),
                          "reduce.w": wtmp, "pos_sum": ptmp, "finish": finish}
-                g = Fn.sr_bwd(g, sv, p, grads, cfg, ek, nk)
+                nc = consumer_cast(ti)
+                g = Fn.sr_bwd(g, sv, p, grads, cfg, ek, nk, gt=gt, next_cast=nc)
+                g, gt = g if nc is not None else (g, None)
             elif kind == "embed":
                 _, ep, ecfg, sv = entry
                 ekeep = plan.k(plan.layers[0]["embed"])
@@ -618,12 +641,12 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                     wt = gv(w).view(w.shape[0], k) if ld == k else torch.zeros((w.shape[0], ld), dtype=torch.float32,
                                                                               device=dev)
                     grads = {"proj.w": wt, "proj.b": gv(self.patch_embed.proj.bias), "pos": gv(self.pos_embed)}
-                    Fn.embed0_bwd(g, sv, ep, grads, ecfg, ekeep)
+                    Fn.embed0_bwd(g, sv, ep, grads, ecfg, ekeep, gt=gt)
                     if ld != k:
                         gv(w).view(w.shape[0], k).copy_(wt[:, :k])
                 else:
                     from .. import stem
-                    stem.embed_conv_bwd(self, g, sv, ep, ecfg, ekeep, gv)
+                    stem.embed_conv_bwd(self, g, sv, ep, ecfg, ekeep, gv, gt=gt)
                 gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:1, :])
         Fn.join_side()                     # weight-gradient GEMMs trail on the side stream (functional.on_side)
         return [gv(p) for p in params]

@@ -94,7 +94,7 @@ def embed_conv_fwd(model, x, p, cfg, keep, save):
     return out, saved
 
 
-def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv):
+def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
     pe, dt = model.patch_embed, cfg["dtype"]
     col1, z1, bn1, col2, z2, bn2, col3, z3, bn3, colp, (B, Hm, Wm, m, g, ps, tr) = saved
     dev = gx.device
@@ -102,12 +102,19 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv):
     P = N - 1
     R = B * Hm * Wm
     ldk = ps * ps * m
-    gt = K.scale_mask_cast(gx, None, keep, N, dt)
+    if gt is None:
+        gt = K.scale_mask_cast(gx, None, keep, N, dt)
     # conv_proj
+    ov = Fn._overlap(gx) and Fn.STEM_SIDE
     wtmp = torch.zeros((C, ldk), dtype=torch.float32, device=dev)
-    Fn.linear_wgrad(gt, colp, wtmp, B * P, C, ldk, C, ldk, a_map=(P, N, 1), db=gv(pe.conv_proj.bias))
-    gv(pe.conv_proj.weight).copy_(wtmp.view(C, ps, ps, m).permute(0, 3, 1, 2))
-    K.batchsum(gx, gv(model.pos_embed))
+
+    def wgrad_proj():
+        Fn.linear_wgrad(gt, colp, wtmp, B * P, C, ldk, C, ldk, a_map=(P, N, 1), db=gv(pe.conv_proj.bias),
+                        sched=1 if ov else 0)
+        gv(pe.conv_proj.weight).copy_(wtmp.view(C, ps, ps, m).permute(0, 3, 1, 2))
+        K.batchsum(gx, gv(model.pos_embed))
+    # weight gradients run beside the data-gradient chain (functional.on_side); joined at the end of this function
+    Fn.on_side(wgrad_proj, gt, wtmp) if ov else wgrad_proj()
     dcolp = torch.empty((B * P, ldk), dtype=dt, device=dev)
     K.gemm(gt, p["proj"].w_c, dcolp, M=B * P, N=ldk, K=C, lda=C, ldb=ldk, ldc=ldk, b_trans=True, a_map=(P, N, 1))
     da3 = K.patch_fold(dcolp, B, g, g, ps, m)                      # d(relu(bn3) + a1)
@@ -118,9 +125,12 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv):
         gv(conv_mod.bn.weight).copy_(sg[1])
         gv(conv_mod.bn.bias).copy_(sg[0])
         wt = torch.zeros((m, ld), dtype=torch.float32, device=dev)
-        Fn.linear_wgrad(dz, col, wt, R, m, ld, m, ld)
         cin = conv_mod.conv.weight.shape[1]
-        gv(conv_mod.conv.weight).copy_(wt[:, :9 * cin].reshape(m, 3, 3, cin).permute(0, 3, 1, 2))
+
+        def wgrad():
+            Fn.linear_wgrad(dz, col, wt, R, m, ld, m, ld, sched=1 if ov else 0)
+            gv(conv_mod.conv.weight).copy_(wt[:, :9 * cin].reshape(m, 3, 3, cin).permute(0, 3, 1, 2))
+        Fn.on_side(wgrad, dz, wt) if ov else wgrad()
         if not need_dx:
             return None
         dcol = torch.empty((R, ld), dtype=dt, device=dev)
@@ -130,3 +140,5 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv):
     da1 = conv_bwd(da2, z2, bn2, col2, p["w2"], pe.conv2, 9 * m, True)
     da1 = da1 + da3                                                 # residual branch (patch_conv.py:69)
     conv_bwd(da1, z1, bn1, col1, p["w1"], pe.conv1, 32, False)
+    if ov:
+        Fn.join_side()
