@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--split-sync", type=int, default=-1, help="two-graph backward with overlapped gradient exchange "
+                    "(-1: when --gpus > 1)")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -153,14 +155,17 @@ def main():
                                  grad_sync=sync)
 
     graphed = None
+    split = (world > 1) if args.split_sync < 0 else bool(args.split_sync)
     if not args.no_graph:
-        graphed = engine.GraphedTrainStep(model, crit, x, t, pt, "seq")
+        # N > 1: the backward is captured as two graphs so that the all-reduce of the last stage's gradients (the tail of
+        # the flat arena, most of the parameters) runs on RCCL's stream while the rest of the backward is still computing
+        graphed = engine.GraphedTrainStep(model, crit, x, t, pt, "seq", split_for_sync=split)
 
     def step(i):
         if graphed is None:
             return eager_step(i)
-        loss = graphed(x, t, pt, epoch=31, train_iter=i, arch_sample=arch)     # fwd + loss + bwd (hipGraph replay)
-        sync.all_reduce_grads()
+        # fwd + loss + bwd (hipGraph replay) + gradient exchange (averaged), then the optimizer
+        loss = graphed.step_with_sync(sync, x, t, pt, epoch=31, train_iter=i, arch_sample=arch)
         opt.step()
         return loss
 
@@ -256,7 +261,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": args.workload, "global_batch": B * world, "per_gpu_batch": B,
                    "example_per_arch": w["epa"], "epoch": 31, "drop_path": w["drop_path"], "parallelism": "dp%d" % world,
-                   "optimizer": "AdamW(torch fused)", "hipgraph": graphed is not None, "final_loss": round(lossv[-1], 4)},
+                   "optimizer": "AdamW(torch fused)", "hipgraph": graphed is not None,
+                   "grad_exchange": ("1 all-reduce of the flat fp32 arena, tail overlapped with the second backward graph"
+                                     if (graphed is not None and graphed.graph_b is not None) else
+                                     "1 all-reduce of the flat fp32 arena" if world > 1 else "none (1 rank)"), "final_loss": round(lossv[-1], 4)},
         "roofline": roof, "cpu_baseline": cpu,
         "dense_equiv": {"train_gflop_per_image": round(dense_flops / 1e9, 2),
                         "tflops_per_gpu": round(dense_flops * img_s / world / 1e12, 1),

@@ -58,12 +58,26 @@ def _worker(rank, world, port, out_dir):
     keeps = torch.stack(model.last_keeps).clone()
     g_local = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
     model.zero_grad(set_to_none=True)
+    # the split exchange of engine.GraphedTrainStep.step_with_sync: tail range while part 2 of the backward runs, then
+    # the rest -- same result as the single all-reduce
+    torch.random.set_rng_state(rng)
+    cut, start = model.split_plan()
+    cls, pat = model(x, patch_output_type="seq")
+    model._bwd_split = cut
+    (crit(cls, t) + crit(pat, pt)).backward()
+    model._bwd_split = None
+    works = [sync.all_reduce_range(start, model._arena["gcur"].numel())]
+    model.resume_backward()
+    works.append(sync.all_reduce_range(0, start))
+    sync.finish(works)
+    g_split = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    model.zero_grad(set_to_none=True)
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
     torch.random.set_rng_state(rng)
     engine.train_step(model, crit, opt, x, t, pt, "seq", epoch=31, train_iter=0, arch_sample="multi", grad_sync=sync)
     g_sync = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
     p1 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
-    torch.save({"p0": p0, "p1": p1, "g_local": g_local, "g_sync": g_sync, "keeps": keeps},
+    torch.save({"p0": p0, "p1": p1, "g_local": g_local, "g_sync": g_sync, "keeps": keeps, "g_split": g_split},
                os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -82,3 +96,5 @@ def test_two_rank_gradient_exchange(tmp_path):
     mean = 0.5 * (r0["g_local"] + r1["g_local"])
     err = float((r0["g_sync"] - mean).abs().max() / mean.abs().max())
     assert err < 1e-5, err
+    assert torch.equal(r0["g_split"], r1["g_split"])
+    assert float((r0["g_split"] - r0["g_sync"]).abs().max() / r0["g_sync"].abs().max()) < 1e-6

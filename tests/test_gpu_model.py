@@ -207,6 +207,44 @@ def test_hipgraph_replay_matches_eager():
             assert rel(p.grad, grads_e[n]) < 1e-4, n
 
 
+@pytest.mark.gpu
+def test_split_hipgraphs_match_eager():
+    """GraphedTrainStep(split_for_sync=True): the backward captured as two graphs (cut after the last stage, so that the
+    gradient exchange of the arena tail overlaps the second one) reproduces the eager gradients; step_with_sync on a
+    single rank is the plain replay."""
+    from vitres import engine
+    from vitres.losses import SoftTargetCrossEntropy
+    prod, orc, sd = build_pair(0, "multi", 100)
+    prod.set_compute_dtype(torch.float32)
+    prod.train()
+    prod.set_epoch(31)
+    prod.load_state_dict(sd)
+    crit = SoftTargetCrossEntropy()
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1))
+    eager = []
+    for it in range(2):
+        torch.manual_seed(700 + it)
+        for p in prod.parameters():
+            p.grad = None
+        out = prod(x, patch_output_type="seq")
+        loss = crit(out[0], t) + crit(out[1], pt)
+        loss.backward()
+        eager.append((loss.item(), {n: p.grad.detach().cpu().clone() for n, p in prod.named_parameters()}))
+        del out, loss
+    for p in prod.parameters():
+        p.grad = None
+    graphed = engine.GraphedTrainStep(prod, crit, x, t, pt, "seq", split_for_sync=True)
+    assert graphed.graph_b is not None and graphed.split is not None
+    sync = engine.GradSync(prod)
+    for it in range(2):
+        torch.manual_seed(700 + it)
+        loss_g = graphed.step_with_sync(sync, x, t, pt, epoch=31, train_iter=it, arch_sample=None).item()
+        loss_e, grads_e = eager[it]
+        assert abs(loss_g - loss_e) < 1e-5 * abs(loss_e)
+        for n, p in prod.named_parameters():
+            assert rel(p.grad, grads_e[n]) < 1e-4, n
+
+
 def test_evo_candidates_on_resident_supernet_match_reference_sliced_subnets():
     """Config C5: a candidate sub-network evaluated as a keep-descriptor on the resident supernet gives the logits the
     REFERENCE computes for the prefix-sliced standalone sub-network (get_sub_state_dict, fixture F5)."""

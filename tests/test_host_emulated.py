@@ -100,6 +100,40 @@ def test_emulated_second_backward_accumulates(monkeypatch):
     assert rel(g2, 2 * prod.cls_head.weight.grad) < 1e-5
 
 
+def test_emulated_split_backward_equals_monolithic(monkeypatch):
+    """The backward cut after the last stage (engine.GraphedTrainStep(split_for_sync=True): second hipGraph overlapped with
+    the all-reduce of the finished arena tail) writes the same gradients as the single pass, and part 1 alone already
+    completes every gradient of the arena tail."""
+    emu_kernels.install(monkeypatch)
+    prod, orc, sd = build_pair(0, "multi", 100)
+    prod.set_compute_dtype(torch.float32)
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    prod.train()
+    prod.set_epoch(31)
+    prod._ensure_arena(torch.device("cpu"))
+    cut, start = prod.split_plan()
+    assert 0 < start < prod._arena["flat"].numel()
+
+    def run(split):
+        torch.manual_seed(5)
+        prod.zero_grad(set_to_none=True)
+        cls, pat = prod(x, patch_output_type="seq")
+        prod._bwd_split = cut if split else None
+        (O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)).backward()
+        prod._bwd_split = None
+        part1 = prod._arena["gcur"].clone()
+        if split:
+            assert prod._bwd_state is not None
+            prod.resume_backward()
+        assert prod._bwd_state is None
+        return part1, prod._arena["gcur"].clone()
+    _, mono = run(False)
+    part1, full = run(True)
+    assert torch.equal(full, mono)
+    assert torch.equal(part1[start:], mono[start:])          # the tail is final after part 1 ...
+    assert not torch.equal(part1[:start], mono[:start])      # ... the rest is not
+
+
 def test_cpu_tensor_is_refused():
     prod, _, _ = build_pair(0, "plain", 100)
     with pytest.raises(RuntimeError):

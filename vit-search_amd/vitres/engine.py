@@ -72,6 +72,22 @@ class GradSync:
         for b in self.model.buffers():
             dist.broadcast(b, src=0)
 
+    def all_reduce_range(self, lo, hi):
+        """Asynchronous all-reduce (sum) of elements [lo, hi) of the flat gradient arena; returns the work handle (None
+        on one rank).  RCCL runs it on the process group's stream after everything queued so far on the current one."""
+        if self.world == 1 or hi <= lo:
+            return None
+        return dist.all_reduce(self.model._arena["gcur"][lo:hi], async_op=True)
+
+    def finish(self, works):
+        """Wait for all_reduce_range handles and apply the 1/world averaging."""
+        if self.world == 1:
+            return
+        for w in works:
+            if w is not None:
+                w.wait()
+        self.model._arena["gcur"].mul_(1.0 / self.world)
+
     def all_reduce_grads(self):
         if self.world == 1:
             return
@@ -133,8 +149,13 @@ class GraphedTrainStep:
     are still sampled on the host with the reference's RNG protocol before each replay.  DropPath noise comes from
     torch's graph-safe device generator.  The gradient exchange and the optimizer stay outside the graph."""
 
-    def __init__(self, model, criterion, samples, targets, patch_targets=None, patch_output_type=None, warmup=2):
+    def __init__(self, model, criterion, samples, targets, patch_targets=None, patch_output_type=None, warmup=2,
+                 split_for_sync=False):
+        """split_for_sync: capture the backward as TWO graphs cut after the last stage (model.split_plan()), so that
+        step_with_sync() can all-reduce the finished tail of the gradient arena (most of the parameters) while the rest
+        of the backward -- most of the time -- is still running."""
         self.model, self.criterion, self.pot = model, criterion, patch_output_type
+        self.graph_b, self.split = None, None
         self.x, self.t = samples.clone(), targets.clone()
         self.pt = patch_targets.clone() if patch_targets is not None else None
         B = samples.shape[0]
@@ -151,11 +172,21 @@ class GraphedTrainStep:
         if plan.rows:
             self.keep_static = torch.stack(plan.rows).to(torch.int32).to(samples.device)
         model.zero_grad(set_to_none=True)
+        if split_for_sync:
+            self.split = model.split_plan()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            plan.keep_dev = self.keep_static
-            self.loss = self._loss(model(self.x, patch_output_type=self.pot, plan=plan))
-            self.loss.backward()
+        model._bwd_split = self.split[0] if self.split is not None else None
+        try:
+            with torch.cuda.graph(self.graph):
+                plan.keep_dev = self.keep_static
+                self.loss = self._loss(model(self.x, patch_output_type=self.pot, plan=plan))
+                self.loss.backward()
+            if getattr(model, "_bwd_state", None) is not None:
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
+                    model.resume_backward()
+        finally:
+            model._bwd_split = None
         self.loss = self.loss.detach()
         torch.random.set_rng_state(rng)
 
@@ -184,7 +215,29 @@ class GraphedTrainStep:
             if self.pt is not None:
                 self.pt.copy_(patch_targets, non_blocking=True)
         self.graph.replay()
+        if self.graph_b is not None:
+            if self._sync is not None:                            # tail of the arena is final: exchange it now
+                self._works.append(self._sync.all_reduce_range(self.split[1], self.model._arena["gcur"].numel()))
+            self.graph_b.replay()
         return self.loss
+
+    _sync, _works = None, ()
+
+    def step_with_sync(self, grad_sync, samples, targets, patch_targets=None, **kw):
+        """Replay + data-parallel gradient exchange: with split_for_sync the all-reduce of the last stage's gradients
+        overlaps the second backward graph; the remainder follows it.  Gradients are averaged on return."""
+        self._sync, self._works = grad_sync, []
+        try:
+            loss = self(samples, targets, patch_targets, **kw)
+        finally:
+            self._sync = None
+        if self.graph_b is not None:
+            self._works.append(grad_sync.all_reduce_range(0, self.split[1]))
+            grad_sync.finish(self._works)
+        else:
+            grad_sync.all_reduce_grads()
+        self._works = ()
+        return loss
 
 
 def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler=None, max_norm=0,

@@ -574,11 +574,57 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         a["gcur"] = a["gflat"] if fresh else torch.zeros_like(a["flat"])
         if fresh:
             a["gcur"].zero_()
+        Fn.join_side()                     # transposed weight shadows (issued beside the forward)
+        st = {"rtape": list(reversed(tape)), "plan": plan, "dcls": dcls, "dpat": dpat, "i": 0, "g": None, "gt": None}
+        # _bwd_split = j: stop after the head and blocks[j:]; the rest runs in resume_backward() (a second hipGraph, so that the
+        # all-reduce of the finished tail of the gradient arena overlaps it -- engine.GraphedTrainStep)
+        cut = getattr(self, "_bwd_split", None)
+        n1 = len(st["rtape"])
+        if cut is not None:                # head + the entries of blocks[cut:] form a prefix of the reversed tape
+            late = {id(b) for b in list(self.blocks)[cut:]}
+            n1 = sum(1 for e in st["rtape"] if e[0] == "head" or (e[0] in ("block", "sr") and id(e[1]) in late))
+        self._bwd_loop(st, n1)
+        self._bwd_state = st if st["i"] < len(st["rtape"]) else None
+        return [self._gview(p) for p in params]
+
+    def resume_backward(self):
+        """Second part of a backward that was split by _bwd_split (gradients land in the same arena views)."""
+        st = self._bwd_state
+        if st is None:
+            raise RuntimeError("no split backward is pending")
+        self._bwd_loop(st, len(st["rtape"]))
+        self._bwd_state = None
+
+    def split_plan(self):
+        """Where to cut the backward for gradient-exchange overlap: (first block index of part 1, first element of the
+        gradient arena that part 1 completes) -- head + the last stage (+ the spatial reduction in front of it), whose
+        parameters form the tail of the arena.  None if the layout does not allow it."""
+        a = self._arena
+        blocks = list(self.blocks)
+        cut = None
+        for j in range(len(blocks) - 1, -1, -1):
+            if isinstance(blocks[j], SpatialReductionPatchEmbedding):
+                cut = j
+                break
+        if cut is None:
+            cut = len(blocks) // 2
+        tail = [p for m in blocks[cut:] for p in m.parameters()] + list(self.norm.parameters()) + \
+            list(self.cls_head.parameters()) + (list(self.patch_head.parameters()) if self.patch_head is not None else [])
+        tail_ids = {id(p) for p in tail}
+        if not tail:
+            return None
+        start = min(a["offsets"][a["index"][id(p)]][0] for p in tail)
+        for p, (off, _) in zip(a["params"], a["offsets"]):
+            if (off >= start) != (id(p) in tail_ids):
+                return None                                     # tail parameters are not contiguous in the arena
+        return cut, start
+
+    def _bwd_loop(self, st, stop):
+        a = self._arena
         gv = self._gview
         dev = a["flat"].device
-        g = None
-        Fn.join_side()                     # transposed weight shadows (issued beside the forward)
-        rtape = list(reversed(tape))
+        rtape, plan, dcls, dpat = st["rtape"], st["plan"], st["dcls"], st["dpat"]
+        g = st["g"]
         ekeep0 = plan.k(plan.layers[0]["embed"])
 
         def consumer_cast(i):
@@ -594,8 +640,9 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             if e[0] == "embed":
                 return (None, ekeep0)
             return None
-        gt = None
-        for ti, entry in enumerate(rtape):
+        gt = st["gt"]
+        for ti in range(st["i"], stop):
+            entry = rtape[ti]
             kind = entry[0]
             if kind == "head":
                 _, hp, hcfg, hk, sv = entry
@@ -649,7 +696,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                     stem.embed_conv_bwd(self, g, sv, ep, ecfg, ekeep, gv, gt=gt)
                 gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:1, :])
         Fn.join_side()                     # weight-gradient GEMMs trail on the side stream (functional.on_side)
-        return [gv(p) for p in params]
+        st["i"], st["g"], st["gt"] = stop, g, gt
 
 
 # ---- registry factories (reference :480-577) -------------------------------------------------------
