@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"], help="flat: vitres.optim.FlatAdamW (one "
+                    "fused HIP pass over the arena); torch: torch.optim.AdamW(fused=True)")
     ap.add_argument("--split-sync", type=int, default=-1, help="two-graph backward with overlapped gradient exchange "
                     "(-1: when --gpus > 1)")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
@@ -146,13 +148,22 @@ def main():
     model._ensure_arena(device)
     sync.broadcast_parameters()
     lr = 5e-4 * B * world / 512.0
-    opt = torch.optim.AdamW(engine.param_groups_weight_decay(model, 0.05), lr=lr, fused=True)
+    if args.optimizer == "flat":
+        # AdamW on the flat arena in one HIP pass, fused with the bf16 weight shadow and the 1/world gradient averaging
+        from vitres.optim import FlatAdamW
+        opt = FlatAdamW(model, engine.param_groups_weight_decay(model, 0.05), lr=lr)
+        opt.grad_scale = 1.0 / world
+        if dtype == torch.bfloat16:
+            opt.own_shadow()
+    else:
+        opt = torch.optim.AdamW(engine.param_groups_weight_decay(model, 0.05), lr=lr, fused=True)
+    average = args.optimizer != "flat"
     crit = SoftTargetCrossEntropy()
     arch = "multi" if w["space"] else None
 
     def eager_step(i):
         return engine.train_step(model, crit, opt, x, t, pt, "seq", epoch=31, train_iter=i, arch_sample=arch,
-                                 grad_sync=sync)
+                                 grad_sync=sync, average_grads=average)
 
     graphed = None
     split = (world > 1) if args.split_sync < 0 else bool(args.split_sync)
@@ -165,7 +176,7 @@ def main():
         if graphed is None:
             return eager_step(i)
         # fwd + loss + bwd (hipGraph replay) + gradient exchange (averaged), then the optimizer
-        loss = graphed.step_with_sync(sync, x, t, pt, epoch=31, train_iter=i, arch_sample=arch)
+        loss = graphed.step_with_sync(sync, x, t, pt, average=average, epoch=31, train_iter=i, arch_sample=arch)
         opt.step()
         return loss
 
@@ -261,7 +272,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": args.workload, "global_batch": B * world, "per_gpu_batch": B,
                    "example_per_arch": w["epa"], "epoch": 31, "drop_path": w["drop_path"], "parallelism": "dp%d" % world,
-                   "optimizer": "AdamW(torch fused)", "hipgraph": graphed is not None,
+                   "optimizer": "AdamW (vitres.optim.FlatAdamW: vr_adamw_flat)" if args.optimizer == "flat" else "AdamW(torch fused)", "hipgraph": graphed is not None,
                    "grad_exchange": ("1 all-reduce of the flat fp32 arena, tail overlapped with the second backward graph"
                                      if (graphed is not None and graphed.graph_b is not None) else
                                      "1 all-reduce of the flat fp32 arena" if world > 1 else "none (1 rank)"), "final_loss": round(lossv[-1], 4)},

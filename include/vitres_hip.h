@@ -122,6 +122,24 @@ int vr_cast_transpose_batch(const float* src, void* dst, const vr_tr_desc* descs
                             vr_stream_t stream);
 
 /*
+ * AdamW over the flat fp32 parameter arena (timm create_optimizer -> torch.optim.AdamW, main.py:385; decoupled weight decay,
+ * bias-corrected moments), one pass, fused with: the bf16 shadow of the updated parameters (NULL to skip), gradient scaling
+ * (grad_scale, e.g. 1/world after a sum all-reduce) and the ModelEmaV2 update ema = d*ema + (1-d)*p (main.py:357-363;
+ * NULL to skip).  Hyper-parameters come per GROUP: group_of_8[i] (device, one byte per 8 consecutive elements; arena
+ * parameters start at multiples of 8) selects groups[...]; 255 = elements that are not updated (padding, frozen).
+ *   p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/bias_c1 * m / (sqrt(v)/sqrt_bias_c2 + eps)
+ * with bias_c1 = 1 - b1^t, sqrt_bias_c2 = sqrt(1 - b2^t) computed by the caller for step t.  n % 8 == 0.
+ */
+#define VR_ADAMW_MAX_GROUPS 16
+typedef struct vr_adamw_group {
+    float lr, beta1, beta2, eps, weight_decay, bias_c1, sqrt_bias_c2, grad_scale;
+} vr_adamw_group;
+int vr_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, float* ema, float ema_decay,
+                  const uint8_t* group_of_8, const vr_adamw_group* groups, int32_t n_groups, int64_t n,
+                  vr_stream_t stream);
+
+
+/*
  * Masked LayerNorm forward (nets/masked_layer_norm.py:23-50,113-125).  x fp32 [M,C] -> y (dtype) [M,C];
  * mean/rstd fp32 [M] saved for backward.  keep NULL -> plain LayerNorm (F.layer_norm path :118-122).
  */

@@ -264,3 +264,52 @@ def test_evo_candidates_on_resident_supernet_match_reference_sliced_subnets():
         assert rel(out, g["cand%d.logits" % i]) < 1e-4, (i, rel(out, g["cand%d.logits" % i]))
     scores = evo_eval.score_population(sup, recipe.MICRO_CANDIDATES, [(x.to(DEV), labels.to(DEV))])
     assert len(scores) == 4 and all(0.0 <= s <= 100.0 for s in scores)
+
+
+@pytest.mark.parametrize("ema", [None, 0.99])
+def test_flat_adamw_matches_torch_adamw(ema):
+    """vitres.optim.FlatAdamW (one vr_adamw_flat pass over the arena, fused bf16 shadow / EMA) follows torch.optim.AdamW
+    on the same parameter groups step for step (the reference's optimizer: timm create_optimizer, main.py:385)."""
+    from vitres import engine
+    from vitres.optim import FlatAdamW
+    from vitres.losses import SoftTargetCrossEntropy
+    crit = SoftTargetCrossEntropy()
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1))
+    models = []
+    for _ in range(2):
+        prod, orc, sd = build_pair(0, "multi", 100)
+        prod.set_compute_dtype(torch.bfloat16)
+        prod.train()
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+        models.append(prod)
+    ref_opt = torch.optim.AdamW(engine.param_groups_weight_decay(models[0], 0.05), lr=2e-3, betas=(0.9, 0.999), eps=1e-8)
+    opt = FlatAdamW(models[1], engine.param_groups_weight_decay(models[1], 0.05), lr=2e-3, betas=(0.9, 0.999), eps=1e-8,
+                    ema_decay=ema)
+    ema_ref = {n: p.detach().clone() for n, p in models[0].named_parameters()}
+    for it in range(3):
+        torch.manual_seed(300 + it)
+        opt.zero_grad(set_to_none=True)
+        out = models[1](x, patch_output_type="seq")
+        (crit(out[0], t) + crit(out[1], pt)).backward()
+        for p_r, p_f in zip(models[0].parameters(), models[1].parameters()):      # identical gradients for both optimizers
+            p_r.grad = p_f.grad.detach().clone()
+        ref_opt.step()
+        opt.step()
+        if it == 1:
+            opt.param_groups[0]["lr"] = ref_opt.param_groups[0]["lr"] = 1e-3        # scheduler-style lr change
+            opt.param_groups[1]["lr"] = ref_opt.param_groups[1]["lr"] = 1e-3
+        for n, p in models[0].named_parameters():
+            ema_ref[n] = 0.99 * ema_ref[n] + 0.01 * p.detach() if ema else ema_ref[n]
+    a = models[1]._arena
+    assert a.get("shadow_ok")
+    assert torch.equal(a["shadow"].float(), a["flat"].bfloat16().float())            # fused shadow == cast of the update
+    p_ref = dict(models[0].named_parameters())
+    for n, p in models[1].named_parameters():
+        assert rel(p, p_ref[n].detach().cpu()) < 2e-6, n
+    if ema:
+        esd = opt.ema_state_dict()
+        for n in ema_ref:
+            assert rel(esd[n], ema_ref[n].cpu()) < 2e-5, n
+    sd = opt.state_dict()
+    assert sd["step"] == 3 and sd["exp_avg"].shape == a["flat"].shape

@@ -79,16 +79,18 @@ class GradSync:
             return None
         return dist.all_reduce(self.model._arena["gcur"][lo:hi], async_op=True)
 
-    def finish(self, works):
-        """Wait for all_reduce_range handles and apply the 1/world averaging."""
+    def finish(self, works, average=True):
+        """Wait for all_reduce_range handles and apply the 1/world averaging (average=False leaves the SUM: an optimizer
+        that scales gradients itself -- vitres.optim.FlatAdamW.grad_scale -- saves the extra pass over the arena)."""
         if self.world == 1:
             return
         for w in works:
             if w is not None:
                 w.wait()
-        self.model._arena["gcur"].mul_(1.0 / self.world)
+        if average:
+            self.model._arena["gcur"].mul_(1.0 / self.world)
 
-    def all_reduce_grads(self):
+    def all_reduce_grads(self, average=True):
         if self.world == 1:
             return
         a = self.model._arena
@@ -96,7 +98,8 @@ class GradSync:
         p0 = a["params"][0] if a is not None else None
         if g is not None and p0.grad is not None and p0.grad.data_ptr() == g.data_ptr() + 4 * a["offsets"][0][0]:
             dist.all_reduce(g)                                    # .grad tensors are views of the flat arena
-            g.mul_(1.0 / self.world)
+            if average:
+                g.mul_(1.0 / self.world)
             return
         for p in self.model.parameters():                         # autograd cloned the views: per-tensor fallback
             if p.grad is not None:
@@ -105,8 +108,9 @@ class GradSync:
 
 
 def train_step(model, criterion, optimizer, samples, targets, patch_targets=None, patch_output_type=None, epoch=0,
-               train_iter=0, arch_sample=None, grad_sync=None, loss_scaler=None, max_norm=None):
-    """One optimisation step; returns the loss tensor (on device, not synchronised)."""
+               train_iter=0, arch_sample=None, grad_sync=None, loss_scaler=None, max_norm=None, average_grads=True):
+    """One optimisation step; returns the loss tensor (on device, not synchronised).  average_grads=False leaves the
+    all-reduced SUM in the arena (optimizer applies 1/world: vitres.optim.FlatAdamW.grad_scale)."""
     rng = None
     if arch_sample is not None:                                   # engine.py:119-131
         rng = torch.random.get_rng_state()
@@ -135,7 +139,7 @@ def train_step(model, criterion, optimizer, samples, targets, patch_targets=None
     else:
         loss.backward()
         if grad_sync is not None:
-            grad_sync.all_reduce_grads()
+            grad_sync.all_reduce_grads(average=average_grads)
         if max_norm:
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
         optimizer.step()
@@ -223,9 +227,10 @@ class GraphedTrainStep:
 
     _sync, _works = None, ()
 
-    def step_with_sync(self, grad_sync, samples, targets, patch_targets=None, **kw):
+    def step_with_sync(self, grad_sync, samples, targets, patch_targets=None, average=True, **kw):
         """Replay + data-parallel gradient exchange: with split_for_sync the all-reduce of the last stage's gradients
-        overlaps the second backward graph; the remainder follows it.  Gradients are averaged on return."""
+        overlaps the second backward graph; the remainder follows it.  Gradients are averaged on return (average=False:
+        summed -- for an optimizer that applies 1/world itself)."""
         self._sync, self._works = grad_sync, []
         try:
             loss = self(samples, targets, patch_targets, **kw)
@@ -233,9 +238,9 @@ class GraphedTrainStep:
             self._sync = None
         if self.graph_b is not None:
             self._works.append(grad_sync.all_reduce_range(0, self.split[1]))
-            grad_sync.finish(self._works)
+            grad_sync.finish(self._works, average=average)
         else:
-            grad_sync.all_reduce_grads()
+            grad_sync.all_reduce_grads(average=average)
         self._works = ()
         return loss
 

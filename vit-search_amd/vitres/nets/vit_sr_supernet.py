@@ -274,6 +274,20 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             for m in self.modules():
                 if isinstance(m, Block):
                     m.rewiring()
+            self.invalidate_shadow()
+
+    def invalidate_shadow(self):
+        """Call after changing parameter VALUES outside an optimizer step (rewiring, load_state_dict, manual edits) when
+        vitres.optim.FlatAdamW maintains the bf16 weight shadow: re-casts it right away (forwards then skip their own cast,
+        also inside a captured hipGraph)."""
+        a = self._arena
+        if a is not None and a.get("shadow_ok") and a["flat"].is_cuda:
+            K.cast_bf16(a["flat"], a["shadow"])
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.invalidate_shadow()
+        return out
 
     def set_compute_dtype(self, dtype):
         assert dtype in (torch.float32, torch.bfloat16)
@@ -512,7 +526,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         if self.compute_dtype == torch.bfloat16:
             if Fn.OVERLAP and a["flat"].is_cuda:
                 Fn.join_side()             # a previous forward's side work (if its backward never ran)
-            K.cast_bf16(a["flat"], a["shadow"])
+            if not a.get("shadow_ok"):                 # vitres.optim.FlatAdamW writes the shadow with every update
+                K.cast_bf16(a["flat"], a["shadow"])
             if a["tr"] is not None and save:
                 # only the backward needs W^T: refresh it beside the forward (joined at the start of _run_backward)
                 if Fn.OVERLAP and a["flat"].is_cuda:

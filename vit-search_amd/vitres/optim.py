@@ -1,0 +1,128 @@
+"""Step tail on the flat parameter arena: AdamW (+ bf16 shadow, gradient averaging, EMA) in ONE HIP pass.
+
+Reference: timm 0.3.2 `create_optimizer(args, model)` -> torch.optim.AdamW(lr, weight_decay=0.05) over the two groups of
+`add_weight_decay` (main.py:385; engine.param_groups_weight_decay restates the grouping), `ModelEmaV2` (main.py:357-363).
+`FlatAdamW` keeps torch.optim.Optimizer's interface (param_groups with mutable 'lr' for the cosine scheduler,
+state_dict / load_state_dict, zero_grad) but its state is two flat fp32 buffers shaped like the model's arena, and step()
+is one `vr_adamw_flat` launch that also refreshes the bf16 weight shadow the next forward reads.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from .kernels import _p, _stream
+
+MAX_GROUPS = 16
+
+
+class _Group(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_c1", "sqrt_bias_c2",
+                                              "grad_scale")]
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, model, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, ema_decay=None):
+        """params: iterable of parameters or of param-group dicts (as torch.optim.AdamW); every parameter must belong to
+        `model`, whose arena they live in.  ema_decay: keep an exponential moving average of the parameters
+        (`ema_state_dict()` returns it under the model's state_dict keys)."""
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) > MAX_GROUPS:
+            raise ValueError("at most %d parameter groups" % MAX_GROUPS)
+        self.model = model
+        self.ema_decay = ema_decay
+        self._step = 0
+        self._arena_id = None
+        self.grad_scale = 1.0              # e.g. 1/world when the all-reduce leaves a SUM in the gradient arena
+
+    # ---- arena-shaped state -------------------------------------------------------------------------------
+    def _bind(self):
+        dev = next(self.model.parameters()).device
+        a = self.model._ensure_arena(dev)
+        if self._arena_id == id(a):
+            return a
+        flat = a["flat"]
+        if flat.numel() % 8:
+            raise RuntimeError("arena length must be a multiple of 8")
+        gid = torch.full((flat.numel() // 8,), 255, dtype=torch.uint8)
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if id(p) not in a["index"]:
+                    raise ValueError("FlatAdamW: parameter does not belong to the model's arena")
+                off, n = a["offsets"][a["index"][id(p)]]
+                gid[off // 8:(off + n + 7) // 8] = gi
+        old = getattr(self, "_flat_state", None)
+        self._flat_state = {"m": torch.zeros_like(flat), "v": torch.zeros_like(flat), "gid": gid.to(flat.device),
+                            "ema": flat.clone() if self.ema_decay is not None else None}
+        if old is not None and old["m"].numel() == flat.numel():      # arena rebuilt (e.g. .to(device)): carry the state
+            for k in ("m", "v", "ema"):
+                if old[k] is not None and self._flat_state[k] is not None:
+                    self._flat_state[k].copy_(old[k])
+        self._arena_id = id(a)
+        return a
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        a = self._bind()
+        g = a.get("gcur")
+        p0 = a["params"][0]
+        if g is None or p0.grad is None or p0.grad.data_ptr() != g.data_ptr() + 4 * a["offsets"][0][0]:
+            raise RuntimeError("FlatAdamW needs the gradients in the model's flat arena (one backward since zero_grad)")
+        self._step += 1
+        t = self._step
+        arr = (_Group * len(self.param_groups))()
+        for gi, group in enumerate(self.param_groups):
+            b1, b2 = group["betas"]
+            arr[gi] = _Group(group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 - b1 ** t,
+                             math.sqrt(1.0 - b2 ** t), self.grad_scale)
+        st = self._flat_state
+        shadow = a["shadow"] if self.model.compute_dtype == torch.bfloat16 else None
+        _lib.check(_lib.lib().vr_adamw_flat(_p(a["flat"]), _p(g), _p(st["m"]), _p(st["v"]), _p(shadow), _p(st["ema"]),
+                                            float(self.ema_decay or 0.0), _p(st["gid"]), ctypes.byref(arr),
+                                            len(self.param_groups), a["flat"].numel(), _stream()), "vr_adamw_flat")
+        if shadow is not None:
+            a["shadow_ok"] = True              # forwards skip their own vr_cast_f32_bf16 from now on (model.invalidate_shadow)
+        return loss
+
+    def own_shadow(self):
+        """Declare before capturing a hipGraph that this optimizer keeps the bf16 weight shadow up to date: casts it once
+        now; forwards (and graphs captured from now on) contain no cast of their own."""
+        a = self._bind()
+        if self.model.compute_dtype == torch.bfloat16:
+            from . import kernels as K
+            K.cast_bf16(a["flat"], a["shadow"])
+            a["shadow_ok"] = True
+
+    # ---- checkpoint / EMA views -------------------------------------------------------------------------------
+    def state_dict(self):
+        self._bind()
+        st = self._flat_state
+        return {"step": self._step, "exp_avg": st["m"].clone(), "exp_avg_sq": st["v"].clone(),
+                "ema": None if st["ema"] is None else st["ema"].clone(),
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self._bind()
+        st = self._flat_state
+        self._step = int(sd["step"])
+        st["m"].copy_(sd["exp_avg"])
+        st["v"].copy_(sd["exp_avg_sq"])
+        if st["ema"] is not None and sd.get("ema") is not None:
+            st["ema"].copy_(sd["ema"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+
+    def ema_state_dict(self):
+        """EMA parameters under the model's state_dict keys (buffers are taken from the live model, as ModelEmaV2's
+        deepcopy shares nothing but is updated from them every step)."""
+        a = self._bind()
+        if self._flat_state["ema"] is None:
+            raise RuntimeError("constructed without ema_decay")
+        ema = self._flat_state["ema"]
+        byid = {id(p): ema[off:off + n].view(p.shape) for p, (off, n) in zip(a["params"], a["offsets"])}
+        out = {}
+        for k, v in self.model.state_dict(keep_vars=True).items():
+            out[k] = byid[id(v)].clone() if id(v) in byid else v.detach().clone()
+        return out
