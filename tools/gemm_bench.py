@@ -28,7 +28,7 @@ def timeit(fn, n=20):
 
 shapes = [  # (tokens M, in K, out N) of Linear layers at B=128
     (32896, 320, 960), (32896, 320, 1280), (32896, 1280, 320), (32896, 256, 768), (32896, 256, 256), (32896, 768, 256), (8320, 512, 1536), (8320, 1536, 512),
-    (2176, 1024, 3072), (2176, 3072, 1024), (2176, 1024, 2304), (32896, 192, 576), (32896, 192, 768), (32896, 768, 192),
+    (2176, 1024, 3072), (2176, 3072, 1024), (2176, 1024, 1024), (8320, 512, 512), (8320, 1536, 512), (2176, 1024, 2304), (32896, 192, 576), (32896, 192, 768), (32896, 768, 192),
 ]
 print("%-26s %10s %10s %10s" % ("M,K,N", "fwd TF", "dgrad TF", "wgrad TF"))
 for M, Kd, N in shapes:

@@ -399,7 +399,7 @@ template <typename K> static int set_lds(K kernel, size_t bytes) {
 template <int D, int NKP>
 static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, const int* keep, int B, int N, int H, float scale,
                       hipStream_t st) {
-    constexpr int NW = 4;
+    constexpr int NW = NKP >= 3 ? 4 : 2;      // waves per (batch, head): one 16-query tile each per pass (measured)
     const int Np = (N + 31) / 32 * 32;
     const size_t lds = (size_t)2 * D * Np * 2;
     int rc = set_lds(fwd_kernel<D, NKP, NW>, lds);
@@ -410,7 +410,7 @@ static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, const int* keep,
 template <int D, int NKP>
 static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse, float* delta, bf16_t* dqkv,
                       const int* keep, int B, int N, int H, float scale, hipStream_t st) {
-    constexpr int NW = 8;
+    constexpr int NW = NKP >= 3 ? 8 : 2;
     const int Np = (N + 31) / 32 * 32;
     const size_t l1 = (size_t)3 * D * Np * 2, l2 = (size_t)4 * D * Np * 2 + 2 * Np * sizeof(float);
     int rc = set_lds(bwd_dq_kernel<D, NKP, NW>, l1);

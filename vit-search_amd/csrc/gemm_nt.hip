@@ -35,8 +35,7 @@ typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
-constexpr int BN = 128, BK = 64, NTHR = 256;
-constexpr int B_BYTES = BN * BK * 2;      // 16 KB per weight slice
+constexpr int BK = 64, NTHR = 256;
 
 __device__ const uint4 zero_chunk[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 
@@ -52,10 +51,15 @@ struct RowMeta {
 // or entirely outside the matrix, so the epilogue is branch-free 16-byte accesses.
 // MI = 16-row fragments per wave along M: 4 -> 128-row tile (4 workgroups / CU), 2 -> 64-row tile (5 / CU; more, smaller
 // workgroups for GEMMs that would leave the 128-row grid a partial last round)
-template <typename TO, int EPI, bool FAST, int MI>
+// NJ = 16-column fragments per wave along N: 4 -> 128-column tile, 2 -> 64-column tile (long-K GEMMs with few tiles: a lone
+// workgroup per CU pays the full ~1.5 us slice latency, four interleaved ones hide it)
+template <typename TO, int EPI, bool FAST, int MI, int NJ>
 __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm_args p) {
     constexpr int BM = 32 * MI, WROWS = 16 * MI;      // tile rows, rows per wave
+    constexpr int BN = 32 * NJ, WCOLS = 16 * NJ;      // tile columns, columns per wave
     constexpr int A_BYTES = BM * BK * 2, AP = MI;     // A slice bytes, LDS-DMA pieces of A per wave
+    constexpr int B_BYTES = BN * BK * 2, BP = NJ;     // same for the weight slice
+    constexpr int LPR = 2 * NJ, RPP = 64 / LPR, NQ = 16 / RPP;   // epilogue: lanes per row, rows per pass, passes per 16 rows
     __shared__ __attribute__((aligned(1024))) char smem[A_BYTES + B_BYTES];   // [A slice][B slice]; epilogue: 4 x 4 KB
     __shared__ RowMeta rowmeta[BM];
     const int t = threadIdx.x, lane = t & 63;
@@ -96,11 +100,11 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
 
     // ---- LDS-DMA source addressing: piece h of this wave = tile rows wave*32 + 8h .. +8, lane -> (row, slot) ----
     const char* gA[AP];
-    const char* gB[4];
-    int chunkA[AP], chunkB[4];     // element offset of this lane's k-chunk inside a slice
+    const char* gB[BP];
+    int chunkA[AP], chunkB[BP];    // element offset of this lane's k-chunk inside a slice
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        const int r = wave * 32 + h * 8 + (lane >> 3);
+    for (int h = 0; h < BP; ++h) {
+        const int r = wave * (8 * BP) + h * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         const int nb = min(n0 + r, p.N - 1);
         gB[h] = reinterpret_cast<const char*>(p.B) + (map_row(bmap, nb) * (long long)p.ldb + c * 8) * 2;
@@ -121,13 +125,13 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     const int frow = lane & 15, fswz = (frow >> 1) & 7;
     const int slot0 = (((lane >> 4)) ^ fswz) << 4, slot1 = ((4 + (lane >> 4)) ^ fswz) << 4;
     const char* As = smem + (wm * WROWS + frow) * 128;
-    const char* Bs = smem + A_BYTES + (wn * 64 + frow) * 128;
+    const char* Bs = smem + A_BYTES + (wn * WCOLS + frow) * 128;
 
-    f32x4 acc[MI][4];
+    f32x4 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto issue = [&](int kt) {
         const int k0 = kt * BK;
@@ -138,9 +142,9 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
             __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(smem + (wave * (8 * AP) + h * 8) * 128), 16, 0, 0);
         }
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
+        for (int h = 0; h < BP; ++h) {
             const char* sb = (!ktail || (k0 + chunkB[h] < p.K)) ? gB[h] + kb : zero;
-            __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(smem + A_BYTES + (wave * 32 + h * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(smem + A_BYTES + (wave * (8 * BP) + h * 8) * 128), 16, 0, 0);
         }
     };
 
@@ -167,15 +171,15 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int so = s == 0 ? slot0 : slot1;
-            bfv8 a[MI], b[4];
+            bfv8 a[MI], b[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bfv8*>(As + i * 2048 + so);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bfv8*>(Bs + j * 2048 + so);
+            for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bfv8*>(Bs + j * 2048 + so);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     // ---- epilogue: lane owns C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) + 0..3] of the wave's 64 x 64 ----
     constexpr int CW = 8;
     float* park = reinterpret_cast<float*>(smem + wave * 4096);      // [16 rows][16 slots of 4 floats], slot ^= row
-    const int n = n0 + wn * 64 + (lane & 7) * 8;                      // this lane's 8 columns
+    const int n = n0 + wn * WCOLS + (lane % LPR) * 8;                 // this lane's 8 columns
     const int nvalid = min(CW, p.N - n);
     const int nc = nvalid > 0 ? n : 0;
     const int nv = nvalid > 0 ? nvalid : 1;
@@ -204,23 +208,23 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     const bool has_pos = (EPI == EPI_STORE) && p.pos;
     const bool has_res = (EPI == EPI_STORE) && p.resid;
     const bool live = nvalid > 0 && !(p.sched & 16);                  // ABLATION knob: bit 4 drops the stores
-    const RowMeta* meta = rowmeta + wm * WROWS + (lane >> 3);
-    // one round per 16-row fragment: park [16 rows][64 columns] (4 KB per wave), read back as rows
+    const RowMeta* meta = rowmeta + wm * WROWS + (lane / LPR);
+    // one round per 16-row fragment: park [16 rows][WCOLS columns] (<= 4 KB per wave), read back as rows
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int slot = (4 * j + (lane >> 4)) ^ (lane & 15);
-            *reinterpret_cast<f32x4*>(park + (lane & 15) * 64 + slot * 4) = acc[i][j];
+        for (int j = 0; j < NJ; ++j) {
+            const int slot = (4 * j + (lane >> 4)) ^ (lane & (4 * NJ - 1));
+            *reinterpret_cast<f32x4*>(park + (lane & 15) * WCOLS + slot * 4) = acc[i][j];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        RowMeta rm[2];
-        long long orow[2];
-        float rv[2][CW], pv[2][CW];
+        RowMeta rm[NQ];
+        long long orow[NQ];
+        float rv[NQ][CW], pv[NQ][CW];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            rm[q] = meta[i * 16 + q * 8];
+        for (int q = 0; q < NQ; ++q) {
+            rm[q] = meta[i * 16 + q * RPP];
             orow[q] = rm[q].orow < 0 ? 0 : rm[q].orow;
 #pragma unroll
             for (int e = 0; e < CW; ++e) { rv[q][e] = 0.f; pv[q][e] = 0.f; }
@@ -231,16 +235,16 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
             }
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int rl = q * 8 + (lane >> 3);
+        for (int q = 0; q < NQ; ++q) {
+            const int rl = q * RPP + (lane / LPR);
             const bool mok = rm[q].orow >= 0;
             const int kn = rm[q].keep - ncp;
             const float sc = rm[q].scale;
             float v[CW];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int slot = (2 * (lane & 7) + h) ^ rl;
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(park + rl * 64 + slot * 4);
+                const int slot = (2 * (lane % LPR) + h) ^ (rl & (4 * NJ - 1));
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(park + rl * WCOLS + slot * 4);
                 v[4 * h] = a4[0]; v[4 * h + 1] = a4[1]; v[4 * h + 2] = a4[2]; v[4 * h + 3] = a4[3];
             }
             bool kc[CW];
@@ -277,20 +281,23 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     }
 }
 
+template <typename TO, int EPI, int MI, int NJ> void launch2(const vr_gemm_args& a, hipStream_t stream, bool fast) {
+    const long long total = (long long)((a.M + 32 * MI - 1) / (32 * MI)) * ((a.N + 32 * NJ - 1) / (32 * NJ));
+    if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true, MI, NJ>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    else hipLaunchKernelGGL((nt_kernel<TO, EPI, false, MI, NJ>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+}
+
 template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
-    const long long tn = (a.N + BN - 1) / BN;
+    const long long tn = (a.N + 127) / 128;
     const long long t128 = (long long)((a.M + 127) / 128) * tn, t64 = (long long)((a.M + 63) / 64) * tn;
     const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);
-    static const int knob_mi = std::getenv("VITRES_NT_MI") ? std::atoi(std::getenv("VITRES_NT_MI")) : 0;
-    // 64-row tiles when the 128-row grid would give a CU fewer than two workgroups (measured crossover, tools/gemm_bench.py)
-    const bool small = knob_mi ? knob_mi == 2 : t128 < 2LL * n_cu;
-    if (small) {
-        if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true, 2>), dim3((unsigned)t64), dim3(NTHR), 0, stream, a);
-        else hipLaunchKernelGGL((nt_kernel<TO, EPI, false, 2>), dim3((unsigned)t64), dim3(NTHR), 0, stream, a);
-    } else {
-        if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true, 4>), dim3((unsigned)t128), dim3(NTHR), 0, stream, a);
-        else hipLaunchKernelGGL((nt_kernel<TO, EPI, false, 4>), dim3((unsigned)t128), dim3(NTHR), 0, stream, a);
-    }
+    static const int knob = std::getenv("VITRES_NT_TILE") ? std::atoi(std::getenv("VITRES_NT_TILE")) : 0;   // 1/2/3: force
+    // tile by grid size (measured crossovers, tools/gemm_bench.py): 128x128 while it gives a CU two workgroups, 64x128
+    // below that, 64x64 when even that leaves CUs with a single workgroup (long-K GEMMs of the last stage)
+    const int tile = knob ? knob : (t128 >= 2LL * n_cu ? 1 : (t64 >= 2LL * n_cu ? 2 : 3));
+    if (tile == 1) launch2<TO, EPI, 4, 4>(a, stream, fast);
+    else if (tile == 2) launch2<TO, EPI, 2, 4>(a, stream, fast);
+    else launch2<TO, EPI, 2, 2>(a, stream, fast);
 }
 
 }  // namespace vr_gemm_nt
