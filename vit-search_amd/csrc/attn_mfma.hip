@@ -34,17 +34,28 @@ __device__ __forceinline__ f32x4 mfma16(bfv8 a, bfv8 b, f32x4 c) {
 }
 
 // ---- staging ---------------------------------------------------------------------------------------------
-// rows [N][D] at src (row stride rs elements) -> chunk-major LDS, rows N..Np-1 zero
-template <int D>
-__device__ __forceinline__ void stage_chunked(char* dst, const bf16_t* __restrict__ src, int rs, int N, int Np, int tid,
-                                              int nthr) {
+// rows [N][D] at src (row stride rs elements) -> chunk-major LDS, rows N..Np-1 zero.
+// Trip counts are compile-time (MAXNP = 32 * NKP >= Np) and the loop is fully unrolled with every global load issued
+// before the first LDS store: a run-time loop made each iteration a separate HBM round trip (load, wait, store), and a
+// workgroup that owns a CU alone (100+ KB of LDS) has nothing else to hide them behind.
+template <int D, int MAXNP, int NTHR>
+__device__ __forceinline__ void stage_chunked(char* dst, const bf16_t* __restrict__ src, int rs, int N, int Np, int tid) {
     constexpr int NCH = AC<D>::NCH;
-    for (int idx = tid; idx < Np * NCH; idx += nthr) {
+    constexpr int IT = (MAXNP * NCH + NTHR - 1) / NTHR;
+    uint4 v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NTHR;
         const int n = idx % Np, ch = idx / Np;
-        const bool ok = n < N;
-        uint4 v = *reinterpret_cast<const uint4*>(src + (long long)(ok ? n : 0) * rs + ch * 8);
-        if (!ok) v = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(dst + ((size_t)ch * Np + n) * 16) = v;
+        const bool ok = n < N && ch < NCH;
+        v[it] = *reinterpret_cast<const uint4*>(src + (long long)(ok ? n : 0) * rs + (ok ? ch : 0) * 8);
+        if (!ok) v[it] = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NTHR;
+        const int n = idx % Np, ch = idx / Np;
+        if (ch < NCH) *reinterpret_cast<uint4*>(dst + ((size_t)ch * Np + n) * 16) = v[it];
     }
 }
 
@@ -53,25 +64,34 @@ template <int D> __device__ __forceinline__ int tr_off(int kq, int d) {
     return kq * (D * 8) + dp * 8;
 }
 
-// rows [N][D] -> transposed LDS [Np/4][D][4]; thread handles 4 rows x 2 adjacent d
-template <int D>
-__device__ __forceinline__ void stage_transposed(char* dst, const bf16_t* __restrict__ src, int rs, int N, int Np, int tid,
-                                                 int nthr) {
+// rows [N][D] -> transposed LDS [Np/4][D][4]; thread handles 4 rows x 2 adjacent d (unrolled like stage_chunked)
+template <int D, int MAXNP, int NTHR>
+__device__ __forceinline__ void stage_transposed(char* dst, const bf16_t* __restrict__ src, int rs, int N, int Np, int tid) {
     constexpr int HP = D / 2;
-    for (int idx = tid; idx < (Np / 4) * HP; idx += nthr) {
+    constexpr int IT = ((MAXNP / 4) * HP + NTHR - 1) / NTHR;
+    uint32_t w[IT][4];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NTHR;
         const int dp = idx % HP, kq = idx / HP;
-        uint32_t w[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int n = kq * 4 + e;
             const bool ok = n < N;
             const uint32_t x = *reinterpret_cast<const uint32_t*>(src + (long long)(ok ? n : 0) * rs + dp * 2);
-            w[e] = ok ? x : 0u;
+            w[it][e] = ok ? x : 0u;
         }
-        const uint2 lo = make_uint2((w[0] & 0xffffu) | (w[1] << 16), (w[2] & 0xffffu) | (w[3] << 16));
-        const uint2 hi = make_uint2((w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u));
-        *reinterpret_cast<uint2*>(dst + tr_off<D>(kq, dp * 2)) = lo;
-        *reinterpret_cast<uint2*>(dst + tr_off<D>(kq, dp * 2 + 1)) = hi;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NTHR;
+        const int dp = idx % HP, kq = idx / HP;
+        if (kq < Np / 4) {
+            const uint2 lo = make_uint2((w[it][0] & 0xffffu) | (w[it][1] << 16), (w[it][2] & 0xffffu) | (w[it][3] << 16));
+            const uint2 hi = make_uint2((w[it][0] >> 16) | (w[it][1] & 0xffff0000u), (w[it][2] >> 16) | (w[it][3] & 0xffff0000u));
+            *reinterpret_cast<uint2*>(dst + tr_off<D>(kq, dp * 2)) = lo;
+            *reinterpret_cast<uint2*>(dst + tr_off<D>(kq, dp * 2 + 1)) = hi;
+        }
     }
 }
 
@@ -137,8 +157,8 @@ __global__ __launch_bounds__(NW * 64) void fwd_kernel(const bf16_t* __restrict__
     const int Np = (N + 31) / 32 * 32, nkt = Np / 16, nkp = Np / 32;
     char* Kc = sm;
     char* Vt = sm + (size_t)D * Np * 2;
-    stage_chunked<D>(Kc, base + HD, RS, N, Np, tid, NW * 64);
-    stage_transposed<D>(Vt, base + 2 * HD, RS, N, Np, tid, NW * 64);
+    stage_chunked<D, 32 * NKP, NW * 64>(Kc, base + HD, RS, N, Np, tid);
+    stage_transposed<D, 32 * NKP, NW * 64>(Vt, base + 2 * HD, RS, N, Np, tid);
     __syncthreads();
     for (int q0 = wave * 16; q0 < N; q0 += NW * 16) {
         bfv8 qf[AC<D>::DK];
@@ -180,18 +200,16 @@ __global__ __launch_bounds__(NW * 64) void fwd_kernel(const bf16_t* __restrict__
             if (kp < nkp) {
                 const bfv8 pf = pack8(st[2 * kp], st[2 * kp + 1]);
 #pragma unroll
-                for (int dt = 0; dt < AC<D>::DT; ++dt) oacc[dt] = mfma16(pf, tfrag<D>(Vt, kp, dt, lane), oacc[dt]);
+                for (int dt = 0; dt < AC<D>::DT; ++dt) oacc[dt] = mfma16(tfrag<D>(Vt, kp, dt, lane), pf, oacc[dt]);
             }
         }
+        // O^T tiles (V^T as the first operand): the lane owns query q0 + c and 4 consecutive d per tile -> 8-byte stores
         const float inv = 1.0f / sum;
+        if (q0 + c < N) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ir = __shfl(inv, 4 * g + r, 64);     // lane 4g+r holds query 4g+r of this tile
-            const int q = q0 + 4 * g + r;
-            if (q < N) {
-#pragma unroll
-                for (int dt = 0; dt < AC<D>::DT; ++dt) ob[(long long)q * HD + dt * 16 + c] = f2bf(oacc[dt][r] * ir);
-            }
+            for (int dt = 0; dt < AC<D>::DT; ++dt)
+                *reinterpret_cast<uint2*>(ob + (long long)(q0 + c) * HD + dt * 16 + 4 * g) =
+                    make_uint2(pack_bf2(oacc[dt][0] * inv, oacc[dt][1] * inv), pack_bf2(oacc[dt][2] * inv, oacc[dt][3] * inv));
         }
         if (g == 0 && q0 + c < N) lb[q0 + c] = mx + __logf(sum);
     }
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(NW * 64) void fwd_kernel(const bf16_t* __restrict__
 // ==========================================================================================================
 // backward A: dQ (+ delta = rowsum(dO * O))
 // ==========================================================================================================
-template <int D, int NKP, int NW>
+template <int D, int NKP, int NW, int QT>
 __global__ __launch_bounds__(NW * 64) void bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                          const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                          float* __restrict__ delta, bf16_t* __restrict__ dqkv,
@@ -227,60 +245,84 @@ __global__ __launch_bounds__(NW * 64) void bwd_dq_kernel(const bf16_t* __restric
     char* Kc = sm;
     char* Vc = Kc + (size_t)D * Np * 2;
     char* Kt = Vc + (size_t)D * Np * 2;
-    stage_chunked<D>(Kc, base + HD, RS, N, Np, tid, NW * 64);
-    stage_chunked<D>(Vc, base + 2 * HD, RS, N, Np, tid, NW * 64);
-    stage_transposed<D>(Kt, base + HD, RS, N, Np, tid, NW * 64);
+    stage_chunked<D, 32 * NKP, NW * 64>(Kc, base + HD, RS, N, Np, tid);
+    stage_chunked<D, 32 * NKP, NW * 64>(Vc, base + 2 * HD, RS, N, Np, tid);
+    stage_transposed<D, 32 * NKP, NW * 64>(Kt, base + HD, RS, N, Np, tid);
     __syncthreads();
-    for (int q0 = wave * 16; q0 < N; q0 += NW * 16) {
-        const bool qok = q0 + c < N;
-        bfv8 qf[AC<D>::DK], gf[AC<D>::DK];
-        float dl = 0.f;
+    // QT query tiles per wave at once: every LDS fragment (K, V, K^T of a key tile) is read once and feeds QT MFMAs --
+    // with one tile per wave the kernel was LDS-bandwidth bound (each wave re-read the whole head per 16 queries)
+    for (int u0 = wave * QT * 16; u0 < N; u0 += NW * QT * 16) {
+        bool qok[QT];
+        bfv8 qf[QT][AC<D>::DK], gf[QT][AC<D>::DK];
+        float dl[QT], l[QT];
+        f32x4 dq[QT][AC<D>::DT];
 #pragma unroll
-        for (int dk = 0; dk < AC<D>::DK; ++dk) {
-            qf[dk] = gfrag<D>(base, RS, q0, N, dk, lane);
-            gf[dk] = gfrag<D>(gb, HD, q0, N, dk, lane);
-            const bfv8 of = gfrag<D>(ob, HD, q0, N, dk, lane);
+        for (int t = 0; t < QT; ++t) {
+            const int q0 = u0 + 16 * t;
+            qok[t] = q0 + c < N;
+            float d = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dl += (float)gf[dk][e] * (float)of[e];
+            for (int dk = 0; dk < AC<D>::DK; ++dk) {
+                qf[t][dk] = gfrag<D>(base, RS, q0, N, dk, lane);
+                gf[t][dk] = gfrag<D>(gb, HD, q0, N, dk, lane);
+                const bfv8 of = gfrag<D>(ob, HD, q0, N, dk, lane);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += (float)gf[t][dk][e] * (float)of[e];
+            }
+            dl[t] = gsum(d);
+            l[t] = qok[t] ? lb[q0 + c] : 0.f;
+            if (g == 0 && qok[t]) db[q0 + c] = dl[t];
+#pragma unroll
+            for (int dt = 0; dt < AC<D>::DT; ++dt) dq[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        dl = gsum(dl);
-        const float l = qok ? lb[q0 + c] : 0.f;
-        if (g == 0 && qok) db[q0 + c] = dl;
-        f32x4 dq[AC<D>::DT];
-#pragma unroll
-        for (int dt = 0; dt < AC<D>::DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kp = 0; kp < NKP; ++kp) {
             if (kp < nkp) {
-                f32x4 ds[2];
+                f32x4 ds[QT][2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int kt = 2 * kp + t;
-                    f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int kt = 2 * kp + tt;
+                    bfv8 ka[AC<D>::DK], va[AC<D>::DK];
 #pragma unroll
                     for (int dk = 0; dk < AC<D>::DK; ++dk) {
-                        s = mfma16(cfrag<D>(Kc, Np, kt * 16, dk, lane), qf[dk], s);
-                        dp = mfma16(cfrag<D>(Vc, Np, kt * 16, dk, lane), gf[dk], dp);
+                        ka[dk] = cfrag<D>(Kc, Np, kt * 16, dk, lane);
+                        va[dk] = cfrag<D>(Vc, Np, kt * 16, dk, lane);
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool ok = qok && ((kt * 16 + 4 * g + r) < N);
-                        const float p = ok ? __expf(s[r] * scale - l) : 0.f;
-                        s[r] = p * (dp[r] - dl) * scale;
+                    for (int t = 0; t < QT; ++t) {
+                        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int dk = 0; dk < AC<D>::DK; ++dk) {
+                            sc = mfma16(ka[dk], qf[t][dk], sc);
+                            dp = mfma16(va[dk], gf[t][dk], dp);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool ok = qok[t] && ((kt * 16 + 4 * g + r) < N);
+                            const float pr = ok ? __expf(sc[r] * scale - l[t]) : 0.f;
+                            sc[r] = pr * (dp[r] - dl[t]) * scale;
+                        }
+                        ds[t][tt] = sc;
                     }
-                    ds[t] = s;
                 }
-                const bfv8 sf = pack8(ds[0], ds[1]);       // dS never leaves registers
+                bfv8 sf[QT];
 #pragma unroll
-                for (int dt = 0; dt < AC<D>::DT; ++dt) dq[dt] = mfma16(sf, tfrag<D>(Kt, kp, dt, lane), dq[dt]);
+                for (int t = 0; t < QT; ++t) sf[t] = pack8(ds[t][0], ds[t][1]);       // dS never leaves registers
+#pragma unroll
+                for (int dt = 0; dt < AC<D>::DT; ++dt) {
+                    const bfv8 kt_f = tfrag<D>(Kt, kp, dt, lane);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) dq[t][dt] = mfma16(kt_f, sf[t], dq[t][dt]);
+                }
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = q0 + 4 * g + r;
-            if (q < N) {
+        for (int t = 0; t < QT; ++t) {
+            if (qok[t]) {      // dQ^T tiles: query q0 + c, 4 consecutive d per tile
 #pragma unroll
-                for (int dt = 0; dt < AC<D>::DT; ++dt) dbase[(long long)q * RS + dt * 16 + c] = f2bf(dq[dt][r]);
+                for (int dt = 0; dt < AC<D>::DT; ++dt)
+                    *reinterpret_cast<uint2*>(dbase + (long long)(u0 + 16 * t + c) * RS + dt * 16 + 4 * g) =
+                        make_uint2(pack_bf2(dq[t][dt][0], dq[t][dt][1]), pack_bf2(dq[t][dt][2], dq[t][dt][3]));
             }
         }
     }
@@ -289,7 +331,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_dq_kernel(const bf16_t* __restric
 // ==========================================================================================================
 // backward B: dK, dV
 // ==========================================================================================================
-template <int D, int NKP, int NW>
+template <int D, int NKP, int NW, int QT>
 __global__ __launch_bounds__(NW * 64) void bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, const int* __restrict__ keep_hd,
@@ -316,66 +358,90 @@ __global__ __launch_bounds__(NW * 64) void bwd_dkv_kernel(const bf16_t* __restri
     char* Gt = Qt + (size_t)D * Np * 2;
     float* Ls = reinterpret_cast<float*>(Gt + (size_t)D * Np * 2);
     float* Ds = Ls + Np;
-    stage_chunked<D>(Qc, base, RS, N, Np, tid, NW * 64);
-    stage_chunked<D>(Gc, gb, HD, N, Np, tid, NW * 64);
-    stage_transposed<D>(Qt, base, RS, N, Np, tid, NW * 64);
-    stage_transposed<D>(Gt, gb, HD, N, Np, tid, NW * 64);
+    stage_chunked<D, 32 * NKP, NW * 64>(Qc, base, RS, N, Np, tid);
+    stage_chunked<D, 32 * NKP, NW * 64>(Gc, gb, HD, N, Np, tid);
+    stage_transposed<D, 32 * NKP, NW * 64>(Qt, base, RS, N, Np, tid);
+    stage_transposed<D, 32 * NKP, NW * 64>(Gt, gb, HD, N, Np, tid);
     for (int n = tid; n < Np; n += NW * 64) {
         Ls[n] = n < N ? lse[((long long)b * H + h) * N + n] : 0.f;
         Ds[n] = n < N ? delta[((long long)b * H + h) * N + n] : 0.f;
     }
     __syncthreads();
-    for (int k0 = wave * 16; k0 < N; k0 += NW * 16) {
-        bfv8 kf[AC<D>::DK], vf[AC<D>::DK];
+    for (int u0 = wave * QT * 16; u0 < N; u0 += NW * QT * 16) {       // QT key tiles per wave (see bwd_dq_kernel)
+        bfv8 kf[QT][AC<D>::DK], vf[QT][AC<D>::DK];
+        f32x4 dka[QT][AC<D>::DT], dva[QT][AC<D>::DT];
 #pragma unroll
-        for (int dk = 0; dk < AC<D>::DK; ++dk) {
-            kf[dk] = gfrag<D>(base + HD, RS, k0, N, dk, lane);
-            vf[dk] = gfrag<D>(base + 2 * HD, RS, k0, N, dk, lane);
-        }
-        f32x4 dka[AC<D>::DT], dva[AC<D>::DT];
+        for (int t = 0; t < QT; ++t) {
 #pragma unroll
-        for (int dt = 0; dt < AC<D>::DT; ++dt) {
-            dka[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dva[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int dk = 0; dk < AC<D>::DK; ++dk) {
+                kf[t][dk] = gfrag<D>(base + HD, RS, u0 + 16 * t, N, dk, lane);
+                vf[t][dk] = gfrag<D>(base + 2 * HD, RS, u0 + 16 * t, N, dk, lane);
+            }
+#pragma unroll
+            for (int dt = 0; dt < AC<D>::DT; ++dt) {
+                dka[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dva[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
 #pragma unroll 1
         for (int qp = 0; qp < nqp; ++qp) {
-            f32x4 p[2], ds[2];
+            f32x4 p[QT][2], ds[QT][2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int q0 = qp * 32 + t * 16;
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            for (int tt = 0; tt < 2; ++tt) {
+                const int q0 = qp * 32 + tt * 16;
+                bfv8 qa[AC<D>::DK], ga[AC<D>::DK];
 #pragma unroll
                 for (int dk = 0; dk < AC<D>::DK; ++dk) {
-                    s = mfma16(cfrag<D>(Qc, Np, q0, dk, lane), kf[dk], s);
-                    dp = mfma16(cfrag<D>(Gc, Np, q0, dk, lane), vf[dk], dp);
+                    qa[dk] = cfrag<D>(Qc, Np, q0, dk, lane);
+                    ga[dk] = cfrag<D>(Gc, Np, q0, dk, lane);
                 }
                 const float4 l4 = *reinterpret_cast<const float4*>(Ls + q0 + 4 * g);
                 const float4 d4 = *reinterpret_cast<const float4*>(Ds + q0 + 4 * g);
                 const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = (q0 + 4 * g + r) < N;
-                    const float pv = ok ? __expf(s[r] * scale - lr[r]) : 0.f;
-                    p[t][r] = pv;
-                    ds[t][r] = pv * (dp[r] - dr[r]) * scale;
+                for (int t = 0; t < QT; ++t) {
+                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int dk = 0; dk < AC<D>::DK; ++dk) {
+                        sc = mfma16(qa[dk], kf[t][dk], sc);
+                        dp = mfma16(ga[dk], vf[t][dk], dp);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = (q0 + 4 * g + r) < N;
+                        const float pv = ok ? __expf(sc[r] * scale - lr[r]) : 0.f;
+                        p[t][tt][r] = pv;
+                        ds[t][tt][r] = pv * (dp[r] - dr[r]) * scale;
+                    }
                 }
             }
-            const bfv8 pf = pack8(p[0], p[1]), sf = pack8(ds[0], ds[1]);
+            bfv8 pf[QT], sf[QT];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                pf[t] = pack8(p[t][0], p[t][1]);
+                sf[t] = pack8(ds[t][0], ds[t][1]);
+            }
 #pragma unroll
             for (int dt = 0; dt < AC<D>::DT; ++dt) {
-                dva[dt] = mfma16(pf, tfrag<D>(Gt, qp, dt, lane), dva[dt]);
-                dka[dt] = mfma16(sf, tfrag<D>(Qt, qp, dt, lane), dka[dt]);
+                const bfv8 gt_f = tfrag<D>(Gt, qp, dt, lane), qt_f = tfrag<D>(Qt, qp, dt, lane);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    dva[t][dt] = mfma16(gt_f, pf[t], dva[t][dt]);
+                    dka[t][dt] = mfma16(qt_f, sf[t], dka[t][dt]);
+                }
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = k0 + 4 * g + r;
-            if (k < N) {
+        for (int t = 0; t < QT; ++t) {
+            const int k = u0 + 16 * t + c;
+            if (k < N) {      // dK^T / dV^T tiles: key k, 4 consecutive d per tile
 #pragma unroll
                 for (int dt = 0; dt < AC<D>::DT; ++dt) {
-                    dbase[(long long)k * RS + HD + dt * 16 + c] = f2bf(dka[dt][r]);
-                    dbase[(long long)k * RS + 2 * HD + dt * 16 + c] = f2bf(dva[dt][r]);
+                    bf16_t* dst = dbase + (long long)k * RS + dt * 16 + 4 * g;
+                    *reinterpret_cast<uint2*>(dst + HD) =
+                        make_uint2(pack_bf2(dka[t][dt][0], dka[t][dt][1]), pack_bf2(dka[t][dt][2], dka[t][dt][3]));
+                    *reinterpret_cast<uint2*>(dst + 2 * HD) =
+                        make_uint2(pack_bf2(dva[t][dt][0], dva[t][dt][1]), pack_bf2(dva[t][dt][2], dva[t][dt][3]));
                 }
             }
         }
@@ -399,7 +465,7 @@ template <typename K> static int set_lds(K kernel, size_t bytes) {
 template <int D, int NKP>
 static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, const int* keep, int B, int N, int H, float scale,
                       hipStream_t st) {
-    constexpr int NW = NKP >= 3 ? 4 : 2;      // waves per (batch, head): one 16-query tile each per pass (measured)
+    constexpr int NW = NKP >= 9 ? 8 : (NKP >= 3 ? 4 : 2);      // waves per (batch, head): one 16-query tile each per pass (measured)
     const int Np = (N + 31) / 32 * 32;
     const size_t lds = (size_t)2 * D * Np * 2;
     int rc = set_lds(fwd_kernel<D, NKP, NW>, lds);
@@ -411,15 +477,16 @@ template <int D, int NKP>
 static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse, float* delta, bf16_t* dqkv,
                       const int* keep, int B, int N, int H, float scale, hipStream_t st) {
     constexpr int NW = NKP >= 3 ? 8 : 2;
+    constexpr int QT = NKP >= 9 ? 3 : 1;      // query / key tiles per wave: 17 tiles of N = 257 = one pass of 6 waves
     const int Np = (N + 31) / 32 * 32;
     const size_t l1 = (size_t)3 * D * Np * 2, l2 = (size_t)4 * D * Np * 2 + 2 * Np * sizeof(float);
-    int rc = set_lds(bwd_dq_kernel<D, NKP, NW>, l1);
+    int rc = set_lds(bwd_dq_kernel<D, NKP, NW, QT>, l1);
     if (rc) return rc;
-    rc = set_lds(bwd_dkv_kernel<D, NKP, NW>, l2);
+    rc = set_lds(bwd_dkv_kernel<D, NKP, NW, QT>, l2);
     if (rc) return rc;
-    hipLaunchKernelGGL((bwd_dq_kernel<D, NKP, NW>), dim3(B * H), dim3(NW * 64), l1, st, qkv, o, d_o, lse, delta, dqkv, keep,
+    hipLaunchKernelGGL((bwd_dq_kernel<D, NKP, NW, QT>), dim3(B * H), dim3(NW * 64), l1, st, qkv, o, d_o, lse, delta, dqkv, keep,
                        B, N, H, scale);
-    hipLaunchKernelGGL((bwd_dkv_kernel<D, NKP, NW>), dim3(B * H), dim3(NW * 64), l2, st, qkv, d_o, lse, delta, dqkv, keep, B,
+    hipLaunchKernelGGL((bwd_dkv_kernel<D, NKP, NW, QT>), dim3(B * H), dim3(NW * 64), l2, st, qkv, d_o, lse, delta, dqkv, keep, B,
                        N, H, scale);
     return 0;
 }
