@@ -19,6 +19,8 @@
 //
 // The Linear's bias gradient (column sums of dY) is one more MFMA per A fragment against an all-ones B fragment, done
 // by the workgroups of the first column tile only.
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/vitres_hip.h"
 #include "gemm_shared.h"
@@ -184,12 +186,14 @@ bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
     vr_gemm_args a = a0;
     const long long tiles = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     if (a.split_k <= 0) {
-        // Every workgroup pays 64 KB of fp32 atomics whatever its share of the tokens, so the split is as coarse as the
-        // chip allows (measured on MI355X, tools/gemm_bench.py): 32 slices of tokens per workgroup when that still yields
-        // >= 1.5 workgroups per CU, else 16; never more than 4 workgroups per CU.
+        // Every workgroup pays 64 KB of fp32 atomics whatever its share of the tokens, so the split is coarse: 32 slices
+        // (2048 tokens) per workgroup, never more than 4 workgroups per CU.  Alone on the chip a small weight would
+        // prefer 16 slices (more workgroups), but the weight gradients run beside the data-gradient chain on a second
+        // stream, which fills the CUs anyway: 32 measured +3 % on the whole training step over the adaptive 16/32 rule,
+        // 24 / 40 / 48 / 64 all slower (VITRES_TN_S overrides for experiments).
+        static const int knob_s = std::getenv("VITRES_TN_S") ? std::atoi(std::getenv("VITRES_TN_S")) : 32;
         const long long slices = (a.K + BT - 1) / BT;
-        const long long s32 = (slices + 31) / 32, s16 = (slices + 15) / 16;
-        long long s = (tiles * s32 * 2 >= 3LL * n_cu) ? s32 : s16;
+        long long s = (slices + knob_s - 1) / knob_s;
         const long long by_fill = (4LL * n_cu + tiles - 1) / tiles;
         if (s > by_fill) s = by_fill;
         a.split_k = (int)(s < 1 ? 1 : s);
