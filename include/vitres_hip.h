@@ -187,7 +187,8 @@ int vr_colsum(const void* in, float* out, int32_t M, int32_t N, int32_t ld, int3
 int vr_scale_mask_cast(const float* in, void* out, const float* scale, const int32_t* keep, int32_t M, int32_t C,
                        int32_t rows_per_sample, int32_t out_dtype, vr_stream_t stream);
 
-/* out[r, c] = sum_b in[b, r, c]   (pos_embed / tokens gradients: sum over the batch). fp32. */
+/* out[r, c] += sum_b in[b, r, c]   (pos_embed / tokens gradients: sum over the batch; fp32 atomics -- the caller
+ * zero-initialises out, as the gradient arena is). */
 int vr_batchsum(const float* in, float* out, int32_t B, int64_t inner, vr_stream_t stream);
 
 /*

@@ -185,7 +185,7 @@ def scale_mask_cast(x, scale, keep, rows_per_sample, out_dtype):
 
 
 def batchsum(x, out):
-    out.copy_(x.sum(0).view(out.shape))
+    out.add_(x.sum(0).view(out.shape))
     return out
 
 

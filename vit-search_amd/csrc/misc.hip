@@ -113,31 +113,63 @@ __global__ __launch_bounds__(256) void scale_mask_cast_kernel(const float* __res
     }
 }
 
+// out[i] += sum_b in[b, i]: the batch is split over blockIdx.y (the inner extent alone is only ~N*C/256 = 257 workgroups),
+// 8 loads in flight per thread, partial sums combined with fp32 atomics (out is zero-initialised by the caller)
 __global__ __launch_bounds__(256) void batchsum_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
-                                                       long long inner) {
+                                                       long long inner, int bper) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= inner) return;
+    const int b0 = blockIdx.y * bper, b1 = min(B, b0 + bper);
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += in[(long long)b * inner + i];
-    out[i] = s;
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = in[(long long)(b + u) * inner + i];
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; b < b1; ++b) s += in[(long long)b * inner + i];
+    atomicAdd(out + i, s);
 }
 
 // ---- timm PatchEmbed im2col: col[(b,py,px)][(c,i,j)] = img[b,c,py*P+i,px*P+j] ---------------------------
+// One workgroup per band of patches (b, py): the band's Cin x P image rows are read once, fully coalesced, into LDS and
+// written out as whole patch rows (ldk contiguous elements each) -- a patch row is only P contiguous floats in the image,
+// so a gather per patch ran at 0.9 TB/s.
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img, T* __restrict__ col, int B,
                                                            int Cin, int H, int W, int P, int ldk) {
+    extern __shared__ __attribute__((aligned(16))) float band[];      // [Cin][P][W]
     const int gw = W / P, gh = H / P;
-    const int row = blockIdx.x;  // (b, py, px)
-    const int px = row % gw, py = (row / gw) % gh, b = row / (gw * gh);
+    const int py = blockIdx.x % gh, b = blockIdx.x / gh;
+    const int rows = Cin * P;
+    const bool v4 = (W % 4) == 0;
+    if (v4) {
+        const int w4 = W / 4;
+        for (int idx = threadIdx.x; idx < rows * w4; idx += blockDim.x) {
+            const int r = idx / w4, x4 = idx % w4;
+            const int c = r / P, i = r % P;
+            *reinterpret_cast<float4*>(band + r * W + 4 * x4) =
+                *reinterpret_cast<const float4*>(img + (((long long)b * Cin + c) * H + py * P + i) * W + 4 * x4);
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < rows * W; idx += blockDim.x) {
+            const int r = idx / W, x = idx % W;
+            const int c = r / P, i = r % P;
+            band[idx] = img[(((long long)b * Cin + c) * H + py * P + i) * W + x];
+        }
+    }
+    __syncthreads();
     const int K = Cin * P * P;
-    T* out = col + (long long)row * ldk;
-    for (int k = threadIdx.x; k < ldk; k += blockDim.x) {
+    T* out = col + ((long long)b * gh + py) * gw * ldk;
+    for (int idx = threadIdx.x; idx < gw * ldk; idx += blockDim.x) {
+        const int px = idx / ldk, k = idx % ldk;
         float v = 0.f;
         if (k < K) {
             const int j = k % P, i = (k / P) % P, c = k / (P * P);
-            v = img[(((long long)b * Cin + c) * H + py * P + i) * W + px * P + j];
+            v = band[(c * P + i) * W + px * P + j];
         }
-        Elem<T>::st(out + k, v);
+        Elem<T>::st(out + idx, v);
     }
 }
 
@@ -197,6 +229,62 @@ __global__ __launch_bounds__(256) void sr_col2im_kernel(const T* __restrict__ dc
             }
         }
         Elem<T>::st(dst + c, s);
+    }
+}
+
+// bf16, C % 8 == 0: one 16-byte chunk (8 channels) per thread -- the element-per-thread kernels above launch one 512-byte
+// workgroup per (pixel, tap) and were launch-rate bound (0.8 TB/s)
+__global__ __launch_bounds__(256) void sr_im2col_v8_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ col, int B, int g,
+                                                           int C, long long total) {
+    const int go = g / 2, c8n = C / 8;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c8 = (int)(idx % c8n);
+        const long long rt = idx / c8n;
+        const int tap = (int)(rt % 9);
+        const long long row = rt / 9;
+        const int ow = (int)(row % go), oh = (int)((row / go) % go), b = (int)(row / (go * go));
+        const int ih = 2 * oh - 1 + tap / 3, iw = 2 * ow - 1 + tap % 3;
+        const bool in = ih >= 0 && ih < g && iw >= 0 && iw < g;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (in) v = *reinterpret_cast<const uint4*>(y + ((long long)b * (1 + g * g) + 1 + ih * g + iw) * C + c8 * 8);
+        *reinterpret_cast<uint4*>(col + row * 9 * C + (long long)tap * C + c8 * 8) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void sr_col2im_v8_kernel(const bf16_t* __restrict__ dcol, bf16_t* __restrict__ dy, int B, int g,
+                                                           int C, long long total) {
+    const int go = g / 2, c8n = C / 8;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c8 = (int)(idx % c8n);
+        const long long pix = idx / c8n;
+        const int iw = (int)(pix % g), ih = (int)((pix / g) % g), b = (int)(pix / (g * g));
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = ih + 1 - kh;
+            const int oh = t >> 1;
+            const bool hok = t >= 0 && !(t & 1) && oh < go;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int u = iw + 1 - kw;
+                const int ow = u >> 1;
+                const bool ok = hok && u >= 0 && !(u & 1) && ow < go;
+                if (ok) {       // wave-divergent by pixel parity only; at most 4 of the 9 taps hit
+                    const uint4 v = *reinterpret_cast<const uint4*>(dcol + ((long long)(b * go + oh) * go + ow) * 9 * C +
+                                                                    (kh * 3 + kw) * C + c8 * 8);
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        s[2 * q] += __uint_as_float(w[q] << 16);
+                        s[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u);
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(dy + ((long long)b * (1 + g * g) + 1 + ih * g + iw) * C + c8 * 8) =
+            make_uint4(pack_bf2(s[0], s[1]), pack_bf2(s[2], s[3]), pack_bf2(s[4], s[5]), pack_bf2(s[6], s[7]));
     }
 }
 
@@ -309,8 +397,9 @@ extern "C" int vr_scale_mask_cast(const float* in, void* out, const float* scale
 
 extern "C" int vr_batchsum(const float* in, float* out, int32_t B, int64_t inner, vr_stream_t stream) {
     if (!in || !out || B <= 0 || inner <= 0) return VR_EINVAL;
-    hipLaunchKernelGGL(batchsum_kernel, dim3((unsigned)((inner + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, B,
-                       (long long)inner);
+    const int bper = B >= 64 ? 16 : (B >= 16 ? 8 : B);
+    hipLaunchKernelGGL(batchsum_kernel, dim3((unsigned)((inner + 255) / 256), (unsigned)((B + bper - 1) / bper)), dim3(256), 0,
+                       (hipStream_t)stream, in, out, B, (long long)inner, bper);
     VR_CHECK_LAUNCH();
     return VR_OK;
 }
@@ -318,11 +407,13 @@ extern "C" int vr_batchsum(const float* in, float* out, int32_t B, int64_t inner
 extern "C" int vr_im2col_patch(const float* img, void* col, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t P,
                                int32_t ldk, int32_t dtype, vr_stream_t stream) {
     if (!img || !col || B <= 0 || P <= 0 || H % P || W % P || ldk < Cin * P * P) return VR_EINVAL;
-    dim3 grid(B * (H / P) * (W / P));
+    dim3 grid(B * (H / P));
+    const size_t lds = (size_t)Cin * P * W * sizeof(float);
+    if (lds > 64 * 1024) return VR_EUNSUPPORTED;
     if (dtype == VR_F32)
-        hipLaunchKernelGGL((im2col_patch_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, img, (float*)col, B, Cin, H, W, P, ldk);
+        hipLaunchKernelGGL((im2col_patch_kernel<float>), grid, dim3(256), lds, (hipStream_t)stream, img, (float*)col, B, Cin, H, W, P, ldk);
     else if (dtype == VR_BF16)
-        hipLaunchKernelGGL((im2col_patch_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)col, B, Cin, H, W, P, ldk);
+        hipLaunchKernelGGL((im2col_patch_kernel<bf16_t>), grid, dim3(256), lds, (hipStream_t)stream, img, (bf16_t*)col, B, Cin, H, W, P, ldk);
     else
         return VR_EUNSUPPORTED;
     VR_CHECK_LAUNCH();
@@ -347,7 +438,12 @@ extern "C" int vr_mask_rows(float* x, const int32_t* keep, int32_t M, int32_t C,
 extern "C" int vr_sr_im2col(const void* y, void* col, int32_t B, int32_t g, int32_t C, int32_t dtype, vr_stream_t stream) {
     if (!y || !col || B <= 0 || g <= 0 || (g & 1)) return VR_EINVAL;
     dim3 grid(B * (g / 2) * (g / 2), 9);
-    if (dtype == VR_F32)
+    if (dtype == VR_BF16 && C % 8 == 0 && !((uintptr_t)y & 15) && !((uintptr_t)col & 15)) {
+        const long long total = (long long)B * (g / 2) * (g / 2) * 9 * (C / 8);
+        const long long blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(sr_im2col_v8_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)y, (bf16_t*)col, B, g, C, total);
+    } else if (dtype == VR_F32)
         hipLaunchKernelGGL((sr_im2col_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, (float*)col, B, g, C);
     else if (dtype == VR_BF16)
         hipLaunchKernelGGL((sr_im2col_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (bf16_t*)col, B, g, C);
@@ -360,7 +456,12 @@ extern "C" int vr_sr_im2col(const void* y, void* col, int32_t B, int32_t g, int3
 extern "C" int vr_sr_col2im(const void* dcol, void* dy, int32_t B, int32_t g, int32_t C, int32_t dtype, vr_stream_t stream) {
     if (!dcol || !dy || B <= 0 || g <= 0 || (g & 1)) return VR_EINVAL;
     dim3 grid(B * g * g);
-    if (dtype == VR_F32)
+    if (dtype == VR_BF16 && C % 8 == 0 && !((uintptr_t)dcol & 15) && !((uintptr_t)dy & 15)) {
+        const long long total = (long long)B * g * g * (C / 8);
+        const long long blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(sr_col2im_v8_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dcol, (bf16_t*)dy, B, g, C, total);
+    } else if (dtype == VR_F32)
         hipLaunchKernelGGL((sr_col2im_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dcol, (float*)dy, B, g, C);
     else if (dtype == VR_BF16)
         hipLaunchKernelGGL((sr_col2im_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dcol, (bf16_t*)dy, B, g, C);

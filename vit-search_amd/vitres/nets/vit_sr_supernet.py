@@ -528,12 +528,6 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 Fn.join_side()             # a previous forward's side work (if its backward never ran)
             if not a.get("shadow_ok"):                 # vitres.optim.FlatAdamW writes the shadow with every update
                 K.cast_bf16(a["flat"], a["shadow"])
-            if a["tr"] is not None and save:
-                # only the backward needs W^T: refresh it beside the forward (joined at the start of _run_backward)
-                if Fn.OVERLAP and a["flat"].is_cuda:
-                    Fn.on_side(lambda: K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"]))
-                else:
-                    K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"])
         B = x.shape[0]
         tape = [] if save else None
         ecfg = {"dtype": self.compute_dtype, "patch": self.patch_size, "patches": self.patch_embed.num_patches,
@@ -547,6 +541,13 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             h, sv = stem.embed_conv_fwd(self, x, ep, ecfg, ekeep, save)
         if save:
             tape.append(("embed", ep, ecfg, sv))
+        if self.compute_dtype == torch.bfloat16 and a["tr"] is not None and save:
+            # only the backward needs W^T: refresh it beside the forward, after the HBM-bound patch gather (joined at the
+            # start of _run_backward)
+            if Fn.OVERLAP and a["flat"].is_cuda:
+                Fn.on_side(lambda: K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"]))
+            else:
+                K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"])
         grid = self.img_size // self.patch_size
         for blk, L in zip(self.blocks, plan.layers[1:]):
             if L is None:
@@ -683,7 +684,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 _, blk, p, cfg, (ek, nk), sv = entry
                 co, ci = blk.patch_reduce.weight.shape[0], blk.patch_reduce.weight.shape[1]
                 wtmp = torch.zeros((co, 9 * ci), dtype=torch.float32, device=dev)
-                ptmp = torch.empty((1 + blk.num_patches, co), dtype=torch.float32, device=dev)
+                ptmp = torch.zeros((1 + blk.num_patches, co), dtype=torch.float32, device=dev)
                 def finish(blk=blk, wtmp=wtmp, ptmp=ptmp, co=co, ci=ci):     # runs on the stream of the weight gradients
                     gv(blk.patch_reduce.weight).copy_(wtmp.view(co, 3, 3, ci).permute(0, 3, 1, 2))
                     gv(blk.pos_embed).copy_(ptmp[1:].unsqueeze(0))
