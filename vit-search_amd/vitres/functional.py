@@ -34,6 +34,7 @@ OVERLAP = _os.environ.get('VITRES_OVERLAP', '1') != '0'
 DEFER_JOIN = _os.environ.get('VITRES_OVERLAP', '1') == '2'
 JOIN_PER_BLOCK = _os.environ.get('VITRES_OVERLAP', '1') == '3'
 FUSE_CAST = _os.environ.get('VITRES_FUSE_CAST', '1') != '0'      # LayerNorm backward also emits the next branch's gradient
+PROJ_LATE = _os.environ.get('VITRES_PROJ_LATE', '0') != '0'      # issue proj's weight gradient after the attention core
 STEM_SIDE = _os.environ.get('VITRES_STEM_SIDE', '0') != '0'      # conv-stem weight gradients on the side stream: measured slower
 _side_streams = {}
 
@@ -134,13 +135,15 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     def wgrad_proj():
         linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"], keep_rows=out_keep, keep_cols=attn_keep,
                      tokens_per_sample=N, sched=sch)
-    if ov:
+    if ov and not PROJ_LATE:
         on_side(wgrad_proj, gt)
-    else:
+    elif not ov:
         wgrad_proj()
     d_o = torch.empty((B, N, HD), dtype=dt, device=x.device)
     linear_dgrad(gt, p["proj"], d_o, M, HD, C, C, HD, keep_n=attn_keep, rows_in=N, keep_k=out_keep, sched=sch)
     dqkv = K.attn_bwd(qkv, o, d_o, lse, attn_keep, B, N, H, D, cfg["scale"])
+    if ov and PROJ_LATE:
+        on_side(wgrad_proj, gt)
 
     def wgrad_qkv():
         linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C, db=grads["qkv.b"], keep_rows=attn_keep,
