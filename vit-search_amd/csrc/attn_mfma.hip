@@ -2,19 +2,22 @@
 // 224 px; any N <= 288) and head dims 32 / 48 / 64 (reference nets/supernet_blocks.py:105-109 and its autograd).
 //
 // One workgroup per (sample, head): the whole head lives in LDS, no online softmax is needed.
-//   forward   : LDS = K (chunk-major) + V^T; each wave owns 16-query tiles.
+//   forward   : LDS = K, V (chunk-major); each wave owns 16-query tiles.
 //               S^T = K Q^T  (v_mfma_f32_16x16x32_bf16, A = K rows from LDS, B = Q rows from global)
 //               softmax over keys = registers + two cross-lane shuffles (xor 16, 32)
-//               O = P V      (A = P straight from the S^T accumulators, B = V^T from LDS)
-//   backward A: dQ     (LDS = K, V chunk-major + K^T)      per 16-query tile, same dataflow as the forward
-//   backward B: dK, dV (LDS = Q, dO chunk-major + Q^T, dO^T) per 16-key tile
+//               O^T = V^T P^T (A = V^T by transposing reads, B = P straight from the S^T accumulators)
+//   backward A: dQ     (LDS = K, V chunk-major)            per 16-query tile, same dataflow as the forward
+//   backward B: dK, dV (LDS = Q, dO chunk-major)           per 16-key tile
 // Why S^T: the C/D layout of the 16x16 MFMA gives each lane 4 consecutive ROWS of one column; with rows = keys the
 // accumulators of two key tiles are exactly an A-operand (i = query, k = 8 key slots) of the next MFMA -- P never
 // leaves registers.  Any consistent assignment of contraction slots to keys is valid as long as the B operand uses
 // the same one: slot (g, e) of key-pair tile kp is key 32*kp + 16*(e/4) + 4*g + e%4.
 // LDS layouts (both conflict free for their read instruction):
-//   chunk-major  [D/8][Np][8 bf16]   : ds_read_b128 fragment (row = lane%16, chunk = 4*dk + lane/16)
-//   transposed   [Np/4][D][4 bf16]   : ds_read_b64 pairs, d XOR-swizzled by 16 on odd key quads (D != 48)
+//   chunk-major  [D/8][Np+8][8 bf16] : ds_read_b128 fragment (row = lane%16, chunk = 4*dk + lane/16); the SAME image
+//   serves the contraction-over-rows operands (V in P V, K in dS K, Q / dO in the dK / dV products) through the gfx950
+//   transposing read ds_read_b64_tr_b16: a 16-lane group fetches a [4 rows][16 d] block, lane i supplying the address
+//   of row i/4, d 4(i%4)..+3 (8 contiguous bytes inside a chunk).  The chunk stride (Np + 8 rows) is an odd multiple
+//   of 128 B, so the two chunks a 32-lane half touches fall on different halves of the 256-B bank row.
 #include "common.h"
 #include "../../include/vitres_hip.h"
 
@@ -40,6 +43,7 @@ __device__ __forceinline__ f32x4 mfma16(bfv8 a, bfv8 b, f32x4 c) {
 // workgroup that owns a CU alone (100+ KB of LDS) has nothing else to hide them behind.
 template <int D, int MAXNP, int NTHR>
 __device__ __forceinline__ void stage_chunked(char* dst, const bf16_t* __restrict__ src, int rs, int N, int Np, int tid) {
+    const int NpS = Np + 8;                    // row stride of a chunk plane (see header)
     constexpr int NCH = AC<D>::NCH;
     constexpr int IT = (MAXNP * NCH + NTHR - 1) / NTHR;
     uint4 v[IT];
@@ -55,43 +59,7 @@ __device__ __forceinline__ void stage_chunked(char* dst, const bf16_t* __restric
     for (int it = 0; it < IT; ++it) {
         const int idx = tid + it * NTHR;
         const int n = idx % Np, ch = idx / Np;
-        if (ch < NCH) *reinterpret_cast<uint4*>(dst + ((size_t)ch * Np + n) * 16) = v[it];
-    }
-}
-
-template <int D> __device__ __forceinline__ int tr_off(int kq, int d) {
-    const int dp = AC<D>::SWZ ? (d ^ ((kq & 1) << 4)) : d;
-    return kq * (D * 8) + dp * 8;
-}
-
-// rows [N][D] -> transposed LDS [Np/4][D][4]; thread handles 4 rows x 2 adjacent d (unrolled like stage_chunked)
-template <int D, int MAXNP, int NTHR>
-__device__ __forceinline__ void stage_transposed(char* dst, const bf16_t* __restrict__ src, int rs, int N, int Np, int tid) {
-    constexpr int HP = D / 2;
-    constexpr int IT = ((MAXNP / 4) * HP + NTHR - 1) / NTHR;
-    uint32_t w[IT][4];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int idx = tid + it * NTHR;
-        const int dp = idx % HP, kq = idx / HP;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int n = kq * 4 + e;
-            const bool ok = n < N;
-            const uint32_t x = *reinterpret_cast<const uint32_t*>(src + (long long)(ok ? n : 0) * rs + dp * 2);
-            w[it][e] = ok ? x : 0u;
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int idx = tid + it * NTHR;
-        const int dp = idx % HP, kq = idx / HP;
-        if (kq < Np / 4) {
-            const uint2 lo = make_uint2((w[it][0] & 0xffffu) | (w[it][1] << 16), (w[it][2] & 0xffffu) | (w[it][3] << 16));
-            const uint2 hi = make_uint2((w[it][0] >> 16) | (w[it][1] & 0xffff0000u), (w[it][2] >> 16) | (w[it][3] & 0xffff0000u));
-            *reinterpret_cast<uint2*>(dst + tr_off<D>(kq, dp * 2)) = lo;
-            *reinterpret_cast<uint2*>(dst + tr_off<D>(kq, dp * 2 + 1)) = hi;
-        }
+        if (ch < NCH) *reinterpret_cast<uint4*>(dst + ((size_t)ch * NpS + n) * 16) = v[it];
     }
 }
 
@@ -109,15 +77,22 @@ template <int D>
 __device__ __forceinline__ bfv8 cfrag(const char* base, int Np, int n0, int dk, int lane) {
     int ch = dk * 4 + (lane >> 4);
     ch = ch < AC<D>::NCH ? ch : AC<D>::NCH - 1;      // partner operand is zero there (D = 48)
-    return *reinterpret_cast<const bfv8*>(base + ((size_t)ch * Np + n0 + (lane & 15)) * 16);
+    return *reinterpret_cast<const bfv8*>(base + ((size_t)ch * (Np + 8) + n0 + (lane & 15)) * 16);
 }
-// contraction slots of pair tile kp for column d = dt*16 + lane%16
+// contraction slots of pair tile kp (rows 32 kp + 16 (e/4) + 4 g + e%4) for column d = dt*16 + lane%16, read from the
+// chunk-major image with two transposing reads (rows +0..3 and +16..19)
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
 template <int D>
-__device__ __forceinline__ bfv8 tfrag(const char* base, int kp, int dt, int lane) {
-    const int g = lane >> 4, d = dt * 16 + (lane & 15);
-    const uint2 a = *reinterpret_cast<const uint2*>(base + tr_off<D>(kp * 8 + g, d));
-    const uint2 b = *reinterpret_cast<const uint2*>(base + tr_off<D>(kp * 8 + 4 + g, d));
-    return __builtin_bit_cast(bfv8, make_uint4(a.x, a.y, b.x, b.y));
+__device__ __forceinline__ bfv8 tfrag(const char* base, int Np, int kp, int dt, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int row = 32 * kp + 4 * g + (i >> 2), d0 = dt * 16 + 4 * (i & 3);
+    const char* p = base + ((size_t)(d0 >> 3) * (Np + 8) + row) * 16 + (d0 & 7) * 2;
+    typedef __attribute__((address_space(3))) s4v lds_s4v;
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(p));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(p + 16 * 16));
+    const s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bfv8, v);
 }
 __device__ __forceinline__ bfv8 pack8(const f32x4& a, const f32x4& b) {
     return __builtin_bit_cast(bfv8, make_uint4(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]),
@@ -156,9 +131,9 @@ __global__ __launch_bounds__(NW * 64) void fwd_kernel(const bf16_t* __restrict__
     }
     const int Np = (N + 31) / 32 * 32, nkt = Np / 16, nkp = Np / 32;
     char* Kc = sm;
-    char* Vt = sm + (size_t)D * Np * 2;
+    char* Vc = sm + (size_t)D * (Np + 8) * 2;
     stage_chunked<D, 32 * NKP, NW * 64>(Kc, base + HD, RS, N, Np, tid);
-    stage_transposed<D, 32 * NKP, NW * 64>(Vt, base + 2 * HD, RS, N, Np, tid);
+    stage_chunked<D, 32 * NKP, NW * 64>(Vc, base + 2 * HD, RS, N, Np, tid);
     __syncthreads();
     for (int q0 = wave * 16; q0 < N; q0 += NW * 16) {
         bfv8 qf[AC<D>::DK];
@@ -200,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void fwd_kernel(const bf16_t* __restrict__
             if (kp < nkp) {
                 const bfv8 pf = pack8(st[2 * kp], st[2 * kp + 1]);
 #pragma unroll
-                for (int dt = 0; dt < AC<D>::DT; ++dt) oacc[dt] = mfma16(tfrag<D>(Vt, kp, dt, lane), pf, oacc[dt]);
+                for (int dt = 0; dt < AC<D>::DT; ++dt) oacc[dt] = mfma16(tfrag<D>(Vc, Np, kp, dt, lane), pf, oacc[dt]);
             }
         }
         // O^T tiles (V^T as the first operand): the lane owns query q0 + c and 4 consecutive d per tile -> 8-byte stores
@@ -243,11 +218,9 @@ __global__ __launch_bounds__(NW * 64) void bwd_dq_kernel(const bf16_t* __restric
     float* db = delta + ((long long)b * H + h) * N;
     const int Np = (N + 31) / 32 * 32, nkp = Np / 32;
     char* Kc = sm;
-    char* Vc = Kc + (size_t)D * Np * 2;
-    char* Kt = Vc + (size_t)D * Np * 2;
+    char* Vc = Kc + (size_t)D * (Np + 8) * 2;
     stage_chunked<D, 32 * NKP, NW * 64>(Kc, base + HD, RS, N, Np, tid);
     stage_chunked<D, 32 * NKP, NW * 64>(Vc, base + 2 * HD, RS, N, Np, tid);
-    stage_transposed<D, 32 * NKP, NW * 64>(Kt, base + HD, RS, N, Np, tid);
     __syncthreads();
     // QT query tiles per wave at once: every LDS fragment (K, V, K^T of a key tile) is read once and feeds QT MFMAs --
     // with one tile per wave the kernel was LDS-bandwidth bound (each wave re-read the whole head per 16 queries)
@@ -310,7 +283,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_dq_kernel(const bf16_t* __restric
                 for (int t = 0; t < QT; ++t) sf[t] = pack8(ds[t][0], ds[t][1]);       // dS never leaves registers
 #pragma unroll
                 for (int dt = 0; dt < AC<D>::DT; ++dt) {
-                    const bfv8 kt_f = tfrag<D>(Kt, kp, dt, lane);
+                    const bfv8 kt_f = tfrag<D>(Kc, Np, kp, dt, lane);
 #pragma unroll
                     for (int t = 0; t < QT; ++t) dq[t][dt] = mfma16(kt_f, sf[t], dq[t][dt]);
                 }
@@ -353,15 +326,11 @@ __global__ __launch_bounds__(NW * 64) void bwd_dkv_kernel(const bf16_t* __restri
     const bf16_t* gb = d_o + (long long)b * N * HD + h * D;
     const int Np = (N + 31) / 32 * 32, nqp = Np / 32;
     char* Qc = sm;
-    char* Gc = Qc + (size_t)D * Np * 2;
-    char* Qt = Gc + (size_t)D * Np * 2;
-    char* Gt = Qt + (size_t)D * Np * 2;
-    float* Ls = reinterpret_cast<float*>(Gt + (size_t)D * Np * 2);
+    char* Gc = Qc + (size_t)D * (Np + 8) * 2;
+    float* Ls = reinterpret_cast<float*>(Gc + (size_t)D * (Np + 8) * 2);
     float* Ds = Ls + Np;
     stage_chunked<D, 32 * NKP, NW * 64>(Qc, base, RS, N, Np, tid);
     stage_chunked<D, 32 * NKP, NW * 64>(Gc, gb, HD, N, Np, tid);
-    stage_transposed<D, 32 * NKP, NW * 64>(Qt, base, RS, N, Np, tid);
-    stage_transposed<D, 32 * NKP, NW * 64>(Gt, gb, HD, N, Np, tid);
     for (int n = tid; n < Np; n += NW * 64) {
         Ls[n] = n < N ? lse[((long long)b * H + h) * N + n] : 0.f;
         Ds[n] = n < N ? delta[((long long)b * H + h) * N + n] : 0.f;
@@ -423,7 +392,7 @@ __global__ __launch_bounds__(NW * 64) void bwd_dkv_kernel(const bf16_t* __restri
             }
 #pragma unroll
             for (int dt = 0; dt < AC<D>::DT; ++dt) {
-                const bfv8 gt_f = tfrag<D>(Gt, qp, dt, lane), qt_f = tfrag<D>(Qt, qp, dt, lane);
+                const bfv8 gt_f = tfrag<D>(Gc, Np, qp, dt, lane), qt_f = tfrag<D>(Qc, Np, qp, dt, lane);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     dva[t][dt] = mfma16(gt_f, pf[t], dva[t][dt]);
@@ -467,7 +436,7 @@ static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, const int* keep,
                       hipStream_t st) {
     constexpr int NW = NKP >= 9 ? 8 : (NKP >= 3 ? 4 : 2);      // waves per (batch, head): one 16-query tile each per pass (measured)
     const int Np = (N + 31) / 32 * 32;
-    const size_t lds = (size_t)2 * D * Np * 2;
+    const size_t lds = (size_t)2 * D * (Np + 8) * 2;
     int rc = set_lds(fwd_kernel<D, NKP, NW>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((fwd_kernel<D, NKP, NW>), dim3(B * H), dim3(NW * 64), lds, st, qkv, o, lse, keep, B, N, H, scale);
@@ -479,7 +448,7 @@ static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, con
     constexpr int NW = NKP >= 3 ? 8 : 2;
     constexpr int QT = NKP >= 9 ? 3 : 1;      // query / key tiles per wave: 17 tiles of N = 257 = one pass of 6 waves
     const int Np = (N + 31) / 32 * 32;
-    const size_t l1 = (size_t)3 * D * Np * 2, l2 = (size_t)4 * D * Np * 2 + 2 * Np * sizeof(float);
+    const size_t l1 = (size_t)2 * D * (Np + 8) * 2, l2 = (size_t)2 * D * (Np + 8) * 2 + 2 * Np * sizeof(float);
     int rc = set_lds(bwd_dq_kernel<D, NKP, NW, QT>, l1);
     if (rc) return rc;
     rc = set_lds(bwd_dkv_kernel<D, NKP, NW, QT>, l2);
