@@ -187,6 +187,15 @@ int vr_colsum(const void* in, float* out, int32_t M, int32_t N, int32_t ld, int3
 int vr_scale_mask_cast(const float* in, void* out, const float* scale, const int32_t* keep, int32_t M, int32_t C,
                        int32_t rows_per_sample, int32_t out_dtype, vr_stream_t stream);
 
+/*
+ * patch_output_type == 'avg' (nets/vit_sr_supernet.py:447-449: patch_features.mean(dim=1) before patch_head):
+ * out[b, c] = mean over tokens n in [first, N) of y[b, n, c]; backward writes dy[b, n, c] = dmean[b, c] / (N - first) for those
+ * tokens.  All tensors in `dtype`, fp32 accumulation.
+ */
+int vr_token_mean(const void* y, void* out, int32_t B, int32_t N, int32_t C, int32_t first, int32_t dtype, vr_stream_t stream);
+int vr_token_mean_bwd(const void* dmean, void* dy, int32_t B, int32_t N, int32_t C, int32_t first, int32_t dtype,
+                      vr_stream_t stream);
+
 /* out[r, c] += sum_b in[b, r, c]   (pos_embed / tokens gradients: sum over the batch; fp32 atomics -- the caller
  * zero-initialises out, as the gradient arena is). */
 int vr_batchsum(const float* in, float* out, int32_t B, int64_t inner, vr_stream_t stream);

@@ -184,6 +184,15 @@ def scale_mask_cast(x, scale, keep, rows_per_sample, out_dtype):
     return (X * mask).view(x.shape).to(out_dtype)
 
 
+def token_mean(y, first):
+    return y[:, first:].float().mean(1).to(y.dtype)
+
+
+def token_mean_bwd(dmean, dy, first):
+    dy[:, first:] = (dmean.float() / (dy.shape[1] - first)).to(dy.dtype)[:, None, :]
+    return dy
+
+
 def batchsum(x, out):
     out.add_(x.sum(0).view(out.shape))
     return out
@@ -303,7 +312,7 @@ def patch_fold(col, B, gh, gw, P, C):
 
 
 ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "attn_fwd", "attn_bwd", "softce", "colsum", "scale_mask_cast",
-       "batchsum", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
+       "batchsum", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
 
 
 def install(monkeypatch):

@@ -430,9 +430,43 @@ def f8_engine():
     save("f8_engine_eval", loss=stats["loss"], acc1=stats["acc1"], acc5=stats["acc5"], state_crc=recipe.checksum(sd))
 
 
+# ------------------------------------------------------------------------------------------------
+# F9: patch_output_type='avg' (vit_sr_supernet.py:447-449): patch head on the mean of the patch tokens
+# ------------------------------------------------------------------------------------------------
+def f9_patch_avg():
+    B = 8
+    out = {}
+    for mode in ("plain", "multi"):
+        torch.manual_seed(1234)
+        kw = {}
+        if mode != "plain":
+            kw = dict(num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30)
+        m = build_ref(recipe.MICRO_DEFS[0], supernet=(mode != "plain"), **kw)
+        sd, shapes = load_recipe(m, seed=100)
+        x, t, pt, labels = recipe.inputs(7, B, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+        m.train()
+        if mode != "plain":
+            m.set_epoch(31)
+            m.load_state_dict(sd)
+        m.zero_grad()
+        torch.manual_seed(586)
+        with KeepRecorder() as rec:
+            cls, pat = m(x.clone(), patch_output_type="avg")
+        loss = soft_ce(cls, t) + soft_ce(pat, t)                   # engine.py:158-159: 'avg' is trained against `targets`
+        loss.backward()
+        out[mode + ".cls"], out[mode + ".pat"], out[mode + ".loss"] = cls.detach().numpy(), pat.detach().numpy(), loss.item()
+        if rec.log:
+            out[mode + ".keeps"] = torch.stack(rec.log).numpy()
+        names = ["norm.weight", "norm.bias", "cls_head.weight", "patch_head.weight", "patch_head.bias",
+                 "blocks.6.mlp.fc2.weight", "blocks.0.attn.qkv.weight", "pos_embed"]
+        for k, v in grads_of(m, names).items():
+            out[mode + "." + k] = v
+    save("f9_patch_avg", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9"]
     table = dict(f1=f1_micro, f2=f2_masked_ln, f3=f3_channel_drop, f4=f4_fullsize, f5=f5_subnet,
-                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine)
+                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg)
     for w in which:
         table[w]()

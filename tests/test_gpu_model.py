@@ -207,6 +207,30 @@ def test_hipgraph_replay_matches_eager():
             assert rel(p.grad, grads_e[n]) < 1e-4, n
 
 
+@pytest.mark.parametrize("mode", ["plain", "multi"])
+def test_patch_output_avg_matches_reference(mode):
+    """patch_output_type='avg' through the HIP path (vr_token_mean + GEMM) vs the reference's golden vectors (fixture F9)."""
+    g = np.load(os.path.join(G, "f9_patch_avg.npz"))
+    prod, orc, sd = build_pair(0, mode, 100)
+    prod.set_compute_dtype(torch.float32)
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1))
+    prod.train()
+    if mode != "plain":
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+    torch.manual_seed(586)
+    cls, pat = prod(x, patch_output_type="avg")
+    ce = lambda a, b: torch.sum(-b * torch.log_softmax(a, -1), -1).mean()      # noqa: E731
+    (ce(cls, t) + ce(pat, t)).backward()
+    assert rel(cls, g[mode + ".cls"]) < 1e-4 and rel(pat, g[mode + ".pat"]) < 1e-4
+    if mode != "plain":
+        assert np.array_equal(torch.stack(prod.last_keeps).cpu().numpy(), g[mode + ".keeps"])
+    p = dict(prod.named_parameters())
+    for k in g.files:
+        if k.startswith(mode + ".grad."):
+            assert rel(p[k[len(mode) + 6:]].grad, g[k]) < 5e-4, k
+
+
 @pytest.mark.gpu
 def test_split_hipgraphs_match_eager():
     """GraphedTrainStep(split_for_sync=True): the backward captured as two graphs (cut after the last stage, so that the

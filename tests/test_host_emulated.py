@@ -134,6 +134,28 @@ def test_emulated_split_backward_equals_monolithic(monkeypatch):
     assert not torch.equal(part1[:start], mono[:start])      # ... the rest is not
 
 
+@pytest.mark.parametrize("mode", ["plain", "multi"])
+def test_emulated_patch_output_avg(monkeypatch, mode):
+    emu_kernels.install(monkeypatch)
+    g = np.load(os.path.join(G, "f9_patch_avg.npz"))
+    prod, orc, sd = build_pair(0, mode, 100)
+    prod.set_compute_dtype(torch.float32)
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    prod.train()
+    if mode != "plain":
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+    torch.manual_seed(586)
+    cls, pat = prod(x, patch_output_type="avg")
+    (O.soft_target_ce(cls, t) + O.soft_target_ce(pat, t)).backward()
+    assert rel(cls.detach(), torch.from_numpy(g[mode + ".cls"])) < 5e-5
+    assert rel(pat.detach(), torch.from_numpy(g[mode + ".pat"])) < 5e-5
+    p = dict(prod.named_parameters())
+    for k in g.files:
+        if k.startswith(mode + ".grad."):
+            assert rel(p[k[len(mode) + 6:]].grad, torch.from_numpy(g[k])) < 2e-4, k
+
+
 def test_cpu_tensor_is_refused():
     prod, _, _ = build_pair(0, "plain", 100)
     with pytest.raises(RuntimeError):

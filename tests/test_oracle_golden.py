@@ -262,3 +262,30 @@ def test_f4_fullsize_ref_tiny_c1():
     m.eval()
     with torch.no_grad():
         close(m(x), g["eval.cls"], tol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["plain", "multi"])
+def test_f9_patch_output_avg(mode):
+    """patch_output_type='avg' (vit_sr_supernet.py:447-449): patch head on the mean patch token, trained against `targets`."""
+    g = load("f9_patch_avg")
+    m = build(recipe.MICRO_DEFS[0], mode)
+    sd, _ = load_recipe(m, 100)
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    m.train()
+    if mode != "plain":
+        m.set_epoch(31)
+        m.load_state_dict(sd)
+    torch.manual_seed(586)
+    (cls, pat), keeps = m(x, patch_output_type="avg", return_keeps=True)
+    loss = O.soft_target_ce(cls, t) + O.soft_target_ce(pat, t)
+    loss.backward()
+    assert pat.shape == (8, recipe.MICRO_CLASSES)
+    close(cls.detach(), g[mode + ".cls"])
+    close(pat.detach(), g[mode + ".pat"])
+    close(loss.item(), g[mode + ".loss"])
+    if mode != "plain":
+        assert np.array_equal(torch.stack(keeps).numpy(), g[mode + ".keeps"])
+    p = dict(m.named_parameters())
+    for k in g.files:
+        if k.startswith(mode + ".grad."):
+            close(p[k[len(mode) + 6:]].grad, g[k], tol=1e-4)

@@ -132,6 +132,26 @@ __global__ __launch_bounds__(256) void batchsum_kernel(const float* __restrict__
     atomicAdd(out + i, s);
 }
 
+// ---- patch_output_type == 'avg' (vit_sr_supernet.py:447-449): mean over the patch tokens of a sample, and its backward ----
+template <typename T>
+__global__ __launch_bounds__(256) void token_mean_kernel(const T* __restrict__ y, T* __restrict__ out, int N, int C, int first) {
+    const int b = blockIdx.x;
+    const float inv = 1.0f / (float)(N - first);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int n = first; n < N; ++n) s += Elem<T>::ld(y + ((long long)b * N + n) * C + c);
+        Elem<T>::st(out + (long long)b * C + c, s * inv);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const T* __restrict__ dmean, T* __restrict__ dy, int N, int C,
+                                                             int first) {
+    const int n = first + blockIdx.x % (N - first), b = blockIdx.x / (N - first);
+    const float inv = 1.0f / (float)(N - first);
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+        Elem<T>::st(dy + ((long long)b * N + n) * C + c, Elem<T>::ld(dmean + (long long)b * C + c) * inv);
+}
+
 // ---- timm PatchEmbed im2col: col[(b,py,px)][(c,i,j)] = img[b,c,py*P+i,px*P+j] ---------------------------
 // One workgroup per band of patches (b, py): the band's Cin x P image rows are read once, fully coalesced, into LDS and
 // written out as whole patch rows (ldk contiguous elements each) -- a patch row is only P contiguous floats in the image,
@@ -389,6 +409,33 @@ extern "C" int vr_scale_mask_cast(const float* in, void* out, const float* scale
         hipLaunchKernelGGL((scale_mask_cast_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, in, (float*)out, scale, keep, M, C, rows_per_sample);
     else if (out_dtype == VR_BF16)
         hipLaunchKernelGGL((scale_mask_cast_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, scale, keep, M, C, rows_per_sample);
+    else
+        return VR_EUNSUPPORTED;
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_token_mean(const void* y, void* out, int32_t B, int32_t N, int32_t C, int32_t first, int32_t dtype,
+                             vr_stream_t stream) {
+    if (!y || !out || B <= 0 || C <= 0 || first < 0 || first >= N) return VR_EINVAL;
+    if (dtype == VR_F32)
+        hipLaunchKernelGGL((token_mean_kernel<float>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)y, (float*)out, N, C, first);
+    else if (dtype == VR_BF16)
+        hipLaunchKernelGGL((token_mean_kernel<bf16_t>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (bf16_t*)out, N, C, first);
+    else
+        return VR_EUNSUPPORTED;
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_token_mean_bwd(const void* dmean, void* dy, int32_t B, int32_t N, int32_t C, int32_t first, int32_t dtype,
+                                 vr_stream_t stream) {
+    if (!dmean || !dy || B <= 0 || C <= 0 || first < 0 || first >= N) return VR_EINVAL;
+    dim3 grid(B * (N - first));
+    if (dtype == VR_F32)
+        hipLaunchKernelGGL((token_mean_bwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dmean, (float*)dy, N, C, first);
+    else if (dtype == VR_BF16)
+        hipLaunchKernelGGL((token_mean_bwd_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dmean, (bf16_t*)dy, N, C, first);
     else
         return VR_EUNSUPPORTED;
     VR_CHECK_LAUNCH();

@@ -46,6 +46,8 @@ SYMBOLS = {
     "vr_softce": [c_void_p] * 4 + [c_int32, c_int32, c_float, c_void_p],
     "vr_colsum": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, RowMap, c_void_p],
     "vr_scale_mask_cast": [c_void_p] * 4 + [c_int32] * 4 + [c_void_p],
+    "vr_token_mean": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
+    "vr_token_mean_bwd": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "vr_batchsum": [c_void_p, c_void_p, c_int32, c_int64, c_void_p],
     "vr_im2col_patch": [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p],
     "vr_embed_cls": [c_void_p] * 4 + [c_int32] * 3 + [c_void_p],

@@ -312,17 +312,21 @@ def head_fwd(x, p, cfg, keep, with_patch, save):
     y, mean, rstd = K.ln_fwd(x, p["nw"], p["nb"], keep, N, cfg["eps"], dt)
     cls = torch.empty((B, nc), dtype=torch.float32, device=x.device)
     K.gemm(y, p["cls"].w_c, cls, M=B, N=nc, K=C, lda=C, ldb=p["cls"].ld, ldc=nc, bias=p["cls"].b, a_map=(1, N, 0))
-    pat = None
-    if with_patch:
+    pat, ym = None, None
+    if with_patch == 2:                 # patch_output_type='avg': patch head on the mean patch token (:447-449)
+        ym = K.token_mean(y, 1)
+        pat = torch.empty((B, nc), dtype=torch.float32, device=x.device)
+        K.gemm(ym, p["patch"].w_c, pat, M=B, N=nc, K=C, lda=C, ldb=p["patch"].ld, ldc=nc, bias=p["patch"].b)
+    elif with_patch:
         pat = torch.empty((B, N - 1, nc), dtype=torch.float32, device=x.device)
         K.gemm(y, p["patch"].w_c, pat, M=B * (N - 1), N=nc, K=C, lda=C, ldb=p["patch"].ld, ldc=nc, bias=p["patch"].b,
                a_map=(N - 1, N, 1))
-    saved = (x, mean, rstd, y) if save else None
+    saved = (x, mean, rstd, y, ym) if save else None
     return cls, pat, saved
 
 
 def head_bwd(dcls, dpat, saved, p, grads, cfg, keep, next_cast=None):
-    x, mean, rstd, y = saved
+    x, mean, rstd, y, ym = saved
     B, N, C = x.shape
     dt = cfg["dtype"]
     nc = cfg["classes"]
@@ -337,7 +341,13 @@ def head_bwd(dcls, dpat, saved, p, grads, cfg, keep, next_cast=None):
         gc = padded(dcls.reshape(B, nc))
         linear_wgrad(gc, y, grads["cls.w"], B, nc, C, ldp, C, b_map=(1, N, 0), db=grads["cls.b"])
         linear_dgrad(gc, p["cls"], dy, B, C, nc, ldp, C, c_map=(1, N, 0))
-    if dpat is not None:
+    if dpat is not None and ym is not None:                                  # 'avg'
+        gp = padded(dpat.reshape(B, nc))
+        linear_wgrad(gp, ym, grads["patch.w"], B, nc, C, ldp, C, db=grads["patch.b"])
+        dmean = torch.empty((B, C), dtype=dt, device=x.device)
+        linear_dgrad(gp, p["patch"], dmean, B, C, nc, ldp, C)
+        K.token_mean_bwd(dmean, dy, 1)
+    elif dpat is not None:
         R = B * (N - 1)
         gp = padded(dpat.reshape(R, nc))
         linear_wgrad(gp, y, grads["patch.w"], R, nc, C, ldp, C, b_map=(N - 1, N, 1), db=grads["patch.b"])

@@ -186,6 +186,20 @@ def scale_mask_cast(x, scale, keep, rows_per_sample, out_dtype):
     return out
 
 
+def token_mean(y, first):
+    """[B, N, C] -> [B, C]: mean over tokens first.. (patch_output_type='avg')."""
+    B, N, C = y.shape
+    out = torch.empty((B, C), dtype=y.dtype, device=y.device)
+    _lib.check(_lib.lib().vr_token_mean(_p(y), _p(out), B, N, C, first, _dt(y), _stream()), "vr_token_mean")
+    return out
+
+
+def token_mean_bwd(dmean, dy, first):
+    B, N, C = dy.shape
+    _lib.check(_lib.lib().vr_token_mean_bwd(_p(dmean), _p(dy), B, N, C, first, _dt(dy), _stream()), "vr_token_mean_bwd")
+    return dy
+
+
 def batchsum(x, out):
     B = x.shape[0]
     inner = x.numel() // B

@@ -460,13 +460,10 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         if _REQUIRE_CUDA and not x.is_cuda:
             raise RuntimeError('vitres runs on MI355X through libvitres_hip.so only; got a %s tensor '
                                '(the CPU restatement lives in oracle/ and is test infrastructure)' % x.device)
-        if patch_output_type not in (None, 'seq'):
-            if patch_output_type == 'avg':
-                raise NotImplementedError("patch_output_type='avg' is not implemented in the HIP path (the "
-                                          "reference's SwitchTokenMix always returns 'seq', token_mixup.py:150)")
+        if patch_output_type not in (None, 'seq', 'avg'):
             raise ValueError()
         self._ensure_arena(x.device)
-        with_patch = bool(self.patch_output and self.training)
+        with_patch = int(bool(self.patch_output and self.training)) * (2 if patch_output_type == 'avg' else 1)
         if plan is None:
             plan = self.sample_plan(x.shape[0])
         self._upload_plan(plan, x.device)
