@@ -188,6 +188,22 @@ int vr_scale_mask_cast(const float* in, void* out, const float* scale, const int
                        int32_t rows_per_sample, int32_t out_dtype, vr_stream_t stream);
 
 /*
+ * SwitchTokenMix (token_mixup.py:39-162), device half: the caller has drawn, with the reference's generators and order,
+ * partner[b] (global sample index each sample is mixed with: the two torch.randperm of :104 and :126 offset into their half),
+ * the patch box [y0,y1) x [x0,x1) in units of the patch_len x patch_len grid, lam_patch = 1 - box/grid, lam_img ~ Beta(.8,.8)
+ * (each lam and 1 - lam rounded to fp32 from the double, as torch does for `tensor * python_float`), and the smoothed
+ * one-hot values on/off (:22-23).  Rows [0, half): out = partner's pixels inside the box; targets = y*lam_p + y[partner]*(1-lam_p);
+ * patch_targets[b, (i,j)] = y[partner] inside the box, y outside.  Rows [half, B): out = x*lam_i + x[partner]*(1-lam_i);
+ * targets likewise; every patch target = the mixed target.  samples/out fp32 [B,C,H,W] (out != samples: the reference's
+ * in-place update reads a gathered COPY), labels int64 [B], targets fp32 [B,K], patch_targets fp32 [B, patch_len^2, K].
+ * Bit-exact with the reference (separately rounded products, then one add).
+ */
+int vr_token_mix(const float* samples, float* out, const int64_t* labels, const int64_t* partner, float* targets,
+                 float* patch_targets, int32_t B, int32_t C, int32_t H, int32_t W, int32_t num_classes, int32_t patch_len,
+                 int32_t half, int32_t y0, int32_t y1, int32_t x0, int32_t x1, float lam_patch, float oml_patch,
+                 float lam_img, float oml_img, float on_value, float off_value, vr_stream_t stream);
+
+/*
  * patch_output_type == 'avg' (nets/vit_sr_supernet.py:447-449: patch_features.mean(dim=1) before patch_head):
  * out[b, c] = mean over tokens n in [first, N) of y[b, n, c]; backward writes dy[b, n, c] = dmean[b, c] / (N - first) for those
  * tokens.  All tensors in `dtype`, fp32 accumulation.

@@ -464,9 +464,43 @@ def f9_patch_avg():
     save("f9_patch_avg", **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# F10: SwitchTokenMix (token_mixup.py:39-162): first half patch-level mix, second half image-level mixup
+# ------------------------------------------------------------------------------------------------
+def f10_token_mix():
+    import importlib.util
+    import numpy.random as npr
+    spec = importlib.util.spec_from_file_location("ref_token_mixup", os.path.join(ref_shim.REF, "token_mixup.py"))
+    tm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tm)
+    # the reference hard-codes device='cuda' in torch.full / torch.zeros: drop the kwarg while it runs on CPU
+    full, zeros = torch.full, torch.zeros
+    strip = lambda f: (lambda *a, **k: f(*a, **{kk: vv for kk, vv in k.items() if kk != "device"}))   # noqa: E731
+    out = {}
+    try:
+        torch.full, torch.zeros = strip(full), strip(zeros)
+        for case, (B, H, pl, nc, seed) in enumerate([(8, 56, 4, 10, 0), (8, 56, 4, 10, 1), (6, 32, 4, 7, 2), (16, 28, 2, 5, 3)]):
+            rs = np.random.RandomState(100 + case)
+            x = torch.from_numpy(rs.standard_normal((B, 3, H, H)).astype(np.float32))
+            y = torch.from_numpy(rs.randint(0, nc, size=(B,)).astype(np.int64))
+            torch.manual_seed(40 + seed)
+            npr.seed(50 + seed)
+            mix = tm.SwitchTokenMix(pl, switch_prob=0.5, num_classes=nc, smoothing=0.1)
+            xs, t, pt, pot = mix(x.clone(), y.clone())
+            tag = "c%d." % case
+            out[tag + "cfg"] = np.array([B, H, pl, nc, seed])
+            out[tag + "samples"], out[tag + "targets"], out[tag + "patch_targets"] = xs.numpy(), t.numpy(), pt.numpy()
+            assert pot == "seq"
+            out[tag + "np_after"] = npr.randint(0, 1 << 30)             # RNG streams advanced exactly as far
+            out[tag + "torch_after"] = torch.randint(0, 1 << 30, (1,)).numpy()
+    finally:
+        torch.full, torch.zeros = full, zeros
+    save("f10_token_mix", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10"]
     table = dict(f1=f1_micro, f2=f2_masked_ln, f3=f3_channel_drop, f4=f4_fullsize, f5=f5_subnet,
-                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg)
+                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix)
     for w in which:
         table[w]()

@@ -337,3 +337,40 @@ def test_flat_adamw_matches_torch_adamw(ema):
             assert rel(esd[n], ema_ref[n].cpu()) < 2e-5, n
     sd = opt.state_dict()
     assert sd["step"] == 3 and sd["exp_avg"].shape == a["flat"].shape
+
+
+def test_switch_token_mix_is_bit_exact_with_reference():
+    """vitres.token_mixup.SwitchTokenMix (vr_token_mix) reproduces the reference's mixed samples, targets and patch targets bit
+    for bit from the same torch / numpy seeds, and advances both RNG streams equally (fixture F10)."""
+    from vitres.token_mixup import SwitchTokenMix
+    g = np.load(os.path.join(G, "f10_token_mix.npz"))
+    for case in range(4):
+        tag = "c%d." % case
+        B, H, pl, nc, seed = (int(v) for v in g[tag + "cfg"])
+        rs = np.random.RandomState(100 + case)
+        x = torch.from_numpy(rs.standard_normal((B, 3, H, H)).astype(np.float32))
+        y = torch.from_numpy(rs.randint(0, nc, size=(B,)).astype(np.int64))
+        torch.manual_seed(40 + seed)
+        np.random.seed(50 + seed)
+        mix = SwitchTokenMix(pl, switch_prob=0.5, num_classes=nc, smoothing=0.1)
+        xin = x.to(DEV)
+        xs, t, pt, pot = mix(xin, y.to(DEV))
+        assert pot == "seq" and torch.equal(xin.cpu(), x)                      # input left untouched
+        assert np.array_equal(xs.cpu().numpy(), g[tag + "samples"])
+        assert np.array_equal(t.cpu().numpy(), g[tag + "targets"])
+        assert np.array_equal(pt.cpu().numpy(), g[tag + "patch_targets"])
+        assert np.random.randint(0, 1 << 30) == int(g[tag + "np_after"])
+        assert int(torch.randint(0, 1 << 30, (1,))) == int(g[tag + "torch_after"][0])
+    # the oracle restatement agrees on a full-size batch too (property check at BASELINE size)
+    torch.manual_seed(7)
+    np.random.seed(7)
+    xb = torch.randn(16, 3, 224, 224)
+    yb = torch.randint(0, 1000, (16,))
+    mix = SwitchTokenMix(4, num_classes=1000, smoothing=0.1)
+    d = mix.draw(16)
+    xs, t, pt, _ = mix(xb.to(DEV), yb.to(DEV), draw=d)
+    od = dict(half=d["half"], perm_a=d["partner"][:8], perm_b=d["partner"][8:] - 8, box=d["box"], lam_patch=d["lam_patch"],
+              lam_img=d["lam_img"])
+    xr, tr, ptr, _ = O.switch_token_mix(xb, yb, 4, 1000, 0.1, draw=od)
+    assert torch.equal(xs.cpu(), xr) and torch.equal(t.cpu(), tr) and torch.equal(pt.cpu(), ptr)
+    assert abs(float(t.sum(1).mean()) - 1.0) < 1e-5                            # soft targets stay distributions

@@ -289,3 +289,23 @@ def test_f9_patch_output_avg(mode):
     for k in g.files:
         if k.startswith(mode + ".grad."):
             close(p[k[len(mode) + 6:]].grad, g[k], tol=1e-4)
+
+
+def test_f10_switch_token_mix():
+    """SwitchTokenMix restatement == the reference, bit for bit, including how far both RNG streams advance."""
+    g = load("f10_token_mix")
+    for case in range(4):
+        tag = "c%d." % case
+        B, H, pl, nc, seed = (int(v) for v in g[tag + "cfg"])
+        rs = np.random.RandomState(100 + case)
+        x = torch.from_numpy(rs.standard_normal((B, 3, H, H)).astype(np.float32))
+        y = torch.from_numpy(rs.randint(0, nc, size=(B,)).astype(np.int64))
+        torch.manual_seed(40 + seed)
+        np.random.seed(50 + seed)
+        xs, t, pt, pot = O.switch_token_mix(x, y, pl, nc, 0.1)
+        assert pot == "seq"
+        assert np.array_equal(xs.numpy(), g[tag + "samples"])
+        assert np.array_equal(t.numpy(), g[tag + "targets"])
+        assert np.array_equal(pt.numpy(), g[tag + "patch_targets"])
+        assert np.random.randint(0, 1 << 30) == int(g[tag + "np_after"])
+        assert int(torch.randint(0, 1 << 30, (1,))) == int(g[tag + "torch_after"][0])
