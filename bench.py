@@ -189,6 +189,7 @@ def main():
     losses = []
     for i in range(args.steps):
         losses.append(step(args.warmup + i))
+    host_enqueue = time.perf_counter() - t0              # host time to issue the K steps (the GPU may still be running)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -272,7 +273,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": args.workload, "global_batch": B * world, "per_gpu_batch": B,
                    "example_per_arch": w["epa"], "epoch": 31, "drop_path": w["drop_path"], "parallelism": "dp%d" % world,
-                   "optimizer": "AdamW (vitres.optim.FlatAdamW: vr_adamw_flat)" if args.optimizer == "flat" else "AdamW(torch fused)", "hipgraph": graphed is not None,
+                   "optimizer": "AdamW (vitres.optim.FlatAdamW: vr_adamw_flat)" if args.optimizer == "flat" else "AdamW(torch fused)", "hipgraph": graphed is not None, "host_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
                    "grad_exchange": ("1 all-reduce of the flat fp32 arena, tail overlapped with the second backward graph"
                                      if (graphed is not None and graphed.graph_b is not None) else
                                      "1 all-reduce of the flat fp32 arena" if world > 1 else "none (1 rank)"), "final_loss": round(lossv[-1], 4)},

@@ -39,7 +39,9 @@ STEM_SIDE = _os.environ.get('VITRES_STEM_SIDE', '0') != '0'      # conv-stem wei
 _side_streams = {}
 
 
-_pending = []            # tensors the side stream may still be reading
+_pending = []            # tensors the side stream may still be reading (current generation)
+_lagged = []             # [(event recorded on the side stream, tensors)]: generations whose join was postponed
+JOIN_LAG = int(_os.environ.get('VITRES_JOIN_LAG', '2'))   # branches a join may trail behind (0: join at once)
 
 
 def on_side(fn, *keepalive):
@@ -57,13 +59,33 @@ def on_side(fn, *keepalive):
 
 
 def join_side():
-    """Current stream waits for all side-stream work issued so far."""
+    """Current stream waits for ALL side-stream work issued so far (and releases every tensor kept for it)."""
     if _pending or _side_streams:
         main = torch.cuda.current_stream()
         side = _side_streams.get(main.device)
         if side is not None:
             main.wait_stream(side)
     _pending.clear()
+    _lagged.clear()
+
+
+def join_side_lagged():
+    """End of a backward branch: instead of waiting for THIS branch's weight gradients (a cross-queue dependency the main
+    chain would sit idle behind: ~18 us of nothing running per join in the captured graph), record where the side stream is
+    and wait for the point recorded JOIN_LAG branches ago -- long finished by now.  The tensors of the postponed generations
+    stay alive meanwhile (one or two branches' worth, so buffers still recycle through the Infinity Cache)."""
+    if JOIN_LAG <= 0:
+        return join_side()
+    main = torch.cuda.current_stream()
+    side = _side_streams.get(main.device)
+    if side is None:
+        _pending.clear()
+        return
+    _lagged.append((side.record_event(), list(_pending)))
+    _pending.clear()
+    while len(_lagged) > JOIN_LAG:
+        ev, _keep = _lagged.pop(0)
+        main.wait_event(ev)
 
 
 def _overlap(x):
@@ -157,7 +179,7 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
                  sched=sch)
     out = K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, grads["n1w"], grads["n1b"], next_cast=next_cast)
     if ov and not DEFER_JOIN:
-        join_side()
+        join_side_lagged()
     return out
 
 
@@ -210,7 +232,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     linear_dgrad(du, p["fc1"], dy, M, C, F, F, C, rows_in=N, keep_k=mlp_keep, keep_n=embed_keep, sched=sch)
     out = K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"], next_cast=next_cast)
     if ov and not DEFER_JOIN and not JOIN_PER_BLOCK:
-        join_side()
+        join_side_lagged()
     return out
 
 
