@@ -48,7 +48,9 @@ __device__ __forceinline__ bfv8 tr_frag(const char* p) {
     return __builtin_bit_cast(bfv8, v);
 }
 
-template <bool BIAS>
+// MAPPED: token rows of A / B go through vr_rowmap (cls / patch rows of the embedding, spatial-reduction and head GEMMs): the
+// row address is recomputed per slice instead of advancing by a constant stride
+template <bool BIAS, bool MAPPED>
 __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * TILE_BYTES];   // [A slice][B slice]
     const int t = threadIdx.x, lane = t & 63;
@@ -92,9 +94,12 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
         // the zero page; their products only reach outputs that are not stored
         const bool aok = m0 + c * 8 + 8 <= p.lda, bok = n0 + c * 8 + 8 <= p.ldb;
         tok[h] = tk;
-        gA[h] = aok ? reinterpret_cast<const char*>(p.A) + ((long long)(kbeg + tk) * p.lda + m0 + c * 8) * 2 : nullptr;
-        gB[h] = bok ? reinterpret_cast<const char*>(p.B) + ((long long)(kbeg + tk) * p.ldb + n0 + c * 8) * 2 : nullptr;
+        const long long ra = MAPPED ? 0 : (long long)(kbeg + tk) * p.lda, rb = MAPPED ? 0 : (long long)(kbeg + tk) * p.ldb;
+        gA[h] = aok ? reinterpret_cast<const char*>(p.A) + (ra + m0 + c * 8) * 2 : nullptr;
+        gB[h] = bok ? reinterpret_cast<const char*>(p.B) + (rb + n0 + c * 8) * 2 : nullptr;
     }
+    const RowMap amap = {p.a_map.rpi, p.a_map.rps, p.a_map.off};
+    const RowMap bmap = {p.b_map.rpi, p.b_map.rps, p.b_map.off};
 
     // ---- fragment addresses: lane (g = lane >> 4, li = lane & 15) -> token 8 g + (li >> 2) (+ 32 s, + 4 for the second
     //      read), channel 64 w + 16 i + 4 (li & 3); slot = chunk ^ ((token & 3) << 1) ----
@@ -127,8 +132,16 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const bool in = k0 + tok[h] < kend;
-            const char* sa = (in && gA[h]) ? gA[h] + kt * strideA : zero;
-            const char* sb = (in && gB[h]) ? gB[h] + kt * strideB : zero;
+            const char* sa;
+            const char* sb;
+            if constexpr (MAPPED) {
+                const int tg = in ? k0 + tok[h] : kbeg;
+                sa = (in && gA[h]) ? gA[h] + map_row(amap, tg) * (long long)p.lda * 2 : zero;
+                sb = (in && gB[h]) ? gB[h] + map_row(bmap, tg) * (long long)p.ldb * 2 : zero;
+            } else {
+                sa = (in && gA[h]) ? gA[h] + kt * strideA : zero;
+                sb = (in && gB[h]) ? gB[h] + kt * strideB : zero;
+            }
             __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(smem + (wave * 4 + h) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(smem + TILE_BYTES + (wave * 4 + h) * 1024), 16, 0, 0);
         }
@@ -175,12 +188,11 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
 
 }  // namespace vr_gemm_tn
 
-// Called by vr_gemm after validation.  Returns false when the form is not covered here (row-mapped operands, odd
-// leading dimensions): the general kernel takes those.
+// Called by vr_gemm after validation.  Returns false when the form is not covered here (odd leading dimensions): the
+// general kernel takes those.
 bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_tn;
     if (a0.in_dtype != VR_BF16 || !a0.a_trans || !a0.b_trans || !a0.atomic || a0.out_dtype != VR_F32) return false;
-    if (a0.a_map.rpi != 0 || a0.b_map.rpi != 0) return false;
     if (a0.lda % 8 || a0.ldb % 8 || ((uintptr_t)a0.A & 15) || ((uintptr_t)a0.B & 15)) return false;
     if (a0.lda < (a0.M + 7) / 8 * 8 || a0.ldb < (a0.N + 7) / 8 * 8) return false;
     vr_gemm_args a = a0;
@@ -199,7 +211,13 @@ bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
         a.split_k = (int)(s < 1 ? 1 : s);
     }
     const long long total = tiles * a.split_k;
-    if (a.bias_grad) hipLaunchKernelGGL((tn_kernel<true>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
-    else hipLaunchKernelGGL((tn_kernel<false>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    const bool mapped = a.a_map.rpi != 0 || a.b_map.rpi != 0;
+    if (mapped) {
+        if (a.bias_grad) hipLaunchKernelGGL((tn_kernel<true, true>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+        else hipLaunchKernelGGL((tn_kernel<false, true>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    } else {
+        if (a.bias_grad) hipLaunchKernelGGL((tn_kernel<true, false>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+        else hipLaunchKernelGGL((tn_kernel<false, false>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    }
     return true;
 }
