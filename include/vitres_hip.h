@@ -258,6 +258,15 @@ int vr_mask_rows(float* x, const int32_t* keep, int32_t M, int32_t C, int32_t ro
 int vr_im2col3x3(const void* src, void* col, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride,
                  int32_t src_nchw_f32, int32_t ld, int32_t dtype, vr_stream_t stream);
 int vr_col2im3x3(const void* dcol, void* dsrc, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, vr_stream_t stream);
+
+/*
+ * Direct 3x3 / stride 1 / pad 1 convolution on MFMA (bf16 fast path of patch_conv.py's conv2 / conv3 and, with the weights
+ * flipped and transposed by the caller, of their data gradients): a bf16 NHWC [B,H,W,Cin], w bf16 [Cout, (kh,kw,ci)],
+ * out [B*H*W, Cout] in out_dtype.  No im2col matrix is materialised.  Cin in {16, 24, 32}, Cout <= 32, Cout % 4 == 0;
+ * VR_EUNSUPPORTED otherwise (callers fall back to vr_im2col3x3 + vr_gemm).
+ */
+int vr_conv3x3(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+               int32_t out_dtype, vr_stream_t stream);
 int vr_bn_stats(const float* z, float* sum, float* sumsq, int64_t R, int32_t C, vr_stream_t stream);
 int vr_bn_relu(const float* z, const float* scale, const float* shift, const void* res, void* out, int64_t R, int32_t C,
                int32_t dtype, vr_stream_t stream);

@@ -340,3 +340,25 @@ def test_gemm_masked_work_skipping(dtype):
     ref = E.gemm(o, wp, torch.zeros(M, C), **kw)
     real = K.gemm(o.to(DEV), wp.to(DEV), torch.full((M, C), 7.0, device=DEV), **{k: to(v) for k, v in kw.items()})
     assert relerr(real, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("Cin,Cout", [(24, 24), (32, 32), (16, 24), (24, 8)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_direct_conv3x3(Cin, Cout, out_dtype):
+    """vr_conv3x3 (implicit-GEMM 3x3 / stride 1 / pad 1 on MFMA) == conv2d of the same bf16 operands; H, W not multiples of
+    the 16 x 16 tile exercise the halo and the edge tiles."""
+    B, H, W = 3, 37, 20
+    a = rnd(B * H * W, Cin, seed=1).to(torch.bfloat16)
+    w = (rnd(Cout, 9 * Cin, seed=2) * (9 * Cin) ** -0.5).to(torch.bfloat16)
+    ref = E.conv3x3(a, w, B, H, W, Cin, Cout, out_dtype)
+    out = K.conv3x3(a.to(DEV), w.to(DEV), B, H, W, Cin, Cout, out_dtype)
+    assert out.dtype == out_dtype and out.shape == ref.shape
+    assert relerr(out, ref) < (2e-5 if out_dtype == torch.float32 else 1e-2)
+    # the data gradient is the same kernel with flipped / transposed weights: check the adjoint identity <conv(a), y> = <a, conv_t(y)>
+    y = rnd(B * H * W, Cout, seed=3).to(torch.bfloat16)
+    wt = w.float().view(Cout, 3, 3, Cin).flip(1, 2).permute(3, 1, 2, 0).reshape(Cin, 9 * Cout).to(torch.bfloat16)
+    if K.conv3x3_supported(y, Cout, Cin):
+        back = K.conv3x3(y.to(DEV), wt.to(DEV), B, H, W, Cout, Cin, torch.float32).cpu()
+        fwd = E.conv3x3(a, w, B, H, W, Cin, Cout, torch.float32)
+        lhs, rhs = float((fwd * y.float()).sum()), float((a.float() * back).sum())
+        assert abs(lhs - rhs) < 2e-3 * max(abs(lhs), 1.0)

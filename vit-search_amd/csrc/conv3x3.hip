@@ -1,0 +1,122 @@
+// Direct 3x3 / stride 1 / pad 1 convolution for the conv patch embedding (reference nets/patch_conv.py:23-73: conv2, conv3 and,
+// with flipped weights, their data gradients): NHWC bf16 activations [B,H,W,Cin] (Cin = 24 / 32: a few channels on 112 x 112
+// maps), weights [Cout, (kh, kw, ci)] bf16, output [B*H*W, Cout] fp32 or bf16.
+//
+// The im2col + GEMM form wrote and re-read a 9x larger matrix (694 MB per convolution at B = 128, m = 24) around 8 GFLOP of
+// work; here a workgroup stages the 18 x 18 pixel halo patch of its 16 x 16 output tile in LDS once (1.27x the input bytes,
+// mostly L2 hits) and the MFMA A fragments are gathered straight from it: contraction index k = (tap, channel chunk), a lane's
+// 16-byte chunk = 8 channels of ONE shifted pixel, so "im2col" is just the per-lane LDS address.  HBM traffic = input + output.
+//   MFMA 16x16x32: rows = 16 consecutive pixels of a tile row, 4 lane groups = 4 consecutive (tap, chunk) slots,
+//   computed transposed (weights first): a lane owns one pixel and 4 consecutive output channels -> 16-byte stores.
+// The pixel stride in LDS is Cin*2 bytes, padded by 16 when Cin/8 is even, so the 16 pixels of a fragment read hit 16
+// different 16-byte slots.
+#include "common.h"
+#include "../../include/vitres_hip.h"
+
+namespace {
+
+typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
+constexpr int TH = 16, TW = 16, PH = TH + 2, PW = TW + 2;
+
+template <int NC, typename TO>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ w,
+                                                      TO* __restrict__ out, int B, int H, int W, int Cout) {
+    constexpr int Cin = 8 * NC, K9 = 9 * NC, STEPS = (K9 + 3) / 4;
+    constexpr int PS = Cin * 2 + ((NC & 1) ? 0 : 16);                 // pixel stride in LDS, bytes
+    __shared__ __attribute__((aligned(16))) char patch[PH * PW * PS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    // ---- halo patch -> LDS (all loads first, zero outside the image) ----
+    constexpr int NCHUNK = PH * PW * NC, IT = (NCHUNK + 255) / 256;
+    uint4 v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 256;
+        const int pix = idx / NC, cc = idx % NC;
+        const int iy = y0 + pix / PW - 1, ix = x0 + pix % PW - 1;
+        const bool ok = idx < NCHUNK && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        v[it] = *reinterpret_cast<const uint4*>(a + (((long long)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + cc * 8);
+        if (!ok) v[it] = make_uint4(0, 0, 0, 0);
+    }
+    // ---- weights -> registers: fragment (step, n-tile): row co = 16 nt + c, chunk 4 step + g ----
+    bfv8 wf[STEPS][2];
+#pragma unroll
+    for (int ks = 0; ks < STEPS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int chunk = 4 * ks + g, co = 16 * nt + c;
+            const bool ok = chunk < K9 && co < Cout;
+            uint4 x = *reinterpret_cast<const uint4*>(w + (long long)(ok ? co : 0) * (9 * Cin) + (ok ? chunk : 0) * 8);
+            if (!ok) x = make_uint4(0, 0, 0, 0);
+            wf[ks][nt] = __builtin_bit_cast(bfv8, x);
+        }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < NCHUNK) *reinterpret_cast<uint4*>(patch + (idx / NC) * PS + (idx % NC) * 16) = v[it];
+    }
+    // per-lane LDS offset of contraction slot (step, g): tap (kh, kw), channel chunk cc; padded slots reuse slot 0 (zero weights)
+    int koff[STEPS];
+#pragma unroll
+    for (int ks = 0; ks < STEPS; ++ks) {
+        int chunk = 4 * ks + g;
+        chunk = chunk < K9 ? chunk : 0;
+        const int tap = chunk / NC, cc = chunk % NC;
+        koff[ks] = ((tap / 3) * PW + (tap % 3)) * PS + cc * 16;
+    }
+    __syncthreads();
+    const bool nt1 = Cout > 16;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int r = wave * 4 + mt;                                   // tile row; the fragment's 16 pixels are its 16 columns
+        const char* base = patch + (r * PW + c) * PS;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < STEPS; ++ks) {
+            const bfv8 af = *reinterpret_cast<const bfv8*>(base + koff[ks]);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][0], af, acc0, 0, 0, 0);
+            if (nt1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][1], af, acc1, 0, 0, 0);
+        }
+        const int oy = y0 + r, ox = x0 + c;
+        if (oy < H && ox < W) {
+            TO* dst = out + (((long long)b * H + oy) * W + ox) * Cout;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int co = 16 * nt + 4 * g;
+                if (co < Cout) {
+                    const f32x4 r4 = nt == 0 ? acc0 : acc1;
+                    if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(dst + co) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+                    else *reinterpret_cast<uint2*>(dst + co) = make_uint2(pack_bf2(r4[0], r4[1]), pack_bf2(r4[2], r4[3]));
+                }
+            }
+        }
+    }
+}
+
+template <int NC> int launch(const bf16_t* a, const bf16_t* w, void* out, int B, int H, int W, int Cout, int out_dtype, hipStream_t st) {
+    const unsigned grid = (unsigned)(B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW));
+    if (out_dtype == VR_F32) hipLaunchKernelGGL((conv3x3_kernel<NC, float>), dim3(grid), dim3(256), 0, st, a, w, (float*)out, B, H, W, Cout);
+    else hipLaunchKernelGGL((conv3x3_kernel<NC, bf16_t>), dim3(grid), dim3(256), 0, st, a, w, (bf16_t*)out, B, H, W, Cout);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vr_conv3x3(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                          int32_t out_dtype, vr_stream_t stream) {
+    if (!a || !w || !out || B <= 0 || H <= 0 || W <= 0) return VR_EINVAL;
+    if (out_dtype != VR_F32 && out_dtype != VR_BF16) return VR_EUNSUPPORTED;
+    if (Cout <= 0 || Cout > 32 || Cout % 4) return VR_EUNSUPPORTED;
+    if (((uintptr_t)a & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return VR_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    switch (Cin) {
+        case 16: launch<2>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st); break;
+        case 24: launch<3>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st); break;
+        case 32: launch<4>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st); break;
+        default: return VR_EUNSUPPORTED;
+    }
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}

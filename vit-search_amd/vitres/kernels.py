@@ -267,6 +267,17 @@ def im2col3x3(a, B, H, W, C):
     return col
 
 
+def conv3x3_supported(a, Cin, Cout):
+    return a.dtype == torch.bfloat16 and Cin in (16, 24, 32) and Cout <= 32 and Cout % 4 == 0
+
+
+def conv3x3(a, w, B, H, W, Cin, Cout, out_dtype):
+    """Direct 3x3 / stride 1 / pad 1 convolution: a bf16 NHWC [B*H*W, Cin], w bf16 [Cout, 9*Cin] (kh, kw, ci) -> [B*H*W, Cout]."""
+    out = torch.empty((B * H * W, Cout), dtype=out_dtype, device=a.device)
+    _lib.check(_lib.lib().vr_conv3x3(_p(a), _p(w), _p(out), B, H, W, Cin, Cout, _dtcode(out_dtype), _stream()), "vr_conv3x3")
+    return out
+
+
 def col2im3x3(dcol, B, H, W, C):
     d = torch.empty((B * H * W, C), dtype=dcol.dtype, device=dcol.device)
     _lib.check(_lib.lib().vr_col2im3x3(_p(dcol), _p(d), B, H, W, C, _dt(dcol), _stream()), "vr_col2im3x3")

@@ -29,8 +29,13 @@ def embed_params(model):
     if m % 8:
         raise NotImplementedError('conv patch embedding needs mid_chans % 8 == 0 on the HIP path (got %d)' % m)
     wp = _perm_weight(pe.conv_proj, dt)
+
+    def flipped(conv):
+        """Weights of the data-gradient convolution: Wt[ci, (kh, kw, co)] = W[co, ci, 2-kh, 2-kw] (3x3, stride 1, pad 1)."""
+        w = conv.weight.detach()
+        return w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], 9 * w.shape[0]).to(dt).contiguous()
     return {"w1": _perm_weight(pe.conv1.conv, dt, ld=32), "w2": _perm_weight(pe.conv2.conv, dt),
-            "w3": _perm_weight(pe.conv3.conv, dt),
+            "w3": _perm_weight(pe.conv3.conv, dt), "w2t": flipped(pe.conv2.conv), "w3t": flipped(pe.conv3.conv),
             "proj": Fn.Weights(pe.conv_proj.weight, pe.conv_proj.bias.detach(), wp, wp.shape[1]),
             "pos": model.pos_embed.detach(), "tokens": model.tokens.detach()}
 
@@ -75,12 +80,21 @@ def embed_conv_fwd(model, x, p, cfg, keep, save):
     z1 = conv(col1, p["w1"], 32)
     bn1 = _bn_affine(z1, pe.conv1.bn, tr)
     a1 = K.bn_relu(z1, bn1[0], bn1[1], None, dt)
-    col2 = K.im2col3x3(a1, B, Hm, Wm, m)
-    z2 = conv(col2, p["w2"], 9 * m)
+    # conv2 / conv3: direct MFMA convolution when the shape is covered (bf16, m in {16,24,32}); the im2col matrix (9x the
+    # activation) is then only built in backward, for the weight gradient
+    direct = K.conv3x3_supported(a1, m, m)
+    if direct:
+        col2, z2 = a1, K.conv3x3(a1, p["w2"], B, Hm, Wm, m, m, torch.float32)
+    else:
+        col2 = K.im2col3x3(a1, B, Hm, Wm, m)
+        z2 = conv(col2, p["w2"], 9 * m)
     bn2 = _bn_affine(z2, pe.conv2.bn, tr)
     a2 = K.bn_relu(z2, bn2[0], bn2[1], None, dt)
-    col3 = K.im2col3x3(a2, B, Hm, Wm, m)
-    z3 = conv(col3, p["w3"], 9 * m)
+    if direct:
+        col3, z3 = a2, K.conv3x3(a2, p["w3"], B, Hm, Wm, m, m, torch.float32)
+    else:
+        col3 = K.im2col3x3(a2, B, Hm, Wm, m)
+        z3 = conv(col3, p["w3"], 9 * m)
     bn3 = _bn_affine(z3, pe.conv3.bn, tr)
     a3 = K.bn_relu(z3, bn3[0], bn3[1], a1, dt)
     ps = model.patch_size // 2
@@ -90,13 +104,13 @@ def embed_conv_fwd(model, x, p, cfg, keep, save):
     K.gemm(colp, p["proj"].w_c, out, M=B * P, N=C, K=ldk, lda=ldk, ldb=ldk, ldc=C, bias=p["proj"].b,
            pos=p["pos"][0, 1:], keep_n=keep, rows_in=P, c_map=(P, N, 1))
     K.embed_cls(p["tokens"], p["pos"], out, keep)
-    saved = (col1, z1, bn1, col2, z2, bn2, col3, z3, bn3, colp, (B, Hm, Wm, m, g, ps, tr)) if save else None
+    saved = (col1, z1, bn1, col2, z2, bn2, col3, z3, bn3, colp, (B, Hm, Wm, m, g, ps, tr, direct)) if save else None
     return out, saved
 
 
 def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
     pe, dt = model.patch_embed, cfg["dtype"]
-    col1, z1, bn1, col2, z2, bn2, col3, z3, bn3, colp, (B, Hm, Wm, m, g, ps, tr) = saved
+    col1, z1, bn1, col2, z2, bn2, col3, z3, bn3, colp, (B, Hm, Wm, m, g, ps, tr, direct) = saved
     dev = gx.device
     _, N, C = gx.shape
     P = N - 1
@@ -119,25 +133,29 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
     K.gemm(gt, p["proj"].w_c, dcolp, M=B * P, N=ldk, K=C, lda=C, ldb=ldk, ldc=ldk, b_trans=True, a_map=(P, N, 1))
     da3 = K.patch_fold(dcolp, B, g, g, ps, m)                      # d(relu(bn3) + a1)
 
-    def conv_bwd(da, z, bn, col, w, conv_mod, ld, need_dx):
+    def conv_bwd(da, z, bn, col, w, conv_mod, ld, need_dx, wt=None):
         sg = torch.zeros((2, m), dtype=torch.float32, device=dev)
         dz = K.bn_bwd(da, z, bn[0], bn[1], bn[2], bn[3], sg[0], sg[1], tr)
         gv(conv_mod.bn.weight).copy_(sg[1])
         gv(conv_mod.bn.bias).copy_(sg[0])
-        wt = torch.zeros((m, ld), dtype=torch.float32, device=dev)
+        wg = torch.zeros((m, ld), dtype=torch.float32, device=dev)
         cin = conv_mod.conv.weight.shape[1]
+        if wt is not None:                      # forward ran the direct convolution and saved the activation, not its im2col
+            col = K.im2col3x3(col, B, Hm, Wm, m)
 
         def wgrad():
-            Fn.linear_wgrad(dz, col, wt, R, m, ld, m, ld, sched=1 if ov else 0)
-            gv(conv_mod.conv.weight).copy_(wt[:, :9 * cin].reshape(m, 3, 3, cin).permute(0, 3, 1, 2))
-        Fn.on_side(wgrad, dz, wt) if ov else wgrad()
+            Fn.linear_wgrad(dz, col, wg, R, m, ld, m, ld, sched=1 if ov else 0)
+            gv(conv_mod.conv.weight).copy_(wg[:, :9 * cin].reshape(m, 3, 3, cin).permute(0, 3, 1, 2))
+        Fn.on_side(wgrad, dz, wg) if ov else wgrad()
         if not need_dx:
             return None
+        if wt is not None:                      # data gradient = direct convolution of dz with the flipped weights
+            return K.conv3x3(dz, wt, B, Hm, Wm, m, m, dt)
         dcol = torch.empty((R, ld), dtype=dt, device=dev)
         K.gemm(dz, w, dcol, M=R, N=ld, K=m, lda=m, ldb=ld, ldc=ld, b_trans=True)
         return K.col2im3x3(dcol, B, Hm, Wm, m)
-    da2 = conv_bwd(da3, z3, bn3, col3, p["w3"], pe.conv3, 9 * m, True)
-    da1 = conv_bwd(da2, z2, bn2, col2, p["w2"], pe.conv2, 9 * m, True)
+    da2 = conv_bwd(da3, z3, bn3, col3, p["w3"], pe.conv3, 9 * m, True, p["w3t"] if direct else None)
+    da1 = conv_bwd(da2, z2, bn2, col2, p["w2"], pe.conv2, 9 * m, True, p["w2t"] if direct else None)
     da1 = da1 + da3                                                 # residual branch (patch_conv.py:69)
     conv_bwd(da1, z1, bn1, col1, p["w1"], pe.conv1, 32, False)
     if ov:
