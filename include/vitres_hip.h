@@ -267,6 +267,10 @@ int vr_col2im3x3(const void* dcol, void* dsrc, int32_t B, int32_t H, int32_t W, 
  */
 int vr_conv3x3(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                int32_t out_dtype, vr_stream_t stream);
+/* Its weight gradient: dw[co, (kh,kw,ci)] (fp32, [Cout, 9*Cin]) += sum over pixels of dz[p, co] * a[p + (kh-1, kw-1), ci]; a, dz
+ * bf16 NHWC.  Covered: Cin == Cout in {16, 24, 32} (the stem's conv2 / conv3); VR_EUNSUPPORTED otherwise. */
+int vr_conv3x3_wgrad(const void* a, const void* dz, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                     vr_stream_t stream);
 int vr_bn_stats(const float* z, float* sum, float* sumsq, int64_t R, int32_t C, vr_stream_t stream);
 int vr_bn_relu(const float* z, const float* scale, const float* shift, const void* res, void* out, int64_t R, int32_t C,
                int32_t dtype, vr_stream_t stream);

@@ -204,6 +204,18 @@ def conv3x3(a, w, B, H, W, Cin, Cout, out_dtype):
     return y.permute(0, 2, 3, 1).reshape(B * H * W, Cout).to(out_dtype)
 
 
+def conv3x3_wgrad_supported(a, Cin, Cout):
+    return a.dtype == torch.bfloat16 and Cin == Cout and Cin in (16, 24, 32)
+
+
+def conv3x3_wgrad(a, dz, dw, B, H, W, Cin, Cout):
+    x = a.float().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    g = dz.float().view(B, H, W, Cout).permute(0, 3, 1, 2)
+    gw = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 3, 3), g, padding=1)           # [Cout, Cin, 3, 3]
+    dw += gw.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+    return dw
+
+
 def batchsum(x, out):
     out.add_(x.sum(0).view(out.shape))
     return out
@@ -323,7 +335,7 @@ def patch_fold(col, B, gh, gw, P, C):
 
 
 ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "attn_fwd", "attn_bwd", "softce", "colsum", "scale_mask_cast",
-       "batchsum", "conv3x3", "conv3x3_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
+       "batchsum", "conv3x3", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
 
 
 def install(monkeypatch):

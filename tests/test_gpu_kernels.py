@@ -362,3 +362,15 @@ def test_direct_conv3x3(Cin, Cout, out_dtype):
         fwd = E.conv3x3(a, w, B, H, W, Cin, Cout, torch.float32)
         lhs, rhs = float((fwd * y.float()).sum()), float((a.float() * back).sum())
         assert abs(lhs - rhs) < 2e-3 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.parametrize("C", [24, 32, 16])
+def test_direct_conv3x3_wgrad(C):
+    """vr_conv3x3_wgrad == the weight gradient of conv2d on the same bf16 operands (edge tiles, accumulation into dw)."""
+    B, H, W = 3, 37, 20
+    a = rnd(B * H * W, C, seed=1).to(torch.bfloat16)
+    dz = rnd(B * H * W, C, seed=2).to(torch.bfloat16)
+    ref = E.conv3x3_wgrad(a, dz, torch.ones(C, 9 * C), B, H, W, C, C)
+    dw = torch.ones(C, 9 * C, device=DEV)
+    K.conv3x3_wgrad(a.to(DEV), dz.to(DEV), dw, B, H, W, C, C)
+    assert relerr(dw, ref) < 3e-5

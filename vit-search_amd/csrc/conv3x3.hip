@@ -95,6 +95,119 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const bf16_t* __restrict__
     }
 }
 
+// ---- weight gradient:  dW[co, (kh, kw, ci)] += sum over pixels of dz[p, co] * a[p + (kh-1, kw-1), ci] --------------------
+// Same tiles and halo patch; the contraction now runs over the 256 pixels of a tile, so BOTH MFMA operands are needed
+// "pixel-contiguous" while LDS holds [pixel][channel]: both come from transposing reads (ds_read_b64_tr_b16, as gemm_tn.hip), the
+// B operand with the tap's shift folded into each lane's address.  Output tile = [Cout <= 32] x [9 taps x ceil(Cin/16) blocks of
+// 16 channels]; the 4 waves split the column blocks, accumulate over ALL tiles the (persistent) workgroup visits and add their
+// part of dW once at the end (fp32 atomics: 21 MB for 1024 workgroups instead of a 694 MB im2col matrix read by a GEMM).
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s4v lds_s4v;
+
+__device__ __forceinline__ bfv8 tr8(const char* p0, const char* p1) {
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)p0);
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)p1);
+    const s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bfv8, v);
+}
+
+template <int NC, int NCO /* Cout / 8 */>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ dz,
+                                                            float* __restrict__ dw, int B, int H, int W, int ntiles_total) {
+    constexpr int Cin = 8 * NC, Cout = 8 * NCO, CB = (Cin + 15) / 16, NT = 9 * CB, MT = (Cout + 15) / 16;
+    constexpr int PS = Cin * 2 + ((NC & 1) ? 0 : 16), DS = Cout * 2 + ((NCO & 1) ? 0 : 16);
+    constexpr int NTW = (NT + 3) / 4;                                  // column blocks per wave
+    __shared__ __attribute__((aligned(16))) char patch[PH * PW * PS + 64];
+    __shared__ __attribute__((aligned(16))) char dzt[TH * TW * DS + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane geometry of a transposing read inside a 32-pixel k-step: pixel 8 g + (i >> 2) (+4), i.e. tile row +(g >> 1),
+    // column 8 (g & 1) + (i >> 2) (+4); channel quad 4 (i & 3)
+    const int prow = g >> 1, pcol = 8 * (g & 1) + (i >> 2);
+    const int dz_lane = (prow * TW + pcol) * DS + 4 * (i & 3) * 2;
+    const int pa_lane = (prow * PW + pcol) * PS + 4 * (i & 3) * 2;
+    for (int tile = blockIdx.x; tile < ntiles_total; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        {   // halo patch of the activation and the dz tile -> LDS (loads first)
+            constexpr int NCHUNK = PH * PW * NC, IT = (NCHUNK + 255) / 256;
+            constexpr int NDZ = TH * TW * NCO, ITD = (NDZ + 255) / 256;
+            uint4 v[IT], d[ITD];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int idx = tid + it * 256;
+                const int pix = idx / NC, cc = idx % NC;
+                const int iy = y0 + pix / PW - 1, ix = x0 + pix % PW - 1;
+                const bool ok = idx < NCHUNK && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                v[it] = *reinterpret_cast<const uint4*>(a + (((long long)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cin + cc * 8);
+                if (!ok) v[it] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < ITD; ++it) {
+                const int idx = tid + it * 256;
+                const int pix = idx / NCO, cc = idx % NCO;
+                const int iy = y0 + pix / TW, ix = x0 + pix % TW;
+                const bool ok = idx < NDZ && iy < H && ix < W;
+                d[it] = *reinterpret_cast<const uint4*>(dz + (((long long)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * Cout + cc * 8);
+                if (!ok) d[it] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int idx = tid + it * 256;
+                if (idx < NCHUNK) *reinterpret_cast<uint4*>(patch + (idx / NC) * PS + (idx % NC) * 16) = v[it];
+            }
+#pragma unroll
+            for (int it = 0; it < ITD; ++it) {
+                const int idx = tid + it * 256;
+                if (idx < NDZ) *reinterpret_cast<uint4*>(dzt + (idx / NCO) * DS + (idx % NCO) * 16) = d[it];
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int s = 0; s < 8; ++s) {                                  // 32 pixels (2 tile rows) per step
+            bfv8 af[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const char* q = dzt + dz_lane + (2 * s * TW) * DS + 16 * m * 2;
+                af[m] = tr8(q, q + 4 * DS);
+            }
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int nt = wave + 4 * n;                           // column block (tap, cb)
+                if (nt < NT) {
+                    const int tap = nt / CB, cb = nt % CB;
+                    const char* q = patch + pa_lane + ((2 * s + tap / 3) * PW + tap % 3) * PS + 16 * cb * 2;
+                    const bfv8 bf = tr8(q, q + 4 * PS);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf, acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- dW += this workgroup's partial: lane holds rows co = 16 m + 4 g + r, column ci = 16 cb + i of block (tap, cb) ----
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int nt = wave + 4 * n;
+        if (nt >= NT) continue;
+        const int tap = nt / CB, ci = 16 * (nt % CB) + i;
+        if (ci >= Cin) continue;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * m + 4 * g + r;
+                if (co < Cout) atomicAdd(dw + (long long)co * (9 * Cin) + tap * Cin + ci, acc[m][n][r]);
+            }
+    }
+}
+
 template <int NC> int launch(const bf16_t* a, const bf16_t* w, void* out, int B, int H, int W, int Cout, int out_dtype, hipStream_t st) {
     const unsigned grid = (unsigned)(B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW));
     if (out_dtype == VR_F32) hipLaunchKernelGGL((conv3x3_kernel<NC, float>), dim3(grid), dim3(256), 0, st, a, w, (float*)out, B, H, W, Cout);
@@ -103,6 +216,23 @@ template <int NC> int launch(const bf16_t* a, const bf16_t* w, void* out, int B,
 }
 
 }  // namespace
+
+extern "C" int vr_conv3x3_wgrad(const void* a, const void* dz, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                int32_t Cout, vr_stream_t stream) {
+    if (!a || !dz || !dw || B <= 0 || H <= 0 || W <= 0) return VR_EINVAL;
+    if (((uintptr_t)a & 15) || ((uintptr_t)dz & 15)) return VR_EALIGN;
+    const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    const unsigned grid = (unsigned)(tiles < 1024 ? tiles : 1024);
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t* pa = (const bf16_t*)a;
+    const bf16_t* pd = (const bf16_t*)dz;
+    if (Cin == 24 && Cout == 24) hipLaunchKernelGGL((conv3x3_wgrad_kernel<3, 3>), dim3(grid), dim3(256), 0, st, pa, pd, dw, B, H, W, tiles);
+    else if (Cin == 32 && Cout == 32) hipLaunchKernelGGL((conv3x3_wgrad_kernel<4, 4>), dim3(grid), dim3(256), 0, st, pa, pd, dw, B, H, W, tiles);
+    else if (Cin == 16 && Cout == 16) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 2>), dim3(grid), dim3(256), 0, st, pa, pd, dw, B, H, W, tiles);
+    else return VR_EUNSUPPORTED;
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
 
 extern "C" int vr_conv3x3(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                           int32_t out_dtype, vr_stream_t stream) {

@@ -278,6 +278,16 @@ def conv3x3(a, w, B, H, W, Cin, Cout, out_dtype):
     return out
 
 
+def conv3x3_wgrad_supported(a, Cin, Cout):
+    return a.dtype == torch.bfloat16 and Cin == Cout and Cin in (16, 24, 32)
+
+
+def conv3x3_wgrad(a, dz, dw, B, H, W, Cin, Cout):
+    """dw fp32 [Cout, 9*Cin] (kh, kw, ci) += weight gradient of the 3x3 / stride 1 / pad 1 convolution (a, dz bf16 NHWC)."""
+    _lib.check(_lib.lib().vr_conv3x3_wgrad(_p(a), _p(dz), _p(dw), B, H, W, Cin, Cout, _stream()), "vr_conv3x3_wgrad")
+    return dw
+
+
 def col2im3x3(dcol, B, H, W, C):
     d = torch.empty((B * H * W, C), dtype=dcol.dtype, device=dcol.device)
     _lib.check(_lib.lib().vr_col2im3x3(_p(dcol), _p(d), B, H, W, C, _dt(dcol), _stream()), "vr_col2im3x3")

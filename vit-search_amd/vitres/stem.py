@@ -140,11 +140,15 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
         gv(conv_mod.bn.bias).copy_(sg[0])
         wg = torch.zeros((m, ld), dtype=torch.float32, device=dev)
         cin = conv_mod.conv.weight.shape[1]
-        if wt is not None:                      # forward ran the direct convolution and saved the activation, not its im2col
+        direct_w = wt is not None and K.conv3x3_wgrad_supported(dz, cin, m)
+        if wt is not None and not direct_w:     # forward ran the direct convolution and saved the activation, not its im2col
             col = K.im2col3x3(col, B, Hm, Wm, m)
 
         def wgrad():
-            Fn.linear_wgrad(dz, col, wg, R, m, ld, m, ld, sched=1 if ov else 0)
+            if direct_w:                        # `col` is the saved NHWC activation: direct weight-gradient kernel
+                K.conv3x3_wgrad(col, dz, wg, B, Hm, Wm, cin, m)
+            else:
+                Fn.linear_wgrad(dz, col, wg, R, m, ld, m, ld, sched=1 if ov else 0)
             gv(conv_mod.conv.weight).copy_(wg[:, :9 * cin].reshape(m, 3, 3, cin).permute(0, 3, 1, 2))
         Fn.on_side(wgrad, dz, wg) if ov else wgrad()
         if not need_dx:
