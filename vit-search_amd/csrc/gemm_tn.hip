@@ -35,28 +35,47 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) s4 lds_s4;
 typedef __attribute__((address_space(1))) const void glb_void;
 
-constexpr int BM = 128, BN = 128, BT = 64, NTHR = 256;   // BT: tokens per slice
-constexpr int TILE_BYTES = BT * BM * 2;                  // 16 KB per operand slice
+constexpr int BT = 64, NTHR = 256;                       // BT: tokens per slice
 
 __device__ const uint4 zero_chunk[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 
-__device__ __forceinline__ bfv8 tr_frag(const char* p) {
-    // tokens +0..3 and +4..7 (4 token rows = 1 KB further) of this lane's channel
+// Geometry of a TW-channel wide operand slice in LDS (TW = 128 or 64): token row = TW*2 bytes = SLOTS 16-byte slots; a piece of
+// LDS-DMA (1 KB) = TPP token rows; slot p of token t holds channel chunk p ^ swz(t), chosen so that the 8 tokens x 2 chunks a
+// 32-lane half of a transposing read touches ({0..3, 8..11} + const) fall on 16 different slots of the 256-B bank row:
+//   TW = 128 (one token per bank row)  : swz = ((t & 3) << 1) ^ (((t >> 3) & 1) << 3)
+//   TW = 64  (two tokens per bank row, t & 1 picks the half) : swz = (((t >> 1) & 1) << 1) | (((t >> 3) & 1) << 2)
+template <int TW> struct Geo {
+    static constexpr int ROWB = TW * 2, SLOTS = TW / 8, TPP = 1024 / ROWB, PIECES = BT / TPP, PPW = PIECES / 4;
+    static constexpr int TILE_BYTES = BT * ROWB;
+    static constexpr int F = TW / 32;                    // 16-channel fragments per wave and operand (waves are 2 x 2)
+    __device__ static __forceinline__ int swz(int t) {
+        if constexpr (TW == 128) return ((t & 3) << 1) ^ (((t >> 3) & 1) << 3);
+        else return (((t >> 1) & 1) << 1) | (((t >> 3) & 1) << 2);
+    }
+};
+
+template <int ROWB> __device__ __forceinline__ bfv8 tr_frag(const char* p) {
+    // tokens +0..3 and +4..7 (4 token rows further) of this lane's channel
     const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p));
-    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p + 4 * 256));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(p + 4 * ROWB));
     const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bfv8, v);
 }
 
 // MAPPED: token rows of A / B go through vr_rowmap (cls / patch rows of the embedding, spatial-reduction and head GEMMs): the
-// row address is recomputed per slice instead of advancing by a constant stride
-template <bool BIAS, bool MAPPED>
+// row address is recomputed per slice instead of advancing by a constant stride.
+// TW: tile = TW x TW outputs.  64 for small weights: the atomic volume (split x |W|) is the same as with 128 x 128 tiles, but
+// four times as many workgroups share it -- a 768 x 256 weight is 12 tiles of 128^2, i.e. ~200 workgroups at the coarse token
+// split the atomics call for, each running its 32 slices alone on a CU at the full ~1.5 us slice latency.
+template <bool BIAS, bool MAPPED, int TW>
 __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
+    typedef Geo<TW> G;
+    constexpr int ROWB = G::ROWB, SLOTS = G::SLOTS, TPP = G::TPP, PPW = G::PPW, TILE_BYTES = G::TILE_BYTES, F = G::F;
     __shared__ __attribute__((aligned(1024))) char smem[2 * TILE_BYTES];   // [A slice][B slice]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.N + TW - 1) / TW, tiles_m = (p.M + TW - 1) / TW;
     const int total = tiles_n * tiles_m * p.split_k;
     int tile = blockIdx.x;
     if (total >= 16) {   // XCD-aware order (see gemm_nt.hip)
@@ -65,7 +84,7 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
     }
     const int tn = tile % tiles_n, rest = tile / tiles_n;
     const int tm = rest % tiles_m, z = rest / tiles_m;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TW, n0 = tn * TW;
     const int kper = ((p.K + p.split_k - 1) / p.split_k + BT - 1) / BT * BT;
     const int kbeg = z * kper, kend = min(p.K, kbeg + kper);
     int ntiles = kbeg < kend ? (kend - kbeg + BT - 1) / BT : 0;
@@ -76,20 +95,20 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
         if (p.rows_in > 0) { s_lo = kbeg / p.rows_in; s_hi = (kend - 1) / p.rows_in; }
         const int kmax = max_keep(p.keep_k, s_lo, s_hi, 1 << 30);
         const int nmax = max_keep(p.keep_n, s_lo, s_hi, 1 << 30);
-        if (!range_has_kept(n0, BN, p.n_period, nmax) || !range_has_kept(m0, BM, p.k_period, kmax)) ntiles = 0;
+        if (!range_has_kept(n0, TW, p.n_period, nmax) || !range_has_kept(m0, TW, p.k_period, kmax)) ntiles = 0;
     }
     if (ntiles == 0) return;
 
-    // ---- LDS-DMA source addressing: piece h of this wave = slice tokens (wave*4 + h)*4 .. +4; lane -> (token, slot) ----
-    const char* gA[4];
-    const char* gB[4];
-    int tok[4];
+    // ---- LDS-DMA source addressing: piece h of this wave = slice tokens (wave*PPW + h)*TPP .. ; lane -> (token, slot) ----
+    const char* gA[PPW];
+    const char* gB[PPW];
+    int tok[PPW];
     const long long strideA = (long long)BT * p.lda * 2, strideB = (long long)BT * p.ldb * 2;
     const char* zero = reinterpret_cast<const char*>(zero_chunk);
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        const int tk = (wave * 4 + h) * 4 + (lane >> 4);
-        const int c = (lane & 15) ^ ((tk & 3) << 1) ^ (((tk >> 3) & 1) << 3);
+    for (int h = 0; h < PPW; ++h) {
+        const int tk = (wave * PPW + h) * TPP + lane / SLOTS;
+        const int c = (lane % SLOTS) ^ G::swz(tk);
         // channel chunks past the matrix edge read the row's own padding (lda, ldb >= roundup(M / N, 8)) or, past that,
         // the zero page; their products only reach outputs that are not stored
         const bool aok = m0 + c * 8 + 8 <= p.lda, bok = n0 + c * 8 + 8 <= p.ldb;
@@ -102,26 +121,26 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
     const RowMap bmap = {p.b_map.rpi, p.b_map.rps, p.b_map.off};
 
     // ---- fragment addresses: lane (g = lane >> 4, li = lane & 15) -> token 8 g + (li >> 2) (+ 32 s, + 4 for the second
-    //      read), channel 64 w + 16 i + 4 (li & 3); slot = chunk ^ ((token & 3) << 1) ----
+    //      read), channel (TW/2) w + 16 i + 4 (li & 3); slot = chunk ^ swz(token) (the same for both reads and all s) ----
     const int li = lane & 15, g = lane >> 4;
-    const int xr2 = ((li >> 2) << 1) | ((g & 1) << 3);
-    const int rowoff = (8 * g + (li >> 2)) * 256 + (li & 1) * 8;
-    int offA[4], offB[4];
+    const int xr2 = G::swz(8 * g + (li >> 2));
+    const int rowoff = (8 * g + (li >> 2)) * ROWB + (li & 1) * 8;
+    int offA[F], offB[F];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ca = (8 * wm + 2 * i + ((li & 3) >> 1)) ^ xr2;
-        const int cb = (8 * wn + 2 * i + ((li & 3) >> 1)) ^ xr2;
+    for (int i = 0; i < F; ++i) {
+        const int ca = ((TW / 16) * wm + 2 * i + ((li & 3) >> 1)) ^ xr2;
+        const int cb = ((TW / 16) * wn + 2 * i + ((li & 3) >> 1)) ^ xr2;
         offA[i] = rowoff + ca * 16;
         offB[i] = TILE_BYTES + rowoff + cb * 16;
     }
 
-    f32x4 acc[4][4];
-    f32x4 accb[4];
+    f32x4 acc[F][F];
+    f32x4 accb[F];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < F; ++i) {
         accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < F; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const bool want_bg = BIAS && tn == 0 && wn == 0;
     const s8 ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
@@ -130,7 +149,7 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
     for (int kt = 0; kt < ntiles; ++kt) {
         const int k0 = kbeg + kt * BT;
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
+        for (int h = 0; h < PPW; ++h) {
             const bool in = k0 + tok[h] < kend;
             const char* sa;
             const char* sb;
@@ -142,25 +161,25 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
                 sa = (in && gA[h]) ? gA[h] + kt * strideA : zero;
                 sb = (in && gB[h]) ? gB[h] + kt * strideB : zero;
             }
-            __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(smem + (wave * 4 + h) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(smem + TILE_BYTES + (wave * 4 + h) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(smem + (wave * PPW + h) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(smem + TILE_BYTES + (wave * PPW + h) * 1024), 16, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bfv8 a[4];
+            bfv8 a[F];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = tr_frag(smem + offA[i] + s * 32 * 256);
+            for (int i = 0; i < F; ++i) a[i] = tr_frag<ROWB>(smem + offA[i] + s * 32 * ROWB);
             if (want_bg) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
+                for (int i = 0; i < F; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bfv8 b = tr_frag(smem + offB[j] + s * 32 * 256);
+            for (int j = 0; j < F; ++j) {
+                const bfv8 b = tr_frag<ROWB>(smem + offB[j] + s * 32 * ROWB);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
+                for (int i = 0; i < F; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -171,19 +190,30 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
     float* C = reinterpret_cast<float*>(p.C);
     const RowMap cm = {p.c_map.rpi, p.c_map.rps, p.c_map.off};
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < F; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * 64 + 16 * i + 4 * g + r;
+            const int m = m0 + wm * (TW / 2) + 16 * i + 4 * g + r;
             if (m >= p.M) continue;
             float* crow = C + map_row(cm, m) * (long long)p.ldc;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + 16 * j + li;
+            for (int j = 0; j < F; ++j) {
+                const int n = n0 + wn * (TW / 2) + 16 * j + li;
                 if (n < p.N) atomicAdd(crow + n, acc[i][j][r]);
             }
             if (want_bg && li == 0) atomicAdd(p.bias_grad + m, accb[i][r]);
         }
+}
+
+template <int TW> void launch_tw(const vr_gemm_args& a, hipStream_t stream, long long total) {
+    const bool mapped = a.a_map.rpi != 0 || a.b_map.rpi != 0;
+    if (mapped) {
+        if (a.bias_grad) hipLaunchKernelGGL((tn_kernel<true, true, TW>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+        else hipLaunchKernelGGL((tn_kernel<false, true, TW>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    } else {
+        if (a.bias_grad) hipLaunchKernelGGL((tn_kernel<true, false, TW>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+        else hipLaunchKernelGGL((tn_kernel<false, false, TW>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    }
 }
 
 }  // namespace vr_gemm_tn
@@ -196,28 +226,27 @@ bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
     if (a0.lda % 8 || a0.ldb % 8 || ((uintptr_t)a0.A & 15) || ((uintptr_t)a0.B & 15)) return false;
     if (a0.lda < (a0.M + 7) / 8 * 8 || a0.ldb < (a0.N + 7) / 8 * 8) return false;
     vr_gemm_args a = a0;
-    const long long tiles = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    static const int knob_s = std::getenv("VITRES_TN_S") ? std::atoi(std::getenv("VITRES_TN_S")) : 32;
+    static const int knob_tw = std::getenv("VITRES_TN_TW") ? std::atoi(std::getenv("VITRES_TN_TW")) : 0;
+    const long long slices = (a.K + BT - 1) / BT;
+    const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    // Every workgroup pays |tile| x 4 B of fp32 atomics whatever its share of the tokens, so the token split is coarse: 32
+    // slices (2048 tokens) per workgroup (measured inside the two-stream training step: +3 % over 16/32 adaptive; 24 / 40 /
+    // 48 / 64 slower; VITRES_TN_S overrides), never more than 4 workgroups per CU.  64 x 64 tiles give 4x the workgroups at the
+    // same atomic volume.
+    long long split = (slices + knob_s - 1) / knob_s;
+    // (64 x 64 is opt-in, VITRES_TN_TW=64: alone on the chip it is up to 2x faster for stage-1 weights, but inside the training
+    // step the extra workgroups take CUs from the data-gradient chain they run beside: measured -3 %)
+    const bool small = knob_tw == 64;
+    const long long tiles = small ? t64 : t128;
     if (a.split_k <= 0) {
-        // Every workgroup pays 64 KB of fp32 atomics whatever its share of the tokens, so the split is coarse: 32 slices
-        // (2048 tokens) per workgroup, never more than 4 workgroups per CU.  Alone on the chip a small weight would
-        // prefer 16 slices (more workgroups), but the weight gradients run beside the data-gradient chain on a second
-        // stream, which fills the CUs anyway: 32 measured +3 % on the whole training step over the adaptive 16/32 rule,
-        // 24 / 40 / 48 / 64 all slower (VITRES_TN_S overrides for experiments).
-        static const int knob_s = std::getenv("VITRES_TN_S") ? std::atoi(std::getenv("VITRES_TN_S")) : 32;
-        const long long slices = (a.K + BT - 1) / BT;
-        long long s = (slices + knob_s - 1) / knob_s;
         const long long by_fill = (4LL * n_cu + tiles - 1) / tiles;
-        if (s > by_fill) s = by_fill;
-        a.split_k = (int)(s < 1 ? 1 : s);
+        if (split > by_fill) split = by_fill;
+        a.split_k = (int)(split < 1 ? 1 : split);
     }
     const long long total = tiles * a.split_k;
-    const bool mapped = a.a_map.rpi != 0 || a.b_map.rpi != 0;
-    if (mapped) {
-        if (a.bias_grad) hipLaunchKernelGGL((tn_kernel<true, true>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
-        else hipLaunchKernelGGL((tn_kernel<false, true>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
-    } else {
-        if (a.bias_grad) hipLaunchKernelGGL((tn_kernel<true, false>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
-        else hipLaunchKernelGGL((tn_kernel<false, false>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
-    }
+    if (small) launch_tw<64>(a, stream, total);
+    else launch_tw<128>(a, stream, total);
     return true;
 }
