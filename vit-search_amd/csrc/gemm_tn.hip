@@ -241,7 +241,8 @@ bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
     const bool small = knob_tw == 64;
     const long long tiles = small ? t64 : t128;
     if (a.split_k <= 0) {
-        const long long by_fill = (4LL * n_cu + tiles - 1) / tiles;
+        static const int knob_fill = std::getenv("VITRES_TN_FILL") ? std::atoi(std::getenv("VITRES_TN_FILL")) : 4;
+        const long long by_fill = ((long long)knob_fill * n_cu + tiles - 1) / tiles;
         if (split > by_fill) split = by_fill;
         a.split_k = (int)(split < 1 ? 1 : split);
     }
