@@ -226,7 +226,7 @@ def main():
             dt_, at, bt, mapped = k
             if dt_ == "bf16" and not at and not bt:
                 return "vr_gemm_nt::nt_kernel (forward+dgrad)"
-            if dt_ == "bf16" and at and bt and not mapped:
+            if dt_ == "bf16" and at and bt:
                 return "vr_gemm_tn::tn_kernel (wgrad)"
             if at:
                 return "gemm_kernel<%s,true,true,float,EPI_ATOMIC> (row-mapped wgrad)" % dt_
