@@ -63,16 +63,46 @@ def plan_for_subnet(model, sub_network_def, batch):
 
 @torch.no_grad()
 def score_candidate(model, sub_network_def, batches):
-    """top-1 accuracy (percent, batch-size weighted -- engine.py:224-229) of one candidate on `batches`."""
+    """top-1 accuracy (percent, batch-size weighted -- engine.py:224-229) of one candidate on `batches`.  The keep
+    descriptor is built once per batch size and the hit count stays on the device: one host sync per candidate (the
+    reference reads `.item()` metrics every batch, engine.py:227-229)."""
     model.eval()
-    correct, count = 0.0, 0
+    correct, count, plans = None, 0, {}
     for images, target in batches:
-        plan = plan_for_subnet(model, sub_network_def, images.shape[0])
-        out = model(images, plan=plan)
+        b = images.shape[0]
+        if b not in plans:
+            plans[b] = plan_for_subnet(model, sub_network_def, b)
+        out = model(images, plan=plans[b])
         out = out[0] if isinstance(out, tuple) else out
-        correct += (out.argmax(dim=1) == target).float().sum().item()
-        count += images.shape[0]
-    return 100.0 * correct / max(count, 1)
+        hits = (out.argmax(dim=1) == target).sum()
+        correct = hits if correct is None else correct + hits
+        count += b
+    return 100.0 * float(correct) / max(count, 1) if count else 0.0
+
+
+def random_candidate(network_def, num_channels_to_keep, rng):
+    """One uniformly drawn sub-network of the search space (same grammar as network_def; the role of
+    search_utils/gen_utils.py:gen_random_func: every stage picks an embedding width, every block its heads x head_dim,
+    its MLP width and -- where the table allows 0 -- whether it exists)."""
+    out, embed = [], None
+    for entry, choice in zip(network_def, num_channels_to_keep):
+        kind = entry[0]
+        if kind in (0, 4, 5):                                    # patch embedding
+            embed = int(rng.choice(choice))
+            out.append((kind, embed) + tuple(entry[2:]))
+        elif kind == _T_TRANS:
+            d = entry[1][2]
+            hd = int(rng.choice(choice['attn']))
+            hidden = int(rng.choice(choice['mlp']))
+            exists = 1 if choice.get('layer') is None else int(int(rng.choice(choice['layer'])) > 0)
+            out.append((kind, (embed, hd // d, d), (embed, hidden), exists))
+        elif kind == _T_SR:
+            new = int(rng.choice(choice))
+            out.append((kind, embed, new))
+            embed = new
+        else:                                                    # head
+            out.append((kind, embed) + tuple(entry[2:]))
+    return tuple(out)
 
 
 @torch.no_grad()
