@@ -374,3 +374,21 @@ def test_direct_conv3x3_wgrad(C):
     dw = torch.ones(C, 9 * C, device=DEV)
     K.conv3x3_wgrad(a.to(DEV), dz.to(DEV), dw, B, H, W, C, C)
     assert relerr(dw, ref) < 3e-5
+
+
+@pytest.mark.parametrize("N,H,D", [(401, 2, 64), (785, 2, 32), (300, 3, 48), (577, 1, 64)])
+def test_attention_long_sequences(N, H, D):
+    """N > 288 (280 / 336 / 392 px fine-tuning: 401 / 577 / 785 tokens): the block-streaming MFMA kernels -- two-pass softmax
+    forward, key-blocked dQ, query-blocked dK / dV -- against the fp32 restatement; one head dropped by the prefix mask."""
+    B = 2
+    dtype = torch.bfloat16
+    qkv = rnd(B, N, 3 * H * D, seed=1).to(dtype)
+    keep = torch.tensor([H * D, max(D, (H - 1) * D)], dtype=torch.int32)
+    scale = D ** -0.5
+    (o, lse), (orf, lser) = both("attn_fwd", (qkv, keep, B, N, H, D, scale))
+    assert relerr(o, orf) < 1.5e-2
+    assert relerr(lse, lser) < 1e-4
+    d_o = rnd(B, N, H * D, seed=2).to(dtype)
+    dq = K.attn_bwd(qkv.to(DEV), o, d_o.to(DEV), lse, keep.to(DEV), B, N, H, D, scale)
+    dqr = E.attn_bwd(qkv, orf, d_o, lser, keep, B, N, H, D, scale)
+    assert relerr(dq, dqr) < 2.5e-2, relerr(dq, dqr)

@@ -374,3 +374,23 @@ def test_switch_token_mix_is_bit_exact_with_reference():
     xr, tr, ptr, _ = O.switch_token_mix(xb, yb, 4, 1000, 0.1, draw=od)
     assert torch.equal(xs.cpu(), xr) and torch.equal(t.cpu(), tr) and torch.equal(pt.cpu(), ptr)
     assert abs(float(t.sum(1).mean()) - 1.0) < 1e-5                            # soft targets stay distributions
+
+
+def test_model_at_280px_uses_long_attention():
+    """Fine-tuning resolution (reference scripts/vit-sr-nas/finetune/*: 280 / 392 px): N = 401 tokens in stage 1 exceeds what fits
+    in LDS per head; the block-streaming attention kernels take over.  bf16 HIP path vs the fp32 CPU oracle."""
+    prod, orc, sd = build_pair(0, "plain", 100, img=280)
+    prod.set_compute_dtype(torch.bfloat16)
+    x, t, pt, _ = recipe.inputs(7, 2, 280, recipe.MICRO_CLASSES, (280 // 14 // 4) ** 2)
+    prod.train()
+    orc.train()
+    cls, pat = prod(x.to(DEV), patch_output_type="seq")
+    rc, rp = orc(x, patch_output_type="seq")
+    assert cls.shape == rc.shape and pat.shape == rp.shape
+    assert rel(cls, rc.detach()) < 3e-2 and rel(pat, rp.detach()) < 3e-2
+    ce = lambda a, b: torch.sum(-b * torch.log_softmax(a, -1), -1).mean()      # noqa: E731
+    ce(cls, t.to(DEV)).backward()
+    O.soft_target_ce(rc, t).backward()
+    pr = dict(orc.named_parameters())
+    for n in ("blocks.0.attn.qkv.weight", "blocks.0.attn.proj.weight", "cls_head.weight"):
+        assert rel(dict(prod.named_parameters())[n].grad, pr[n].grad) < 8e-2, n

@@ -417,6 +417,289 @@ __global__ __launch_bounds__(NW * 64) void bwd_dkv_kernel(const bf16_t* __restri
     }
 }
 
+// ==========================================================================================================
+// N > 288 (fine-tuning at 280 / 336 / 392 px: N = 401 / 577 / 785, reference scripts/vit-sr-nas/finetune/*): the head no
+// longer fits in LDS.  Same fragments and dataflow, but a workgroup owns 128 queries (or keys) and walks the other
+// sequence in blocks of 256 rows staged in LDS one after the other.  The forward makes two passes over the key blocks --
+// log-sum-exp first, then P = exp(s - lse) and O += V^T P^T exactly like the backward kernels recompute P -- instead of an
+// online softmax with accumulator rescaling; QK^T is computed twice, on a path that is 5 % of the FLOPs.
+// ==========================================================================================================
+constexpr int LKB = 256, LQB = 128, LNW = 8;              // rows per staged block, rows per workgroup, waves
+
+template <int D>
+__global__ __launch_bounds__(LNW * 64) void fwd_long_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                            float* __restrict__ lse, const int* __restrict__ keep_hd, int B,
+                                                            int N, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int nqb = (N + LQB - 1) / LQB;
+    const int qb = blockIdx.x % nqb, bh = blockIdx.x / nqb, b = bh / H, h = bh % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int HD = H * D, RS = 3 * HD;
+    const bf16_t* base = qkv + (long long)b * N * RS + h * D;
+    bf16_t* ob = o + (long long)b * N * HD + h * D;
+    float* lb = lse + ((long long)b * H + h) * N;
+    const int q0 = qb * LQB + wave * 16;
+    if (keep_hd && h * D >= keep_hd[b]) {
+        for (int i = tid; i < LQB * (D / 8); i += LNW * 64) {
+            const int n = qb * LQB + i / (D / 8), ch = i % (D / 8);
+            if (n < N) *reinterpret_cast<uint4*>(ob + (long long)n * HD + ch * 8) = make_uint4(0, 0, 0, 0);
+        }
+        for (int n = qb * LQB + tid; n < min(N, (qb + 1) * LQB); n += LNW * 64) lb[n] = 0.f;
+        return;
+    }
+    char* Kc = sm;
+    char* Vc = sm + (size_t)D * (LKB + 8) * 2;
+    bfv8 qf[AC<D>::DK];
+#pragma unroll
+    for (int dk = 0; dk < AC<D>::DK; ++dk) qf[dk] = gfrag<D>(base, RS, q0, N, dk, lane);
+    const int nkb = (N + LKB - 1) / LKB;
+    // ---- pass 1: log-sum-exp of every query over all key blocks ----
+    float mx = -INFINITY, sum = 0.f;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int k0 = kb * LKB, nk = min(LKB, N - k0);
+        __syncthreads();
+        stage_chunked<D, LKB, LNW * 64>(Kc, base + HD + (long long)k0 * RS, RS, nk, LKB, tid);
+        __syncthreads();
+        f32x4 st[LKB / 16];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < LKB / 16; ++kt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dk = 0; dk < AC<D>::DK; ++dk) acc = mfma16(cfrag<D>(Kc, LKB, kt * 16, dk, lane), qf[dk], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r] = (kt * 16 + 4 * g + r) < nk ? acc[r] * scale : -INFINITY;
+                bm = fmaxf(bm, acc[r]);
+            }
+            st[kt] = acc;
+        }
+        bm = gmax(bm);
+        const float nm = fmaxf(mx, bm);
+        float bs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < LKB / 16; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bs += __expf(st[kt][r] - nm);
+        sum = sum * __expf(mx - nm) + gsum(bs);
+        mx = nm;
+    }
+    const float l = mx + __logf(sum);
+    if (g == 0 && q0 + c < N) lb[q0 + c] = l;
+    // ---- pass 2: O^T += V^T P^T with P = exp(s - lse) ----
+    f32x4 oacc[AC<D>::DT];
+#pragma unroll
+    for (int dt = 0; dt < AC<D>::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int k0 = kb * LKB, nk = min(LKB, N - k0);
+        __syncthreads();
+        stage_chunked<D, LKB, LNW * 64>(Kc, base + HD + (long long)k0 * RS, RS, nk, LKB, tid);
+        stage_chunked<D, LKB, LNW * 64>(Vc, base + 2 * HD + (long long)k0 * RS, RS, nk, LKB, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kp = 0; kp < LKB / 32; ++kp) {
+            f32x4 pr[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int kt = 2 * kp + tt;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dk = 0; dk < AC<D>::DK; ++dk) acc = mfma16(cfrag<D>(Kc, LKB, kt * 16, dk, lane), qf[dk], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = (kt * 16 + 4 * g + r) < nk ? __expf(acc[r] * scale - l) : 0.f;
+                pr[tt] = acc;
+            }
+            const bfv8 pf = pack8(pr[0], pr[1]);
+#pragma unroll
+            for (int dt = 0; dt < AC<D>::DT; ++dt) oacc[dt] = mfma16(tfrag<D>(Vc, LKB, kp, dt, lane), pf, oacc[dt]);
+        }
+    }
+    if (q0 + c < N) {
+#pragma unroll
+        for (int dt = 0; dt < AC<D>::DT; ++dt)
+            *reinterpret_cast<uint2*>(ob + (long long)(q0 + c) * HD + dt * 16 + 4 * g) =
+                make_uint2(pack_bf2(oacc[dt][0], oacc[dt][1]), pack_bf2(oacc[dt][2], oacc[dt][3]));
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(LNW * 64) void bwd_dq_long_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                               const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                               float* __restrict__ delta, bf16_t* __restrict__ dqkv,
+                                                               const int* __restrict__ keep_hd, int B, int N, int H,
+                                                               float scale) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int nqb = (N + LQB - 1) / LQB;
+    const int qb = blockIdx.x % nqb, bh = blockIdx.x / nqb, b = bh / H, h = bh % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int HD = H * D, RS = 3 * HD;
+    const bf16_t* base = qkv + (long long)b * N * RS + h * D;
+    bf16_t* dbase = dqkv + (long long)b * N * RS + h * D;
+    if (keep_hd && h * D >= keep_hd[b]) {
+        for (int i = tid; i < LQB * (D / 8); i += LNW * 64) {
+            const int n = qb * LQB + i / (D / 8), ch = i % (D / 8);
+            if (n < N) *reinterpret_cast<uint4*>(dbase + (long long)n * RS + ch * 8) = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
+    const bf16_t* ob = o + (long long)b * N * HD + h * D;
+    const bf16_t* gb = d_o + (long long)b * N * HD + h * D;
+    const float* lb = lse + ((long long)b * H + h) * N;
+    float* db = delta + ((long long)b * H + h) * N;
+    char* Kc = sm;
+    char* Vc = Kc + (size_t)D * (LKB + 8) * 2;
+    const int q0 = qb * LQB + wave * 16;
+    const bool qok = q0 + c < N;
+    bfv8 qf[AC<D>::DK], gf[AC<D>::DK];
+    float dl = 0.f;
+#pragma unroll
+    for (int dk = 0; dk < AC<D>::DK; ++dk) {
+        qf[dk] = gfrag<D>(base, RS, q0, N, dk, lane);
+        gf[dk] = gfrag<D>(gb, HD, q0, N, dk, lane);
+        const bfv8 of = gfrag<D>(ob, HD, q0, N, dk, lane);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)gf[dk][e] * (float)of[e];
+    }
+    dl = gsum(dl);
+    const float l = qok ? lb[q0 + c] : 0.f;
+    if (g == 0 && qok) db[q0 + c] = dl;
+    f32x4 dq[AC<D>::DT];
+#pragma unroll
+    for (int dt = 0; dt < AC<D>::DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkb = (N + LKB - 1) / LKB;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int k0 = kb * LKB, nk = min(LKB, N - k0);
+        __syncthreads();
+        stage_chunked<D, LKB, LNW * 64>(Kc, base + HD + (long long)k0 * RS, RS, nk, LKB, tid);
+        stage_chunked<D, LKB, LNW * 64>(Vc, base + 2 * HD + (long long)k0 * RS, RS, nk, LKB, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kp = 0; kp < LKB / 32; ++kp) {
+            f32x4 ds[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int kt = 2 * kp + tt;
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dk = 0; dk < AC<D>::DK; ++dk) {
+                    sc = mfma16(cfrag<D>(Kc, LKB, kt * 16, dk, lane), qf[dk], sc);
+                    dp = mfma16(cfrag<D>(Vc, LKB, kt * 16, dk, lane), gf[dk], dp);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = qok && ((kt * 16 + 4 * g + r) < nk);
+                    const float pr = ok ? __expf(sc[r] * scale - l) : 0.f;
+                    sc[r] = pr * (dp[r] - dl) * scale;
+                }
+                ds[tt] = sc;
+            }
+            const bfv8 sf = pack8(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < AC<D>::DT; ++dt) dq[dt] = mfma16(tfrag<D>(Kc, LKB, kp, dt, lane), sf, dq[dt]);
+        }
+    }
+    if (qok) {
+#pragma unroll
+        for (int dt = 0; dt < AC<D>::DT; ++dt)
+            *reinterpret_cast<uint2*>(dbase + (long long)(q0 + c) * RS + dt * 16 + 4 * g) =
+                make_uint2(pack_bf2(dq[dt][0], dq[dt][1]), pack_bf2(dq[dt][2], dq[dt][3]));
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(LNW * 64) void bwd_dkv_long_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                bf16_t* __restrict__ dqkv, const int* __restrict__ keep_hd,
+                                                                int B, int N, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int nkbk = (N + LQB - 1) / LQB;
+    const int kblk = blockIdx.x % nkbk, bh = blockIdx.x / nkbk, b = bh / H, h = bh % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int HD = H * D, RS = 3 * HD;
+    const bf16_t* base = qkv + (long long)b * N * RS + h * D;
+    bf16_t* dbase = dqkv + (long long)b * N * RS + h * D;
+    if (keep_hd && h * D >= keep_hd[b]) {
+        for (int i = tid; i < LQB * (D / 8); i += LNW * 64) {
+            const int n = kblk * LQB + i / (D / 8), ch = i % (D / 8);
+            if (n < N) {
+                *reinterpret_cast<uint4*>(dbase + (long long)n * RS + HD + ch * 8) = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(dbase + (long long)n * RS + 2 * HD + ch * 8) = make_uint4(0, 0, 0, 0);
+            }
+        }
+        return;
+    }
+    const bf16_t* gb = d_o + (long long)b * N * HD + h * D;
+    const float* lb = lse + ((long long)b * H + h) * N;
+    const float* db = delta + ((long long)b * H + h) * N;
+    char* Qc = sm;
+    char* Gc = Qc + (size_t)D * (LKB + 8) * 2;
+    float* Ls = reinterpret_cast<float*>(Gc + (size_t)D * (LKB + 8) * 2);
+    float* Ds = Ls + LKB;
+    const int k0 = kblk * LQB + wave * 16;
+    bfv8 kf[AC<D>::DK], vf[AC<D>::DK];
+#pragma unroll
+    for (int dk = 0; dk < AC<D>::DK; ++dk) {
+        kf[dk] = gfrag<D>(base + HD, RS, k0, N, dk, lane);
+        vf[dk] = gfrag<D>(base + 2 * HD, RS, k0, N, dk, lane);
+    }
+    f32x4 dka[AC<D>::DT], dva[AC<D>::DT];
+#pragma unroll
+    for (int dt = 0; dt < AC<D>::DT; ++dt) {
+        dka[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dva[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nqb = (N + LKB - 1) / LKB;
+    for (int qb = 0; qb < nqb; ++qb) {
+        const int q0b = qb * LKB, nq = min(LKB, N - q0b);
+        __syncthreads();
+        stage_chunked<D, LKB, LNW * 64>(Qc, base + (long long)q0b * RS, RS, nq, LKB, tid);
+        stage_chunked<D, LKB, LNW * 64>(Gc, gb + (long long)q0b * HD, HD, nq, LKB, tid);
+        for (int n = tid; n < LKB; n += LNW * 64) {
+            Ls[n] = n < nq ? lb[q0b + n] : 0.f;
+            Ds[n] = n < nq ? db[q0b + n] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int qp = 0; qp < LKB / 32; ++qp) {
+            f32x4 p[2], ds[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int q0 = qp * 32 + tt * 16;
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dk = 0; dk < AC<D>::DK; ++dk) {
+                    sc = mfma16(cfrag<D>(Qc, LKB, q0, dk, lane), kf[dk], sc);
+                    dp = mfma16(cfrag<D>(Gc, LKB, q0, dk, lane), vf[dk], dp);
+                }
+                const float4 l4 = *reinterpret_cast<const float4*>(Ls + q0 + 4 * g);
+                const float4 d4 = *reinterpret_cast<const float4*>(Ds + q0 + 4 * g);
+                const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (q0 + 4 * g + r) < nq;
+                    const float pv = ok ? __expf(sc[r] * scale - lr[r]) : 0.f;
+                    p[tt][r] = pv;
+                    ds[tt][r] = pv * (dp[r] - dr[r]) * scale;
+                }
+            }
+            const bfv8 pf = pack8(p[0], p[1]), sf = pack8(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < AC<D>::DT; ++dt) {
+                dva[dt] = mfma16(tfrag<D>(Gc, LKB, qp, dt, lane), pf, dva[dt]);
+                dka[dt] = mfma16(tfrag<D>(Qc, LKB, qp, dt, lane), sf, dka[dt]);
+            }
+        }
+    }
+    if (k0 + c < N) {
+#pragma unroll
+        for (int dt = 0; dt < AC<D>::DT; ++dt) {
+            bf16_t* dst = dbase + (long long)(k0 + c) * RS + dt * 16 + 4 * g;
+            *reinterpret_cast<uint2*>(dst + HD) = make_uint2(pack_bf2(dka[dt][0], dka[dt][1]), pack_bf2(dka[dt][2], dka[dt][3]));
+            *reinterpret_cast<uint2*>(dst + 2 * HD) = make_uint2(pack_bf2(dva[dt][0], dva[dt][1]), pack_bf2(dva[dt][2], dva[dt][3]));
+        }
+    }
+}
+
 // ---- host dispatch ---------------------------------------------------------------------------------------
 // Raising the dynamic-LDS limit is a per-function, idempotent driver call; it is made once per (kernel, size class)
 // so that later launches (e.g. under hipGraph stream capture) are pure stream work.
@@ -460,6 +743,30 @@ static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, con
     return 0;
 }
 
+template <int D>
+static int launch_fwd_long(const bf16_t* qkv, bf16_t* o, float* lse, const int* keep, int B, int N, int H, float scale,
+                           hipStream_t st) {
+    const size_t lds = (size_t)2 * D * (LKB + 8) * 2;
+    int rc = set_lds(fwd_long_kernel<D>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((fwd_long_kernel<D>), dim3(B * H * ((N + LQB - 1) / LQB)), dim3(LNW * 64), lds, st, qkv, o, lse, keep, B, N, H,
+                       scale);
+    return 0;
+}
+template <int D>
+static int launch_bwd_long(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse, float* delta, bf16_t* dqkv,
+                           const int* keep, int B, int N, int H, float scale, hipStream_t st) {
+    const size_t l1 = (size_t)2 * D * (LKB + 8) * 2, l2 = l1 + 2 * LKB * sizeof(float);
+    int rc = set_lds(bwd_dq_long_kernel<D>, l1);
+    if (rc) return rc;
+    rc = set_lds(bwd_dkv_long_kernel<D>, l2);
+    if (rc) return rc;
+    const unsigned grid = (unsigned)(B * H * ((N + LQB - 1) / LQB));
+    hipLaunchKernelGGL((bwd_dq_long_kernel<D>), dim3(grid), dim3(LNW * 64), l1, st, qkv, o, d_o, lse, delta, dqkv, keep, B, N, H, scale);
+    hipLaunchKernelGGL((bwd_dkv_long_kernel<D>), dim3(grid), dim3(LNW * 64), l2, st, qkv, d_o, lse, delta, dqkv, keep, B, N, H, scale);
+    return 0;
+}
+
 #define VR_ATTN_DISPATCH(FN, ...)                                            \
     do {                                                                     \
         const int nkp = (N + 31) / 32;                                       \
@@ -479,14 +786,25 @@ static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, con
     } while (0)
 
 bool supported(int N, int H, int D) {
-    return (D == 32 || D == 48 || D == 64) && N >= 1 && N <= 288 && ((H * D) % 8 == 0);
+    return (D == 32 || D == 48 || D == 64) && N >= 1 && ((H * D) % 8 == 0);
 }
 
 int fwd(const void* qkv, void* o, float* lse, const int* keep, int B, int N, int H, int D, float scale, hipStream_t st) {
+    if (N > 288) {
+        if (D == 64) return launch_fwd_long<64>((const bf16_t*)qkv, (bf16_t*)o, lse, keep, B, N, H, scale, st);
+        if (D == 48) return launch_fwd_long<48>((const bf16_t*)qkv, (bf16_t*)o, lse, keep, B, N, H, scale, st);
+        return launch_fwd_long<32>((const bf16_t*)qkv, (bf16_t*)o, lse, keep, B, N, H, scale, st);
+    }
     VR_ATTN_DISPATCH(launch_fwd, (const bf16_t*)qkv, (bf16_t*)o, lse, keep, B, N, H, scale, st);
 }
 int bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, const int* keep, int B,
         int N, int H, int D, float scale, hipStream_t st) {
+    if (N > 288) {
+        const bf16_t *q = (const bf16_t*)qkv, *oo = (const bf16_t*)o, *go = (const bf16_t*)d_o;
+        if (D == 64) return launch_bwd_long<64>(q, oo, go, lse, delta, (bf16_t*)dqkv, keep, B, N, H, scale, st);
+        if (D == 48) return launch_bwd_long<48>(q, oo, go, lse, delta, (bf16_t*)dqkv, keep, B, N, H, scale, st);
+        return launch_bwd_long<32>(q, oo, go, lse, delta, (bf16_t*)dqkv, keep, B, N, H, scale, st);
+    }
     VR_ATTN_DISPATCH(launch_bwd, (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse, delta, (bf16_t*)dqkv, keep, B,
                      N, H, scale, st);
 }
