@@ -498,9 +498,24 @@ def f10_token_mix():
     save("f10_token_mix", **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# F11: positional-embedding interpolation for higher-resolution fine-tuning (network_utils/finetune_state_dict.py:24-65)
+# ------------------------------------------------------------------------------------------------
+def f11_pos_embed_interp():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_ft", os.path.join(ref_shim.REF, "network_utils", "finetune_state_dict.py"))
+    ft = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ft)
+    lo = build_ref(recipe.MICRO_DEFS[0], img=56)
+    hi = build_ref(recipe.MICRO_DEFS[0], img=140)          # grid 4 -> 10 (SR grids 2 -> 5, 1 -> 2)
+    sd, _ = load_recipe(lo, seed=321)
+    out = ft.state_dict_interpolate_pos_embed(hi.state_dict(), {k: v.clone() for k, v in sd.items()})
+    save("f11_pos_embed_interp", **{k: v.numpy() for k, v in out.items() if "pos_embed" in k})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11"]
     table = dict(f1=f1_micro, f2=f2_masked_ln, f3=f3_channel_drop, f4=f4_fullsize, f5=f5_subnet,
-                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix)
+                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp)
     for w in which:
         table[w]()

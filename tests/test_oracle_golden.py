@@ -309,3 +309,21 @@ def test_f10_switch_token_mix():
         assert np.array_equal(pt.numpy(), g[tag + "patch_targets"])
         assert np.random.randint(0, 1 << 30) == int(g[tag + "np_after"])
         assert int(torch.randint(0, 1 << 30, (1,))) == int(g[tag + "torch_after"][0])
+
+
+def test_f11_pos_embed_interpolation():
+    """vitres.network_utils.finetune_state_dict == the reference's resampling of every positional embedding (56 -> 140 px)."""
+    import vitres
+    from vitres.network_utils.finetune_state_dict import state_dict_interpolate_pos_embed
+    g = load("f11_pos_embed_interp")
+    kw = dict(num_classes=recipe.MICRO_CLASSES, network_def=recipe.MICRO_DEFS[0], drop_path_rate=0.0)
+    lo = vitres.create_model("flexible_vit_sr_patch14_224_patch_output", img_size=56, **kw)
+    hi = vitres.create_model("flexible_vit_sr_patch14_224_patch_output", img_size=140, **kw)
+    sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in lo.state_dict().items()], 321)
+    out = state_dict_interpolate_pos_embed(hi.state_dict(), {k: v.clone() for k, v in sd.items()})
+    keys = [k for k in out if "pos_embed" in k]
+    assert sorted(keys) == sorted(g.files) and len(keys) == 3
+    for k in keys:
+        assert out[k].shape == hi.state_dict()[k].shape
+        assert np.array_equal(out[k].numpy(), g[k]), k
+    hi.load_state_dict(out)                                # and the resized checkpoint loads
