@@ -89,9 +89,10 @@ typedef struct vr_gemm_args {
     int32_t rows_in;     /* rows per sample of the M index (0: single sample); wgrad: tokens per sample of the K index */
     int32_t n_period;    /* > 0: column n is kept iff (n % n_period) < keep_n[s] (per-head prefixes of the qkv layout) */
     int32_t k_period;    /* same for keep_k */
-    int32_t sched;       /* 0: own the chip (persistent workgroups, big tile allowed); 1: launched next to another kernel on a
-                            second stream -- 128x128 tile, one workgroup per output tile, so that the hardware interleaves
-                            the two kernels' workgroups on every CU */
+    int32_t sched;       /* scheduling hints (bit mask, 0 = default): 1 = launched beside another kernel on a second stream (general
+                            kernel: 128x128 tile, one workgroup per tile instead of persistent workgroups); 2 = keep the hardware's
+                            round-robin workgroup -> XCD order (default: tiles remapped so that an XCD owns a contiguous run);
+                            4 = always use the general kernel (gemm.hip) -- measurement aid */
     vr_rowmap a_map;     /* remap of A's token rows (M index if a_trans==0, K index if a_trans==1) */
     vr_rowmap b_map;     /* remap of B's token rows (only meaningful when b_trans==1 && a_trans==1) */
     vr_rowmap c_map;     /* remap of output rows */

@@ -80,7 +80,6 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
 
     // ---- masked-work skipping (same rules as the general kernel) ----
     int ntiles = (p.K + BK - 1) / BK;
-    if (p.sched & 8) ntiles = 0;      // ABLATION knob: bit 3 drops the K loop
     int kmax = 1 << 30;
     bool n_any = true;
     if (p.keep_k || p.keep_n) {
@@ -207,7 +206,7 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     if ((EPI == EPI_STORE || EPI == EPI_GELU) && p.bias) loadw<float, CW>(p.bias, nc, bv, vecb, nv);
     const bool has_pos = (EPI == EPI_STORE) && p.pos;
     const bool has_res = (EPI == EPI_STORE) && p.resid;
-    const bool live = nvalid > 0 && !(p.sched & 16);                  // ABLATION knob: bit 4 drops the stores
+    const bool live = nvalid > 0;
     const RowMeta* meta = rowmeta + wm * WROWS + (lane / LPR);
     // one round per 16-row fragment: park [16 rows][WCOLS columns] (<= 4 KB per wave), read back as rows
 #pragma unroll
