@@ -53,14 +53,18 @@ struct RowMeta {
 // workgroups for GEMMs that would leave the 128-row grid a partial last round)
 // NJ = 16-column fragments per wave along N: 4 -> 128-column tile, 2 -> 64-column tile (long-K GEMMs with few tiles: a lone
 // workgroup per CU pays the full ~1.5 us slice latency, four interleaved ones hide it)
-template <typename TO, int EPI, bool FAST, int MI, int NJ>
+// STAGES = 1: one slice buffer, the CU's other workgroups hide the load latency.  STAGES = 3: ring of three buffers with two
+// slices in flight (counted s_waitcnt vmcnt, raw s_barrier: __syncthreads would drain the LDS-DMA queue) for grids that leave a
+// CU one or two workgroups -- long-K GEMMs of the last stage, where a lone workgroup paid ~1 us per slice.
+template <typename TO, int EPI, bool FAST, int MI, int NJ, int STAGES>
 __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm_args p) {
     constexpr int BM = 32 * MI, WROWS = 16 * MI;      // tile rows, rows per wave
     constexpr int BN = 32 * NJ, WCOLS = 16 * NJ;      // tile columns, columns per wave
     constexpr int A_BYTES = BM * BK * 2, AP = MI;     // A slice bytes, LDS-DMA pieces of A per wave
     constexpr int B_BYTES = BN * BK * 2, BP = NJ;     // same for the weight slice
     constexpr int LPR = 2 * NJ, RPP = 64 / LPR, NQ = 16 / RPP;   // epilogue: lanes per row, rows per pass, passes per 16 rows
-    __shared__ __attribute__((aligned(1024))) char smem[A_BYTES + B_BYTES];   // [A slice][B slice]; epilogue: 4 x 4 KB
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE_BYTES];   // ring of [A slice][B slice]; epilogue: 4 x 4 KB
     __shared__ RowMeta rowmeta[BM];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -132,58 +136,90 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto issue = [&](int kt) {
+    auto issue = [&](int kt, int buf) {
         const int k0 = kt * BK;
         const long long kb = (long long)k0 * 2;
+        char* dst = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int h = 0; h < AP; ++h) {
             const char* sa = (!ktail || (k0 + chunkA[h] < p.K)) ? gA[h] + kb : zero;
-            __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(smem + (wave * (8 * AP) + h * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(dst + (wave * (8 * AP) + h * 8) * 128), 16, 0, 0);
         }
 #pragma unroll
         for (int h = 0; h < BP; ++h) {
             const char* sb = (!ktail || (k0 + chunkB[h] < p.K)) ? gB[h] + kb : zero;
-            __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(smem + A_BYTES + (wave * (8 * BP) + h * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(dst + A_BYTES + (wave * (8 * BP) + h * 8) * 128), 16, 0, 0);
         }
     };
 
-    int kt = next_live(0);
-    if (kt < ntiles) issue(kt);
-    // row metadata (its loads overlap the first slice)
-    if (t < BM) {
-        const int m = m0 + t;
-        RowMeta rm;
-        rm.keep = 1 << 30; rm.scale = 1.0f; rm.orow = -1; rm.mloc = 0;
-        if (m < p.M) {
-            const int sample = p.rows_in > 0 ? m / p.rows_in : 0;
-            rm.mloc = p.rows_in > 0 ? m - sample * p.rows_in : m;
-            rm.orow = (int)map_row({p.c_map.rpi, p.c_map.rps, p.c_map.off}, m);
-            if (p.scale) rm.scale = p.scale[sample];
-            if (p.keep_n) rm.keep = p.keep_n[sample];
-        }
-        rowmeta[t] = rm;
-    }
-    if (kt >= ntiles) __syncthreads();
-    while (kt < ntiles) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    auto compute = [&](int buf) {
+        const char* Ab = As + buf * STAGE_BYTES;
+        const char* Bb = Bs + buf * STAGE_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int so = s == 0 ? slot0 : slot1;
             bfv8 a[MI], b[NJ];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bfv8*>(As + i * 2048 + so);
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bfv8*>(Ab + i * 2048 + so);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bfv8*>(Bs + j * 2048 + so);
+            for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bfv8*>(Bb + j * 2048 + so);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
+    };
+    auto fill_rowmeta = [&]() {      // per-row epilogue metadata (its loads overlap the first slices)
+        if (t < BM) {
+            const int m = m0 + t;
+            RowMeta rm;
+            rm.keep = 1 << 30; rm.scale = 1.0f; rm.orow = -1; rm.mloc = 0;
+            if (m < p.M) {
+                const int sample = p.rows_in > 0 ? m / p.rows_in : 0;
+                rm.mloc = p.rows_in > 0 ? m - sample * p.rows_in : m;
+                rm.orow = (int)map_row({p.c_map.rpi, p.c_map.rps, p.c_map.off}, m);
+                if (p.scale) rm.scale = p.scale[sample];
+                if (p.keep_n) rm.keep = p.keep_n[sample];
+            }
+            rowmeta[t] = rm;
+        }
+    };
+
+    if constexpr (STAGES == 1) {
+        int kt = next_live(0);
+        if (kt < ntiles) issue(kt, 0);
+        fill_rowmeta();
+        if (kt >= ntiles) __syncthreads();
+        while (kt < ntiles) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+            kt = next_live(kt + 1);
+            if (kt < ntiles) issue(kt, 0);
+        }
+    } else {
+        fill_rowmeta();              // its global loads complete (the compiler waits for them) before any LDS-DMA is issued
+        int c0 = next_live(0);
+        int c1 = c0 < ntiles ? next_live(c0 + 1) : ntiles;
+        if (c0 < ntiles) issue(c0, 0);
+        if (c1 < ntiles) issue(c1, 1);
+        int buf = 0;
+        while (c0 < ntiles) {
+            // slice c0 has landed when at most the pieces of the younger slice c1 are outstanding
+            if (c1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();         // every wave has also finished reading the buffer re-filled next
+            const int c2 = c1 < ntiles ? next_live(c1 + 1) : ntiles;
+            const int nb = buf == 0 ? 2 : buf - 1;      // (buf + 2) % 3
+            if (c2 < ntiles) issue(c2, nb);
+            compute(buf);
+            c0 = c1;
+            c1 = c2;
+            buf = buf == 2 ? 0 : buf + 1;
+        }
         __syncthreads();
-        kt = next_live(kt + 1);
-        if (kt < ntiles) issue(kt);
     }
 
     // ---- epilogue: lane owns C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) + 0..3] of the wave's 64 x 64 ----
@@ -280,10 +316,10 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     }
 }
 
-template <typename TO, int EPI, int MI, int NJ> void launch2(const vr_gemm_args& a, hipStream_t stream, bool fast) {
+template <typename TO, int EPI, int MI, int NJ, int STAGES = 1> void launch2(const vr_gemm_args& a, hipStream_t stream, bool fast) {
     const long long total = (long long)((a.M + 32 * MI - 1) / (32 * MI)) * ((a.N + 32 * NJ - 1) / (32 * NJ));
-    if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true, MI, NJ>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
-    else hipLaunchKernelGGL((nt_kernel<TO, EPI, false, MI, NJ>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true, MI, NJ, STAGES>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    else hipLaunchKernelGGL((nt_kernel<TO, EPI, false, MI, NJ, STAGES>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
 }
 
 template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
@@ -296,7 +332,14 @@ template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t 
     const int tile = knob ? knob : (t128 >= 2LL * n_cu ? 1 : (t64 >= 2LL * n_cu ? 2 : 3));
     if (tile == 1) launch2<TO, EPI, 4, 4>(a, stream, fast);
     else if (tile == 2) launch2<TO, EPI, 2, 4>(a, stream, fast);
-    else launch2<TO, EPI, 2, 2>(a, stream, fast);
+    else {
+        // 64 x 64 tiles: with fewer than ~3 workgroups per CU and a long K the slices are pipelined inside the workgroup
+        static const int knob_st = std::getenv("VITRES_NT_STAGES") ? std::atoi(std::getenv("VITRES_NT_STAGES")) : 0;
+        const long long t3 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+        const bool ring = knob_st ? knob_st == 3 : (t3 < 3LL * n_cu && a.K >= 24 * BK);      // measured: +23 % at K = 3072, -3 % at K = 1024
+        if (ring) launch2<TO, EPI, 2, 2, 3>(a, stream, fast);
+        else launch2<TO, EPI, 2, 2>(a, stream, fast);
+    }
 }
 
 }  // namespace vr_gemm_nt
