@@ -67,11 +67,15 @@ template <int ROWB> __device__ __forceinline__ bfv8 tr_frag(const char* p) {
 // TW: tile = TW x TW outputs.  64 for small weights: the atomic volume (split x |W|) is the same as with 128 x 128 tiles, but
 // four times as many workgroups share it -- a 768 x 256 weight is 12 tiles of 128^2, i.e. ~200 workgroups at the coarse token
 // split the atomics call for, each running its 32 slices alone on a CU at the full ~1.5 us slice latency.
-template <bool BIAS, bool MAPPED, int TW>
+// STAGES = 3 (opt-in, VITRES_TN_STAGES=3): ring of three slice buffers, two slices in flight (counted vmcnt + raw barrier, as
+// gemm_nt.hip).  Faster alone; inside the training step its 96 KB of LDS displace the data-gradient workgroups it runs beside
+// (measured -5 %), so the default stays the single buffer.
+template <bool BIAS, bool MAPPED, int TW, int STAGES>
 __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
     typedef Geo<TW> G;
     constexpr int ROWB = G::ROWB, SLOTS = G::SLOTS, TPP = G::TPP, PPW = G::PPW, TILE_BYTES = G::TILE_BYTES, F = G::F;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * TILE_BYTES];   // [A slice][B slice]
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE_BYTES];   // ring of [A slice][B slice]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -146,8 +150,9 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
     const s8 ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
     const bfv8 ones = __builtin_bit_cast(bfv8, ones_bits);
 
-    for (int kt = 0; kt < ntiles; ++kt) {
+    auto issue = [&](int kt, int buf) {
         const int k0 = kbeg + kt * BT;
+        char* dst = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int h = 0; h < PPW; ++h) {
             const bool in = k0 + tok[h] < kend;
@@ -161,28 +166,49 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
                 sa = (in && gA[h]) ? gA[h] + kt * strideA : zero;
                 sb = (in && gB[h]) ? gB[h] + kt * strideB : zero;
             }
-            __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(smem + (wave * PPW + h) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(smem + TILE_BYTES + (wave * PPW + h) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(dst + (wave * PPW + h) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(dst + TILE_BYTES + (wave * PPW + h) * 1024), 16, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    };
+    auto compute = [&](int buf) {
+        const char* sb_ = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bfv8 a[F];
 #pragma unroll
-            for (int i = 0; i < F; ++i) a[i] = tr_frag<ROWB>(smem + offA[i] + s * 32 * ROWB);
+            for (int i = 0; i < F; ++i) a[i] = tr_frag<ROWB>(sb_ + offA[i] + s * 32 * ROWB);
             if (want_bg) {
 #pragma unroll
                 for (int i = 0; i < F; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < F; ++j) {
-                const bfv8 b = tr_frag<ROWB>(smem + offB[j] + s * 32 * ROWB);
+                const bfv8 b = tr_frag<ROWB>(sb_ + offB[j] + s * 32 * ROWB);
 #pragma unroll
                 for (int i = 0; i < F; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();
+    };
+    if constexpr (STAGES == 1) {
+        for (int kt = 0; kt < ntiles; ++kt) {
+            issue(kt, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
+    } else {
+        issue(0, 0);
+        if (ntiles > 1) issue(1, 1);
+        int buf = 0;
+        for (int kt = 0; kt < ntiles; ++kt) {
+            if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");   // slice kt landed, kt+1 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < ntiles) issue(kt + 2, buf == 0 ? 2 : buf - 1);
+            compute(buf);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
     }
 
     // ---- epilogue: lane holds C[m = 16 i + 4 (lane >> 4) + r][n = 16 j + (lane & 15)]: 16 consecutive columns (64 B)
@@ -205,14 +231,14 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
         }
 }
 
-template <int TW> void launch_tw(const vr_gemm_args& a, hipStream_t stream, long long total) {
+template <int TW, int STAGES> void launch_tw(const vr_gemm_args& a, hipStream_t stream, long long total) {
     const bool mapped = a.a_map.rpi != 0 || a.b_map.rpi != 0;
     if (mapped) {
-        if (a.bias_grad) hipLaunchKernelGGL((tn_kernel<true, true, TW>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
-        else hipLaunchKernelGGL((tn_kernel<false, true, TW>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+        if (a.bias_grad) hipLaunchKernelGGL((tn_kernel<true, true, TW, STAGES>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+        else hipLaunchKernelGGL((tn_kernel<false, true, TW, STAGES>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
     } else {
-        if (a.bias_grad) hipLaunchKernelGGL((tn_kernel<true, false, TW>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
-        else hipLaunchKernelGGL((tn_kernel<false, false, TW>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+        if (a.bias_grad) hipLaunchKernelGGL((tn_kernel<true, false, TW, STAGES>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+        else hipLaunchKernelGGL((tn_kernel<false, false, TW, STAGES>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
     }
 }
 
@@ -247,7 +273,13 @@ bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
         a.split_k = (int)(split < 1 ? 1 : split);
     }
     const long long total = tiles * a.split_k;
-    if (small) launch_tw<64>(a, stream, total);
-    else launch_tw<128>(a, stream, total);
+    static const int knob_st = std::getenv("VITRES_TN_STAGES") ? std::atoi(std::getenv("VITRES_TN_STAGES")) : 1;
+    if (small) {
+        if (knob_st == 3) launch_tw<64, 3>(a, stream, total);
+        else launch_tw<64, 1>(a, stream, total);
+    } else {
+        if (knob_st == 3) launch_tw<128, 3>(a, stream, total);
+        else launch_tw<128, 1>(a, stream, total);
+    }
     return true;
 }
