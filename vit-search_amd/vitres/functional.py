@@ -12,24 +12,17 @@ Reference op sequences replaced (file:line in /root/reference):
   patch_embed : timm PatchEmbed / nets/patch_conv.py:63-72 + vit_sr_supernet.py:398-407
   head        : nets/vit_sr_supernet.py:420-428,440-449
 """
+import os as _os
+
 import torch
 
 from . import kernels as K
-
-
-def _split_k(tokens, n_out=128, k_in=128):
-    """Number of contraction splits for a weight-gradient GEMM over `tokens` rows: enough workgroups to fill
-    256 CUs a few times over, never fewer than ~512 tokens per split."""
-    tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
-    return max(1, min(tokens // 512, max(1, 1024 // tiles)))
-
 
 # ---- two-stream execution of independent GEMMs ----------------------------------------------------------------
 # The weight-gradient GEMM of a Linear and the data-gradient GEMM that feeds the next backward op are independent.
 # At ViT-Res shapes each alone leaves most of the chip idle in its prologue / epilogue / tail phases, so they are
 # issued on two streams (parallel branches once the step is captured into a hipGraph) with `sched=1` launches
 # (one workgroup per tile) so the hardware interleaves both kernels' workgroups on every CU.
-import os as _os
 OVERLAP = _os.environ.get('VITRES_OVERLAP', '1') != '0'
 DEFER_JOIN = _os.environ.get('VITRES_OVERLAP', '1') == '2'
 JOIN_PER_BLOCK = _os.environ.get('VITRES_OVERLAP', '1') == '3'
