@@ -167,9 +167,9 @@ def main():
     crit = SoftTargetCrossEntropy()
     arch = "multi" if w["space"] else None
 
-    def eager_step(i):
+    def eager_step(i, exchange=True):
         return engine.train_step(model, crit, opt, x, t, pt, "seq", epoch=31, train_iter=i, arch_sample=arch,
-                                 grad_sync=sync, average_grads=average)
+                                 grad_sync=sync if exchange else None, average_grads=average)
 
     graphed = None
     split = (world > 1) if args.split_sync < 0 else bool(args.split_sync)
@@ -217,7 +217,7 @@ def main():
     if args.profile_steps > 0:
         K.PROFILE = []
         for i in range(args.profile_steps):
-            eager_step(10_000 + i)
+            eager_step(10_000 + i, exchange=False)      # rank 0 only, after the timed region: no collectives here
         torch.cuda.synchronize()
         agg = {}
         for kind, fl, dense, by, e0, e1 in K.PROFILE:
@@ -268,7 +268,7 @@ def main():
                     "tflops_kept": round(v[1] / v[0] / 1e12, 2), "tflops_dense_equiv": round(v[4] / v[0] / 1e12, 2),
                     "algorithmic_GBps": round(v[2] / v[0] / 1e9, 1), "ms_per_step": round(v[0] / args.profile_steps * 1e3, 3)}
                     for k, v in byname.items()}}
-    cpu = None if args.no_cpu_baseline else cpu_baseline(args.workload)
+    cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.workload)      # rank 0 at N = 1 only
     from vitres.network_utils.compute_flop_mac import train_flops_per_image
     dense_flops = train_flops_per_image(nd)
     img_s = B * world * args.steps / elapsed
