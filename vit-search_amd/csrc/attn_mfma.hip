@@ -729,14 +729,15 @@ template <int D, int NKP>
 static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse, float* delta, bf16_t* dqkv,
                       const int* keep, int B, int N, int H, float scale, hipStream_t st) {
     constexpr int NW = NKP >= 3 ? 8 : 2;
-    constexpr int QT = NKP >= 9 ? 3 : 1;      // query / key tiles per wave: 17 tiles of N = 257 = one pass of 6 waves
+    constexpr int QT = NKP >= 9 ? 3 : 1;      // key tiles per wave in dK/dV: 17 tiles of N = 257 = one pass of 6 waves
+    constexpr int QTQ = 1;                    // query tiles per wave in dQ: 1 measured best inside the step (3: -1 %)
     const int Np = (N + 31) / 32 * 32;
     const size_t l1 = (size_t)2 * D * (Np + 8) * 2, l2 = (size_t)2 * D * (Np + 8) * 2 + 2 * Np * sizeof(float);
-    int rc = set_lds(bwd_dq_kernel<D, NKP, NW, QT>, l1);
+    int rc = set_lds(bwd_dq_kernel<D, NKP, NW, QTQ>, l1);
     if (rc) return rc;
     rc = set_lds(bwd_dkv_kernel<D, NKP, NW, QT>, l2);
     if (rc) return rc;
-    hipLaunchKernelGGL((bwd_dq_kernel<D, NKP, NW, QT>), dim3(B * H), dim3(NW * 64), l1, st, qkv, o, d_o, lse, delta, dqkv, keep,
+    hipLaunchKernelGGL((bwd_dq_kernel<D, NKP, NW, QTQ>), dim3(B * H), dim3(NW * 64), l1, st, qkv, o, d_o, lse, delta, dqkv, keep,
                        B, N, H, scale);
     hipLaunchKernelGGL((bwd_dkv_kernel<D, NKP, NW, QT>), dim3(B * H), dim3(NW * 64), l2, st, qkv, d_o, lse, delta, dqkv, keep, B,
                        N, H, scale);
