@@ -513,9 +513,26 @@ def f11_pos_embed_interp():
     save("f11_pos_embed_interp", **{k: v.numpy() for k, v in out.items() if "pos_embed" in k})
 
 
+# ------------------------------------------------------------------------------------------------
+# F12: parameter initialisation from a seed (vit_sr_supernet.py:352-376: trunc_normal(.02) Linears / tokens / pos_embeds, default
+#      Conv2d init, LN ones / zeros) -- the order random numbers are consumed in is part of the drop-in surface
+# ------------------------------------------------------------------------------------------------
+def f12_init():
+    out = {}
+    for et, sup in ((0, False), (0, True), (4, True), (5, False)):
+        kw = dict(num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30) if sup else {}
+        torch.manual_seed(77)
+        m = build_ref(recipe.MICRO_DEFS[et], supernet=sup, **kw)
+        sd = m.state_dict()
+        out["t%d_%d.crc" % (et, int(sup))] = recipe.checksum(sd)
+        out["t%d_%d.tokens" % (et, int(sup))] = sd["tokens"].numpy()
+        out["t%d_%d.head" % (et, int(sup))] = sd["cls_head.weight"].numpy()
+    save("f12_init", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
     table = dict(f1=f1_micro, f2=f2_masked_ln, f3=f3_channel_drop, f4=f4_fullsize, f5=f5_subnet,
-                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp)
+                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init)
     for w in which:
         table[w]()

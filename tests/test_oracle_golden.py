@@ -327,3 +327,20 @@ def test_f11_pos_embed_interpolation():
         assert out[k].shape == hi.state_dict()[k].shape
         assert np.array_equal(out[k].numpy(), g[k]), k
     hi.load_state_dict(out)                                # and the resized checkpoint loads
+
+
+@pytest.mark.parametrize("et,sup", [(0, False), (0, True), (4, True), (5, False)])
+def test_f12_same_seed_same_initialisation(et, sup):
+    """vitres.create_model consumes the random stream exactly like the reference's constructor: the same torch seed gives the
+    same initial parameters (trunc_normal Linears / tokens / pos_embeds, default conv init), bit for bit."""
+    import vitres
+    g = load("f12_init")
+    kw = dict(num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30) if sup else {}
+    torch.manual_seed(77)
+    name = "flexible_vit_sr_patch14_224_patch_output" + ("_supernet" if sup else "")
+    m = vitres.create_model(name, img_size=recipe.MICRO_IMG, num_classes=recipe.MICRO_CLASSES, network_def=recipe.MICRO_DEFS[et], **kw)
+    sd = m.state_dict()
+    tag = "t%d_%d." % (et, int(sup))
+    assert np.array_equal(sd["tokens"].numpy(), g[tag + "tokens"])
+    assert np.array_equal(sd["cls_head.weight"].numpy(), g[tag + "head"])
+    assert recipe.checksum(sd) == int(g[tag + "crc"])
