@@ -230,6 +230,8 @@ def main():
         K.PROFILE = None
         def kname(k):
             dt_, at, bt, mapped = k
+            if mapped == 2:
+                return "vr_gemm_ntln::ntln_kernel (Linear + LayerNorm epilogue)"
             if dt_ == "bf16" and not at and not bt:
                 return "vr_gemm_nt::nt_kernel (forward+dgrad)"
             if dt_ == "bf16" and at and bt:

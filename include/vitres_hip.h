@@ -100,6 +100,38 @@ typedef struct vr_gemm_args {
 
 int vr_gemm(const vr_gemm_args* args, vr_stream_t stream);
 
+/*
+ * vr_gemm with the adjacent LayerNorm fused into its epilogue (workgroups own whole output rows; bf16 operands, fp32 output,
+ * N % 8 == 0, N <= 512, no n_period / pos / act / row maps on the output; ldc is also the row stride of x, resid, gt_out).
+ *   mode 0 -- forward of attention `proj` / Mlp `fc2` (nets/supernet_blocks.py:214-253) and the LayerNorm that consumes the
+ *     updated residual stream (norm2 of the block, norm1 of the next block):
+ *       C = resid + scale[s] * mask_{keep_n}(A B^T + bias)                     exactly vr_gemm
+ *       (y, mean, rstd) = MaskedLayerNorm(C; w, b, keep, eps)                  exactly vr_ln_fwd with bf16 output, y is [M, N]
+ *   mode 1 -- data gradient of `qkv` / `fc1` and the backward of the LayerNorm that fed them (nets/masked_layer_norm.py:55-88):
+ *       dy = A B^T  (A = dU, B = W^T K-contiguous; never written),
+ *       C = (resid ? resid : 0) + dLN/dx(dy);  dw += sum dy*xhat;  db += sum dy;
+ *       gt_out[m,c] = c < gt_keep[s] ? C[m,c] * gt_scale[s] : 0 (bf16, optional)  exactly vr_ln_bwd on a fp32 dy
+ *     (args.bias / scale / keep_n must be NULL; keep_k / k_period / rows_in keep their vr_gemm meaning).
+ */
+typedef struct vr_ln_epilogue {
+    int32_t mode;
+    float eps;               /* mode 0 */
+    const float* w;          /* LayerNorm weight [N] */
+    const float* b;          /* LayerNorm bias [N] (mode 0) */
+    const int32_t* keep;     /* [batch] kept prefix of the LayerNorm, NULL = all N channels */
+    void* y;                 /* mode 0 out: bf16 [M, N] */
+    float* mean;             /* mode 0 out / mode 1 in: [M] */
+    float* rstd;
+    const float* x;          /* mode 1: the LayerNorm's input saved by the forward, fp32 [M, ldc] */
+    float* dw;               /* mode 1: fp32 [N], accumulated with atomics */
+    float* db;
+    void* gt_out;            /* mode 1, optional: bf16 [M, ldc] */
+    const float* gt_scale;   /* [batch] or NULL */
+    const int32_t* gt_keep;  /* [batch] or NULL */
+} vr_ln_epilogue;
+int vr_gemm_ln(const vr_gemm_args* args, const vr_ln_epilogue* ln, vr_stream_t stream);
+int vr_gemm_ln_supported(int32_t N);
+
 /* fp32 -> bf16 (round to nearest even), n elements.  Replaces autocast's per-op weight casts (engine.py:112). */
 int vr_cast_f32_bf16(const float* src, void* dst, int64_t n, vr_stream_t stream);
 

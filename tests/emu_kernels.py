@@ -134,6 +134,25 @@ def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db, next_cast
     return dx, scale_mask_cast(dx, next_cast[0], next_cast[1], rows_per_sample, dy.dtype)
 
 
+def gemm_ln_supported(a, N, ldc):
+    return a.dtype == torch.bfloat16 and N == ldc and N % 8 == 0 and N <= 512
+
+
+def gemm_ln_fwd(a, b, out, ln_w, ln_b, ln_keep, eps, *, M, N, K, lda, ldb, ldc, bias=None, scale=None, keep_n=None,
+                resid=None, rows_in=0, keep_k=None, k_period=0):
+    gemm(a, b, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, bias=bias, scale=scale, keep_n=keep_n, resid=resid,
+         rows_in=rows_in, keep_k=keep_k, k_period=k_period)
+    return ln_fwd(out, ln_w, ln_b, ln_keep, rows_in or M, eps, torch.bfloat16)
+
+
+def gemm_ln_bwd(du, wt, x, ln_w, mean, rstd, ln_keep, dx_in, dw, db, next_cast=None, *, M, N, K, lda, ldb, rows_in=0,
+                keep_k=None, k_period=0):
+    dy = torch.empty(x.shape, dtype=torch.float32)
+    gemm(du.float(), wt.float(), dy, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, rows_in=rows_in, keep_k=keep_k, k_period=k_period)
+    out = ln_bwd(dy, x, ln_w, mean, rstd, ln_keep, rows_in or M, dx_in, dw, db, next_cast=next_cast)
+    return out if next_cast is None else (out[0], out[1].to(torch.bfloat16))
+
+
 def attn_fwd(qkv, keep_hd, B, N, H, D, scale):
     q, k, v = qkv.float().view(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
     s = (q @ k.transpose(-2, -1)) * scale
@@ -334,7 +353,7 @@ def patch_fold(col, B, gh, gw, P, C):
     return x.reshape(B * gh * P * gw * P, C).clone()
 
 
-ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "attn_fwd", "attn_bwd", "softce", "colsum", "scale_mask_cast",
+ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "colsum", "scale_mask_cast",
        "batchsum", "conv3x3", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
 
 

@@ -392,3 +392,85 @@ def test_attention_long_sequences(N, H, D):
     dq = K.attn_bwd(qkv.to(DEV), o, d_o.to(DEV), lse, keep.to(DEV), B, N, H, D, scale)
     dqr = E.attn_bwd(qkv, orf, d_o, lser, keep, B, N, H, D, scale)
     assert relerr(dq, dqr) < 2.5e-2, relerr(dq, dqr)
+
+
+# ---- vr_gemm_ln: Linear with the adjacent LayerNorm in its epilogue (gemm_nt_ln.hip) -------------------------------
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("B,Nt,C,Kd,masked", [(6, 257, 256, 768, True), (4, 65, 512, 1536, True), (3, 50, 192, 256, False),
+                                              (5, 17, 448, 128, True), (2, 33, 8, 72, False)])
+def test_gemm_ln_forward(B, Nt, C, Kd, masked):
+    """mode 0 == vr_gemm (residual epilogue) followed by vr_ln_fwd: same residual stream bit for bit (same MFMA order is not
+    required: compared with tolerance), LayerNorm output / statistics within bf16 / fp32 rounding."""
+    M = B * Nt
+    a, w = _bf(rnd(M, Kd, seed=1)), _bf(rnd(C, Kd, seed=2, scale=Kd ** -0.5))
+    bias, resid = rnd(C, seed=3), rnd(M, C, seed=4)
+    lw, lb = 1 + 0.1 * rnd(C, seed=5), 0.1 * rnd(C, seed=6)
+    scale = (torch.rand(B, generator=torch.Generator().manual_seed(7)) > 0.3).float() / 0.7 if masked else None
+    keep_n = torch.tensor([C - 8 * (i % 3) for i in range(B)], dtype=torch.int32) if masked else None
+    ln_keep = torch.tensor([C - 16 * (i % 2) - 8 * (i % 3) for i in range(B)], dtype=torch.int32) if masked else None
+    keep_k = torch.tensor([Kd - 64 * (i % 2) for i in range(B)], dtype=torch.int32) if masked else None
+    if keep_k is not None:                                   # the producer zeroes masked K columns (contract of keep_k)
+        a = a.view(B, Nt, Kd).clone()
+        for i in range(B):
+            a[i, :, int(keep_k[i]):] = 0
+        a = a.view(M, Kd)
+    kw = dict(M=M, N=C, K=Kd, lda=Kd, ldb=Kd, ldc=C, bias=bias, scale=scale, keep_n=keep_n, resid=resid, rows_in=Nt, keep_k=keep_k)
+    out_ref = torch.empty(M, C)
+    y_ref, mu_ref, rs_ref = E.gemm_ln_fwd(a, w, out_ref, lw, lb, ln_keep, 1e-6, **kw)
+    cu = lambda t: None if t is None else t.to(DEV)
+    out = torch.empty(M, C, device=DEV)
+    kw_d = {k: (cu(v) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+    assert K.gemm_ln_supported(cu(a), C, C)
+    y, mu, rs = K.gemm_ln_fwd(cu(a), cu(w), out, cu(lw), cu(lb), cu(ln_keep), 1e-6, **kw_d)
+    torch.cuda.synchronize()
+    assert relerr(out, out_ref) < 2e-5
+    assert relerr(mu, mu_ref) < 2e-5 and relerr(rs, rs_ref) < 1e-4
+    assert relerr(y, y_ref) < 1.2e-2
+    # against the two separate kernels on the device: the LayerNorm of the SAME residual stream
+    y2, mu2, rs2 = K.ln_fwd(out, cu(lw), cu(lb), cu(ln_keep), Nt, 1e-6, torch.bfloat16)
+    assert relerr(mu, mu2) < 1e-5 and relerr(rs, rs2) < 1e-4
+    assert float((y.float() - y2.float()).abs().max()) <= 2 ** -6 * float(y2.float().abs().max())
+
+
+@pytest.mark.parametrize("B,Nt,C,Kd,masked,nxt", [(6, 257, 256, 768, True, True), (4, 65, 512, 1536, True, True),
+                                                  (3, 50, 192, 256, False, False), (5, 17, 448, 192, True, False),
+                                                  (2, 33, 8, 72, False, True)])
+def test_gemm_ln_backward(B, Nt, C, Kd, masked, nxt):
+    """mode 1 == data-gradient GEMM (fp32 result) followed by vr_ln_bwd."""
+    M = B * Nt
+    du, wt = _bf(rnd(M, Kd, seed=1)), _bf(rnd(C, Kd, seed=2, scale=Kd ** -0.5))
+    x, dx_in = rnd(M, C, seed=3), rnd(M, C, seed=4)
+    lw = 1 + 0.1 * rnd(C, seed=5)
+    ln_keep = torch.tensor([C - 16 * (i % 2) - 8 * (i % 3) for i in range(B)], dtype=torch.int32) if masked else None
+    keep_k = torch.tensor([Kd - 64 * (i % 2) for i in range(B)], dtype=torch.int32) if masked else None
+    if keep_k is not None:
+        du = du.view(B, Nt, Kd).clone()
+        for i in range(B):
+            du[i, :, int(keep_k[i]):] = 0
+        du = du.view(M, Kd)
+    _, mean, rstd = E.ln_fwd(x, lw, torch.zeros(C), ln_keep, Nt, 1e-6, torch.float32)
+    nc = None
+    if nxt:
+        nc = ((torch.rand(B, generator=torch.Generator().manual_seed(9)) > 0.3).float() / 0.7,
+              torch.tensor([C - 8 * (i % 4) for i in range(B)], dtype=torch.int32))
+    dw_ref, db_ref = torch.zeros(C), torch.zeros(C)
+    ref = E.gemm_ln_bwd(du, wt, x, lw, mean, rstd, ln_keep, dx_in, dw_ref, db_ref, next_cast=nc, M=M, N=C, K=Kd, lda=Kd, ldb=Kd,
+                        rows_in=Nt, keep_k=keep_k)
+    cu = lambda t: None if t is None else t.to(DEV)
+    dw, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    real = K.gemm_ln_bwd(cu(du), cu(wt), cu(x), cu(lw), cu(mean), cu(rstd), cu(ln_keep), cu(dx_in), dw, db,
+                         next_cast=None if nc is None else (cu(nc[0]), cu(nc[1])), M=M, N=C, K=Kd, lda=Kd, ldb=Kd, rows_in=Nt,
+                         keep_k=cu(keep_k))
+    torch.cuda.synchronize()
+    dx, dx_ref = (real[0], ref[0]) if nxt else (real, ref)
+    assert relerr(dx, dx_ref) < 5e-5
+    assert relerr(dw, dw_ref) < 1e-4 and relerr(db, db_ref) < 1e-4
+    if nxt:
+        assert relerr(real[1], ref[1]) < 1.2e-2
+        if masked:
+            for i in range(B):
+                tail = real[1].view(B, Nt, C)[i, :, int(nc[1][i]):]
+                assert tail.numel() == 0 or float(tail.abs().max()) == 0.0

@@ -394,3 +394,34 @@ def test_model_at_280px_uses_long_attention():
     pr = dict(orc.named_parameters())
     for n in ("blocks.0.attn.qkv.weight", "blocks.0.attn.proj.weight", "cls_head.weight"):
         assert rel(dict(prod.named_parameters())[n].grad, pr[n].grad) < 8e-2, n
+
+
+@pytest.mark.gpu
+def test_fused_layernorm_kernels_match_separate_kernels(monkeypatch):
+    """functional.FUSE_LN=3 (opt-in vr_gemm_ln: LayerNorm forward / backward in the epilogue of the neighbouring Linear) gives
+    the logits and gradients of the default vr_gemm + vr_ln_fwd / vr_ln_bwd sequence within bf16 rounding."""
+    import vitres.functional as Fn
+    from vitres.losses import SoftTargetCrossEntropy
+    prod, orc, sd = build_pair(0, "multi", 100)
+    prod.set_compute_dtype(torch.bfloat16)
+    prod.train()
+    prod.set_epoch(31)
+    prod.load_state_dict(sd)
+    crit = SoftTargetCrossEntropy()
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1))
+
+    def run(fuse):
+        monkeypatch.setattr(Fn, "FUSE_LN", fuse)
+        torch.manual_seed(701)
+        for p in prod.parameters():
+            p.grad = None
+        out = prod(x, patch_output_type="seq")
+        loss = crit(out[0], t) + crit(out[1], pt)
+        loss.backward()
+        torch.cuda.synchronize()
+        return out[0].detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in prod.named_parameters()}
+    c0, g0 = run(0)
+    c3, g3 = run(3)
+    assert rel(c3, c0) < 2e-2
+    worst = max(rel(g3[n], g0[n]) for n in g0 if float(g0[n].abs().max()) > 0)
+    assert worst < 6e-2, worst

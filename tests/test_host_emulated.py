@@ -160,3 +160,33 @@ def test_cpu_tensor_is_refused():
     prod, _, _ = build_pair(0, "plain", 100)
     with pytest.raises(RuntimeError):
         prod(torch.zeros(2, 3, 56, 56))
+
+
+def test_emulated_fused_layernorm_path_equals_separate_kernels(monkeypatch):
+    """functional.FUSE_LN (vr_gemm_ln: the LayerNorm computed in the epilogue of the Linear before / after it, opt-in) only
+    re-routes kernel calls: the same logits and gradients as the separate vr_gemm + vr_ln_fwd / vr_ln_bwd sequence."""
+    import vitres.functional as Fn
+    emu_kernels.install(monkeypatch)
+    prod, orc, sd = build_pair(0, "multi", 100)
+    prod.set_compute_dtype(torch.bfloat16)
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    prod.train()
+    prod.set_epoch(31)
+    calls = []
+    real_fwd, real_bwd = emu_kernels.gemm_ln_fwd, emu_kernels.gemm_ln_bwd
+    import vitres.kernels as K
+    monkeypatch.setattr(K, "gemm_ln_fwd", lambda *a, **k: (calls.append("f"), real_fwd(*a, **k))[1])
+    monkeypatch.setattr(K, "gemm_ln_bwd", lambda *a, **k: (calls.append("b"), real_bwd(*a, **k))[1])
+
+    def run(fuse):
+        monkeypatch.setattr(Fn, "FUSE_LN", fuse)
+        torch.manual_seed(5)
+        prod.zero_grad(set_to_none=True)
+        cls, pat = prod(x, patch_output_type="seq")
+        (O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)).backward()
+        return cls.detach().clone(), prod._arena["gcur"].clone()
+    c0, g0 = run(0)
+    assert not calls
+    c3, g3 = run(3)
+    assert "f" in calls and "b" in calls
+    assert rel(c3, c0) < 2e-2 and rel(g3, g0) < 5e-2          # bf16 mode: the fused backward keeps dy in fp32 instead of bf16

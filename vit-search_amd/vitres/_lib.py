@@ -32,10 +32,18 @@ class GemmArgs(ctypes.Structure):
     ]
 
 
+class LnEpilogue(ctypes.Structure):
+    _fields_ = [("mode", c_int32), ("eps", c_float), ("w", c_void_p), ("b", c_void_p), ("keep", c_void_p), ("y", c_void_p),
+                ("mean", c_void_p), ("rstd", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("db", c_void_p),
+                ("gt_out", c_void_p), ("gt_scale", c_void_p), ("gt_keep", c_void_p)]
+
+
 # name -> argtypes ; every entry point returns int.  Must list every symbol of include/vitres_hip.h
 SYMBOLS = {
     "vr_version": [],
     "vr_gemm": [ctypes.POINTER(GemmArgs), c_void_p],
+    "vr_gemm_ln": [ctypes.POINTER(GemmArgs), ctypes.POINTER(LnEpilogue), c_void_p],
+    "vr_gemm_ln_supported": [c_int32],
     "vr_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "vr_adamw_flat": [c_void_p] * 6 + [c_float, c_void_p, c_void_p, c_int32, c_int64, c_void_p],
     "vr_cast_transpose_batch": [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p],

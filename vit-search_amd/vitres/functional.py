@@ -28,6 +28,12 @@ DEFER_JOIN = _os.environ.get('VITRES_OVERLAP', '1') == '2'
 JOIN_PER_BLOCK = _os.environ.get('VITRES_OVERLAP', '1') == '3'
 FUSE_CAST = _os.environ.get('VITRES_FUSE_CAST', '1') != '0'      # LayerNorm backward also emits the next branch's gradient
 PROJ_LATE = _os.environ.get('VITRES_PROJ_LATE', '0') != '0'      # issue proj's weight gradient after the attention core
+# vr_gemm_ln (gemm_nt_ln.hip), opt-in: bit 0 = LayerNorm forward in the epilogue of the Linear that produces its input, bit 1 =
+# LayerNorm backward in the epilogue of the data-gradient GEMM that produces its gradient.  Measured on the sr_tiny step: the
+# separate kernels already stream at ~4 TB/s, whole-row tiles (64 x 256 / 32 x 512) re-stream the weights per 64 / 32 rows and
+# leave a CU 2-3 workgroups: forward fusion +0.5 % at width 256, -3 % with width 512 included; backward fusion -25 % (spills).
+FUSE_LN = int(_os.environ.get('VITRES_FUSE_LN', '0'))
+FUSE_LN_MAXN = int(_os.environ.get('VITRES_FUSE_LN_MAXN', '512'))
 STEM_SIDE = _os.environ.get('VITRES_STEM_SIDE', '0') != '0'      # conv-stem weight gradients on the side stream: measured slower
 _side_streams = {}
 
@@ -37,14 +43,24 @@ _lagged = []             # [(event recorded on the side stream, tensors)]: gener
 JOIN_LAG = int(_os.environ.get('VITRES_JOIN_LAG', '2'))   # branches a join may trail behind (0: join at once)
 
 
-def on_side(fn, *keepalive):
-    """Run fn() on the side stream after everything queued so far on the current stream; the tensors it reads are kept
-    alive (so the caching allocator cannot hand them out again) until join_side()."""
-    main = torch.cuda.current_stream()
-    dev = main.device
+N_SIDE = max(1, int(_os.environ.get('VITRES_SIDE_STREAMS', '1')))   # side streams used round-robin
+_rr = [0]
+
+
+def _sides(dev):
     side = _side_streams.get(dev)
     if side is None:
-        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+        side = _side_streams[dev] = [torch.cuda.Stream(device=dev) for _ in range(N_SIDE)]
+    return side
+
+
+def on_side(fn, *keepalive):
+    """Run fn() on a side stream after everything queued so far on the current stream; the tensors it reads are kept
+    alive (so the caching allocator cannot hand them out again) until join_side()."""
+    main = torch.cuda.current_stream()
+    sides = _sides(main.device)
+    side = sides[_rr[0] % len(sides)]
+    _rr[0] += 1
     side.wait_stream(main)
     with torch.cuda.stream(side):
         fn()
@@ -55,8 +71,7 @@ def join_side():
     """Current stream waits for ALL side-stream work issued so far (and releases every tensor kept for it)."""
     if _pending or _side_streams:
         main = torch.cuda.current_stream()
-        side = _side_streams.get(main.device)
-        if side is not None:
+        for side in _side_streams.get(main.device, ()):
             main.wait_stream(side)
     _pending.clear()
     _lagged.clear()
@@ -70,15 +85,16 @@ def join_side_lagged():
     if JOIN_LAG <= 0:
         return join_side()
     main = torch.cuda.current_stream()
-    side = _side_streams.get(main.device)
-    if side is None:
+    sides = _side_streams.get(main.device)
+    if sides is None:
         _pending.clear()
         return
-    _lagged.append((side.record_event(), list(_pending)))
+    _lagged.append(([sd.record_event() for sd in sides], list(_pending)))
     _pending.clear()
     while len(_lagged) > JOIN_LAG:
-        ev, _keep = _lagged.pop(0)
-        main.wait_event(ev)
+        evs, _keep = _lagged.pop(0)
+        for ev in evs:
+            main.wait_event(ev)
 
 
 def _overlap(x):
@@ -115,22 +131,34 @@ def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_m
 # --------------------------------------------------------------------------------------------------
 # transformer block halves
 # --------------------------------------------------------------------------------------------------
-def attn_branch_fwd(x, p, cfg, embed_keep, attn_keep, out_keep, scale, save):
+def _ln_fusable(a, C, next_ln):
+    return next_ln is not None and (FUSE_LN & 1) and C <= FUSE_LN_MAXN and K.gemm_ln_supported(a, C, C)
+
+
+def attn_branch_fwd(x, p, cfg, embed_keep, attn_keep, out_keep, scale, save, pre=None, next_ln=None):
+    """pre: (y, mean, rstd) of norm1(x) when the producer of x already computed it; next_ln = (w, b, keep, eps) of the
+    LayerNorm that consumes this branch's output -> third result (y, mean, rstd) of it, or None when it was not fused."""
     B, N, C = x.shape
     M = B * N
     H, D = cfg["heads"], cfg["head_dim"]
     HD = H * D
     dt = cfg["dtype"]
-    y, mean, rstd = K.ln_fwd(x, p["n1w"], p["n1b"], embed_keep, N, cfg["eps"], dt)
+    y, mean, rstd = pre if pre is not None else K.ln_fwd(x, p["n1w"], p["n1b"], embed_keep, N, cfg["eps"], dt)
     qkv = torch.empty((B, N, 3 * HD), dtype=dt, device=x.device)
     K.gemm(y, p["qkv"].w_c, qkv, M=M, N=3 * HD, K=C, lda=C, ldb=p["qkv"].ld, ldc=3 * HD, bias=p["qkv"].b, rows_in=N,
            keep_k=embed_keep, keep_n=attn_keep, n_period=HD)
     o, lse = K.attn_fwd(qkv, attn_keep, B, N, H, D, cfg["scale"])
     x1 = torch.empty_like(x)
-    K.gemm(o, p["proj"].w_c, x1, M=M, N=C, K=HD, lda=HD, ldb=p["proj"].ld, ldc=C, bias=p["proj"].b, scale=scale,
-           keep_n=out_keep, resid=x, rows_in=N, keep_k=attn_keep)
+    post = None
+    if _ln_fusable(o, C, next_ln):
+        post = K.gemm_ln_fwd(o, p["proj"].w_c, x1, next_ln[0], next_ln[1], next_ln[2], next_ln[3], M=M, N=C, K=HD, lda=HD,
+                             ldb=p["proj"].ld, ldc=C, bias=p["proj"].b, scale=scale, keep_n=out_keep, resid=x, rows_in=N,
+                             keep_k=attn_keep)
+    else:
+        K.gemm(o, p["proj"].w_c, x1, M=M, N=C, K=HD, lda=HD, ldb=p["proj"].ld, ldc=C, bias=p["proj"].b, scale=scale,
+               keep_n=out_keep, resid=x, rows_in=N, keep_k=attn_keep)
     saved = (x, mean, rstd, y, qkv, o, lse) if save else None
-    return x1, saved
+    return x1, saved, post
 
 
 def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, scale, gt=None, next_cast=None):
@@ -167,30 +195,41 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
         on_side(wgrad_qkv, dqkv)
     else:
         wgrad_qkv()
-    dy = torch.empty((B, N, C), dtype=dt, device=x.device)
-    linear_dgrad(dqkv, p["qkv"], dy, M, C, 3 * HD, 3 * HD, C, rows_in=N, keep_k=attn_keep, k_period=HD, keep_n=embed_keep,
-                 sched=sch)
-    out = K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, grads["n1w"], grads["n1b"], next_cast=next_cast)
+    if (FUSE_LN & 2) and C <= FUSE_LN_MAXN and p["qkv"].w_t is not None and K.gemm_ln_supported(dqkv, C, C):
+        out = K.gemm_ln_bwd(dqkv, p["qkv"].w_t, x, p["n1w"], mean, rstd, embed_keep, g, grads["n1w"], grads["n1b"],
+                            next_cast=next_cast, M=M, N=C, K=3 * HD, lda=3 * HD, ldb=p["qkv"].ld_t, rows_in=N,
+                            keep_k=attn_keep, k_period=HD)
+    else:
+        dy = torch.empty((B, N, C), dtype=dt, device=x.device)
+        linear_dgrad(dqkv, p["qkv"], dy, M, C, 3 * HD, 3 * HD, C, rows_in=N, keep_k=attn_keep, k_period=HD, keep_n=embed_keep,
+                     sched=sch)
+        out = K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, grads["n1w"], grads["n1b"], next_cast=next_cast)
     if ov and not DEFER_JOIN:
         join_side_lagged()
     return out
 
 
-def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save):
+def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save, pre=None, next_ln=None):
     B, N, C = x.shape
     M = B * N
     F = cfg["hidden"]
     dt = cfg["dtype"]
-    y, mean, rstd = K.ln_fwd(x, p["n2w"], p["n2b"], embed_keep, N, cfg["eps"], dt)
+    y, mean, rstd = pre if pre is not None else K.ln_fwd(x, p["n2w"], p["n2b"], embed_keep, N, cfg["eps"], dt)
     u = torch.empty((B, N, F), dtype=dt, device=x.device)
     h = torch.empty((B, N, F), dtype=dt, device=x.device)
     K.gemm(y, p["fc1"].w_c, u, out2=h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b, act=1,
            keep_n=mlp_keep, rows_in=N, keep_k=embed_keep)
     x2 = torch.empty_like(x)
-    K.gemm(h, p["fc2"].w_c, x2, M=M, N=C, K=F, lda=F, ldb=p["fc2"].ld, ldc=C, bias=p["fc2"].b, scale=scale,
-           keep_n=out_keep, resid=x, rows_in=N, keep_k=mlp_keep)
+    post = None
+    if _ln_fusable(h, C, next_ln):
+        post = K.gemm_ln_fwd(h, p["fc2"].w_c, x2, next_ln[0], next_ln[1], next_ln[2], next_ln[3], M=M, N=C, K=F, lda=F,
+                             ldb=p["fc2"].ld, ldc=C, bias=p["fc2"].b, scale=scale, keep_n=out_keep, resid=x, rows_in=N,
+                             keep_k=mlp_keep)
+    else:
+        K.gemm(h, p["fc2"].w_c, x2, M=M, N=C, K=F, lda=F, ldb=p["fc2"].ld, ldc=C, bias=p["fc2"].b, scale=scale,
+               keep_n=out_keep, resid=x, rows_in=N, keep_k=mlp_keep)
     saved = (x, mean, rstd, y, u, h) if save else None
-    return x2, saved
+    return x2, saved, post
 
 
 def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scale, gt=None, next_cast=None):
@@ -221,9 +260,13 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
         on_side(wgrad_fc1, du)
     else:
         wgrad_fc1()
-    dy = torch.empty((B, N, C), dtype=dt, device=x.device)
-    linear_dgrad(du, p["fc1"], dy, M, C, F, F, C, rows_in=N, keep_k=mlp_keep, keep_n=embed_keep, sched=sch)
-    out = K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"], next_cast=next_cast)
+    if (FUSE_LN & 2) and C <= FUSE_LN_MAXN and p["fc1"].w_t is not None and K.gemm_ln_supported(du, C, C):
+        out = K.gemm_ln_bwd(du, p["fc1"].w_t, x, p["n2w"], mean, rstd, embed_keep, g, grads["n2w"], grads["n2b"],
+                            next_cast=next_cast, M=M, N=C, K=F, lda=F, ldb=p["fc1"].ld_t, rows_in=N, keep_k=mlp_keep)
+    else:
+        dy = torch.empty((B, N, C), dtype=dt, device=x.device)
+        linear_dgrad(du, p["fc1"], dy, M, C, F, F, C, rows_in=N, keep_k=mlp_keep, keep_n=embed_keep, sched=sch)
+        out = K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"], next_cast=next_cast)
     if ov and not DEFER_JOIN and not JOIN_PER_BLOCK:
         join_side_lagged()
     return out
@@ -232,14 +275,14 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
 # --------------------------------------------------------------------------------------------------
 # spatial-reduction block
 # --------------------------------------------------------------------------------------------------
-def sr_fwd(x, p, cfg, embed_keep, new_keep, save):
+def sr_fwd(x, p, cfg, embed_keep, new_keep, save, pre=None):
     B, Ni, C = x.shape
     g = cfg["grid"]
     go = g // 2
     No = 1 + go * go
     Co = cfg["cout"]
     dt = cfg["dtype"]
-    y, mean, rstd = K.ln_fwd(x, p["nw"], p["nb"], embed_keep, Ni, cfg["eps"], dt)
+    y, mean, rstd = pre if pre is not None else K.ln_fwd(x, p["nw"], p["nb"], embed_keep, Ni, cfg["eps"], dt)
     out = K.sr_resid(x, B, g, C, Co)
     col = K.sr_im2col(y, B, g, C)
     K.gemm(col, p["reduce"].w_c, out, M=B * go * go, N=Co, K=9 * C, lda=9 * C, ldb=p["reduce"].ld, ldc=Co,
@@ -320,11 +363,11 @@ def embed0_bwd(g, saved, p, grads, cfg, keep, gt=None):
 # --------------------------------------------------------------------------------------------------
 # final norm + heads
 # --------------------------------------------------------------------------------------------------
-def head_fwd(x, p, cfg, keep, with_patch, save):
+def head_fwd(x, p, cfg, keep, with_patch, save, pre=None):
     B, N, C = x.shape
     dt = cfg["dtype"]
     nc = cfg["classes"]
-    y, mean, rstd = K.ln_fwd(x, p["nw"], p["nb"], keep, N, cfg["eps"], dt)
+    y, mean, rstd = pre if pre is not None else K.ln_fwd(x, p["nw"], p["nb"], keep, N, cfg["eps"], dt)
     cls = torch.empty((B, nc), dtype=torch.float32, device=x.device)
     K.gemm(y, p["cls"].w_c, cls, M=B, N=nc, K=C, lda=C, ldb=p["cls"].ld, ldc=nc, bias=p["cls"].b, a_map=(1, N, 0))
     pat, ym = None, None

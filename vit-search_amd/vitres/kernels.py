@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import GemmArgs, RowMap, VR_BF16, VR_F32
+from ._lib import GemmArgs, LnEpilogue, RowMap, VR_BF16, VR_F32
 
 IDENT = (0, 0, 0)
 
@@ -46,10 +46,9 @@ def _rm(m):
     return RowMap(*(m or IDENT))
 
 
-def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
-         scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
-         a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0):
-    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T) -- see vr_gemm in include/vitres_hip.h."""
+def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
+               scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
+               a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0):
     args = GemmArgs()
     args.A, args.B, args.C, args.C2 = _p(a), _p(b), _p(out), _p(out2)
     args.bias, args.pos, args.scale, args.keep_n = _p(bias), _p(pos), _p(scale), _p(keep_n)
@@ -62,6 +61,80 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     assert b.dtype == a.dtype, "A and B must share a dtype"
     args.act, args.atomic, args.split_k, args.rows_in = act, int(atomic), split_k, rows_in
     args.a_map, args.b_map, args.c_map = _rm(a_map), _rm(b_map), _rm(c_map)
+    return args
+
+
+def gemm_ln_supported(a, N, ldc):
+    """vr_gemm_ln covers this Linear (bf16 operands, whole rows in one tile)."""
+    return a.dtype == torch.bfloat16 and N == ldc and bool(_lib.lib().vr_gemm_ln_supported(N))
+
+
+def _kept_flops(M, N, K, rows_in, keep_k, keep_n, k_period=0):
+    def kept(keep, dim, period):
+        if keep is None:
+            return None
+        k = keep.detach().to("cpu", torch.float64)
+        return torch.clamp(k, max=period) * (dim // period) if period else torch.clamp(k, max=dim)
+    kk, kn = kept(keep_k, K, k_period), kept(keep_n, N, 0)
+    if kk is None and kn is None:
+        return 2.0 * M * N * K
+    nb = len(kk if kk is not None else kn)
+    kk = kk if kk is not None else torch.full((nb,), float(K), dtype=torch.float64)
+    kn = kn if kn is not None else torch.full((nb,), float(N), dtype=torch.float64)
+    return float((2.0 * rows_in * kk * kn).sum())
+
+
+def _launch_gemm_ln(args, ln, a, M, N, K, rows_in, keep_k, keep_n, k_period, extra_bytes):
+    if PROFILE is None:
+        _lib.check(_lib.lib().vr_gemm_ln(ctypes.byref(args), ctypes.byref(ln), _stream()), "vr_gemm_ln")
+        return
+    flops = _kept_flops(M, N, K, rows_in, keep_k, keep_n, k_period)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(_lib.lib().vr_gemm_ln(ctypes.byref(args), ctypes.byref(ln), _stream()), "vr_gemm_ln")
+    e1.record()
+    PROFILE.append((("bf16", 0, 0, 2), flops, 2.0 * M * N * K, float((M * K + N * K) * 2 + extra_bytes), e0, e1))
+
+
+def gemm_ln_fwd(a, b, out, ln_w, ln_b, ln_keep, eps, *, M, N, K, lda, ldb, ldc, bias=None, scale=None, keep_n=None,
+                resid=None, rows_in=0, keep_k=None, k_period=0):
+    """out = resid + scale * mask(a @ b^T + bias) (fp32) and (y, mean, rstd) = masked LayerNorm(out) -- vr_gemm_ln mode 0."""
+    args = _gemm_args(a, b, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, bias=bias, scale=scale, keep_n=keep_n, resid=resid,
+                      rows_in=rows_in, keep_k=keep_k, k_period=k_period)
+    y = torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
+    mean = torch.empty(M, dtype=torch.float32, device=out.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=out.device)
+    ln = LnEpilogue()
+    ln.mode, ln.eps = 0, eps
+    ln.w, ln.b, ln.keep, ln.y, ln.mean, ln.rstd = _p(ln_w), _p(ln_b), _p(ln_keep), _p(y), _p(mean), _p(rstd)
+    _launch_gemm_ln(args, ln, a, M, N, K, rows_in, keep_k, keep_n, k_period, M * N * (4 + 4 + 2))
+    return y, mean, rstd
+
+
+def gemm_ln_bwd(du, wt, x, ln_w, mean, rstd, ln_keep, dx_in, dw, db, next_cast=None, *, M, N, K, lda, ldb, rows_in=0,
+                keep_k=None, k_period=0):
+    """LayerNorm backward of dy = du @ wt^T without writing dy -- vr_gemm_ln mode 1; returns dx or (dx, gt) like ln_bwd."""
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    gt = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if next_cast is not None else None
+    sc, kp = next_cast if next_cast is not None else (None, None)
+    args = _gemm_args(du, wt, dx, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, resid=dx_in, rows_in=rows_in, keep_k=keep_k,
+                      k_period=k_period)
+    ln = LnEpilogue()
+    ln.mode, ln.eps = 1, 0.0
+    ln.w, ln.keep, ln.mean, ln.rstd, ln.x = _p(ln_w), _p(ln_keep), _p(mean), _p(rstd), _p(x)
+    ln.dw, ln.db, ln.gt_out, ln.gt_scale, ln.gt_keep = _p(dw), _p(db), _p(gt), _p(sc), _p(kp)
+    _launch_gemm_ln(args, ln, du, M, N, K, rows_in, keep_k, ln_keep, k_period, M * N * (4 + 4 + 4 + 2))
+    return dx if next_cast is None else (dx, gt)
+
+
+def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
+         scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
+         a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0):
+    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T) -- see vr_gemm in include/vitres_hip.h."""
+    args = _gemm_args(a, b, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, a_trans=a_trans, b_trans=b_trans, out2=out2,
+                      bias=bias, pos=pos, scale=scale, keep_n=keep_n, resid=resid, dact_u=dact_u, ldu=ldu, act=act,
+                      atomic=atomic, split_k=split_k, rows_in=rows_in, a_map=a_map, b_map=b_map, c_map=c_map,
+                      bias_grad=bias_grad, keep_k=keep_k, n_period=n_period, k_period=k_period, sched=sched)
     if PROFILE is None:
         _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
         return out

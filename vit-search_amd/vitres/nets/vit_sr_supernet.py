@@ -546,31 +546,48 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             else:
                 K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"])
         grid = self.img_size // self.patch_size
-        for blk, L in zip(self.blocks, plan.layers[1:]):
-            if L is None:
-                continue
-            p, cfg = self._layer_params(blk), self._layer_cfg(blk, grid)
-            if isinstance(blk, Block):
-                s1 = s2 = None
-                if L["dp"] is not None:
-                    s1, s2 = plan.scales[L["dp"]], plan.scales[L["dp"] + 1]
-                ek, ka, km, ko = plan.k(L["embed"]), plan.k(L["attn"]), plan.k(L["mlp"]), plan.k(L["out"])
-                h, sa = Fn.attn_branch_fwd(h, p, cfg, ek, ka, ko, s1, save)
-                h, sm = Fn.mlp_branch_fwd(h, p, cfg, ek, km, ko, s2, save)
-                if save:
-                    tape.append(("block", blk, p, cfg, (ek, ka, km, ko, s1, s2), sa, sm))
-            else:
-                ek, nk = plan.k(L["embed"]), plan.k(L["new"])
-                h, sv = Fn.sr_fwd(h, p, cfg, ek, nk, save)
-                if save:
-                    tape.append(("sr", blk, p, cfg, (ek, nk), sv))
-                grid //= 2
         hp = {"nw": self.norm.weight.detach(), "nb": self.norm.bias.detach(), "cls": self._lin(self.cls_head)}
         if with_patch:
             hp["patch"] = self._lin(self.patch_head)
         hcfg = {"dtype": self.compute_dtype, "eps": 1e-6, "classes": self.num_classes}
         hk = plan.k(plan.head)
-        cls, pat, sv = Fn.head_fwd(h, hp, hcfg, hk, with_patch, save)
+        seq = []
+        for blk, L in zip(self.blocks, plan.layers[1:]):
+            if L is None:
+                continue
+            seq.append((blk, L, self._layer_params(blk), self._layer_cfg(blk, grid)))
+            if not isinstance(blk, Block):
+                grid //= 2
+
+        def first_ln(i):
+            """(w, b, keep, eps) of the LayerNorm layer i of `seq` starts with (the head's norm past the end): its producer
+            computes it in its own epilogue when it can (functional.FUSE_LN)."""
+            if i >= len(seq):
+                return hp["nw"], hp["nb"], hk, hcfg["eps"]
+            blk_, L_, p_, cfg_ = seq[i]
+            if isinstance(blk_, Block):
+                return p_["n1w"], p_["n1b"], plan.k(L_["embed"]), cfg_["eps"]
+            return p_["nw"], p_["nb"], plan.k(L_["embed"]), cfg_["eps"]
+
+        pre = None
+        for i, (blk, L, p, cfg) in enumerate(seq):
+            if isinstance(blk, Block):
+                s1 = s2 = None
+                if L["dp"] is not None:
+                    s1, s2 = plan.scales[L["dp"]], plan.scales[L["dp"] + 1]
+                ek, ka, km, ko = plan.k(L["embed"]), plan.k(L["attn"]), plan.k(L["mlp"]), plan.k(L["out"])
+                h, sa, pre = Fn.attn_branch_fwd(h, p, cfg, ek, ka, ko, s1, save, pre=pre,
+                                                next_ln=(p["n2w"], p["n2b"], ek, cfg["eps"]))
+                h, sm, pre = Fn.mlp_branch_fwd(h, p, cfg, ek, km, ko, s2, save, pre=pre, next_ln=first_ln(i + 1))
+                if save:
+                    tape.append(("block", blk, p, cfg, (ek, ka, km, ko, s1, s2), sa, sm))
+            else:
+                ek, nk = plan.k(L["embed"]), plan.k(L["new"])
+                h, sv = Fn.sr_fwd(h, p, cfg, ek, nk, save, pre=pre)
+                pre = None
+                if save:
+                    tape.append(("sr", blk, p, cfg, (ek, nk), sv))
+        cls, pat, sv = Fn.head_fwd(h, hp, hcfg, hk, with_patch, save, pre=pre)
         if save:
             tape.append(("head", hp, hcfg, hk, sv))
         return cls, pat, tape
