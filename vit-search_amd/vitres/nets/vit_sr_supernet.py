@@ -527,6 +527,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 K.cast_bf16(a["flat"], a["shadow"])
         B = x.shape[0]
         tape = [] if save else None
+        side_params = {}
         ecfg = {"dtype": self.compute_dtype, "patch": self.patch_size, "patches": self.patch_embed.num_patches,
                 "dim": self.embed_dim}
         ep = self._embed_params()
@@ -542,7 +543,19 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             # only the backward needs W^T: refresh it beside the forward, after the HBM-bound patch gather (joined at the
             # start of _run_backward)
             if Fn.OVERLAP and a["flat"].is_cuda:
-                Fn.on_side(lambda: K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"]))
+                # also off the critical path, beside the first stage: the re-laid-out conv weights of the spatial reductions
+                # (torch permute / cast / transpose) and the zeroing of the gradient arena the backward accumulates into
+                fresh = a["gflat"] is not None and all(p_.grad is None for p_ in a["params"])
+
+                def side_prep():
+                    K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"])
+                    for blk_ in self.blocks:
+                        if isinstance(blk_, SpatialReductionPatchEmbedding):
+                            side_params[id(blk_)] = self._layer_params(blk_)
+                    if fresh:
+                        a["gflat"].zero_()
+                Fn.on_side(side_prep)
+                a["gzeroed"] = fresh
             else:
                 K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"])
         grid = self.img_size // self.patch_size
@@ -555,7 +568,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         for blk, L in zip(self.blocks, plan.layers[1:]):
             if L is None:
                 continue
-            seq.append((blk, L, self._layer_params(blk), self._layer_cfg(blk, grid)))
+            seq.append((blk, L, side_params.get(id(blk)) or self._layer_params(blk), self._layer_cfg(blk, grid)))
             if not isinstance(blk, Block):
                 grid //= 2
 
@@ -582,6 +595,9 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 if save:
                     tape.append(("block", blk, p, cfg, (ek, ka, km, ko, s1, s2), sa, sm))
             else:
+                if side_params:
+                    Fn.join_side()         # its weights were re-laid out on the side stream
+                    side_params = {}
                 ek, nk = plan.k(L["embed"]), plan.k(L["new"])
                 h, sv = Fn.sr_fwd(h, p, cfg, ek, nk, save, pre=pre)
                 pre = None
@@ -602,8 +618,9 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         # grads already live in the arena (no zero_grad since the last backward): use a scratch arena so that
         # autograd's accumulation adds a separate buffer
         a["gcur"] = a["gflat"] if fresh else torch.zeros_like(a["flat"])
-        if fresh:
+        if fresh and not a.pop("gzeroed", False):      # (the forward may have zeroed it on the side stream already)
             a["gcur"].zero_()
+        a["gzeroed"] = False
         Fn.join_side()                     # transposed weight shadows (issued beside the forward)
         st = {"rtape": list(reversed(tape)), "plan": plan, "dcls": dcls, "dpat": dpat, "i": 0, "g": None, "gt": None}
         # _bwd_split = j: stop after the head and blocks[j:]; the rest runs in resume_backward() (a second hipGraph, so that the
