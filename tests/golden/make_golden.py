@@ -530,9 +530,56 @@ def f12_init():
     save("f12_init", **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# F13: evolutionary-search population bookkeeping + candidate generation (search_utils/evolver.py, gen_utils.py) under a seed:
+#      the reference's own classes, numpy global RNG, sr_tiny and sr_small spaces, toy scores from recipe.toy_candidate_score
+# ------------------------------------------------------------------------------------------------
+def f13_evolver():
+    import contextlib
+    import importlib
+    import io
+    import json
+    evo = importlib.import_module("search_utils.evolver")
+    gen = importlib.import_module("search_utils.gen_utils")
+    flop = importlib.import_module("search_utils.compute_flop_mac")
+    out = {}
+    runs = {"sr_tiny": (recipe.SR_TINY_DEF, 0.45, 0, 12, 3, 6, 6), "sr_small": (recipe.SR_SMALL_DEF, None, 3, 10, 2, 5, 4)}
+    with contextlib.redirect_stdout(io.StringIO()):
+        for name, (nd, frac, seed, n_init, n_gen, parents, msize) in runs.items():
+            est = flop.ComputationEstimator(distill=False, input_resolution=224, patch_size=14)
+            constraint = est(nd) * frac if frac else 2.9e9          # 2.9e9: evolutionary_search/no_distill/small_flexible-conv-patch.sh:19
+            keep = R.cfg[name].num_channels_to_keep
+            pe = evo.PopulationEvolver(largest_network_def=nd, num_channels_to_keep=keep, constraint=constraint, compute_resource=est)
+            np.random.seed(seed)
+            gens = []
+            for it in range(1 + n_gen):
+                if it == 0:
+                    pe.random_sample(n_init)
+                else:
+                    pe.evolve_sample(parent_size=parents, mutate_prob=0.3, mutate_size=msize)
+                for ind in pe.popu:
+                    ind.score = recipe.toy_candidate_score(ind.network_def)
+                gens.append([[ind.network_def, ind.score] for ind in pe.popu])
+                pe.update_history()
+                pe.sort_history()
+            out[name + ".generations"] = json.dumps(gens)
+            out[name + ".history"] = json.dumps([[ind.network_def, ind.score] for ind in pe.history_popu])
+            out[name + ".constraint"] = float(constraint)
+            out[name + ".rng_after"] = float(np.random.uniform())
+            # the pieces one by one, from a fresh seed
+            np.random.seed(seed + 100)
+            a = gen.gen_random_network_def(nd, keep, constraint, est)
+            b = gen.gen_random_network_def(nd, keep, constraint, est)
+            m = gen.mutate_network_def(a, keep, 0.3, constraint, est)
+            c = gen.crossover_network_def(a, b, keep, constraint, est)
+            p = gen.tupleit(gen.reduce_constraint(nd, keep, constraint * 0.8, est))
+            out[name + ".pieces"] = json.dumps([a, b, m, c, p])
+    save("f13_evolver", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
     table = dict(f1=f1_micro, f2=f2_masked_ln, f3=f3_channel_drop, f4=f4_fullsize, f5=f5_subnet,
-                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init)
+                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init, f13=f13_evolver)
     for w in which:
         table[w]()

@@ -109,3 +109,12 @@ def checksum(sd):
     for k in sd:
         c = zlib.crc32(sd[k].detach().cpu().contiguous().numpy().tobytes(), c)
     return c
+
+
+def toy_candidate_score(network_def):
+    """Deterministic stand-in for a candidate's accuracy (F13: drives the evolver without a trained supernet)."""
+    s = 0.0
+    for i, e in enumerate(network_def):
+        if e[0] == 1 and e[3]:
+            s += (1.0 + 0.013 * i) * (e[1][1] * e[1][2] * 1.7 + e[2][1] * 0.41) * (e[1][0] ** 0.5)
+    return round(s / 1e4, 6)

@@ -98,3 +98,47 @@ def test_two_rank_gradient_exchange(tmp_path):
     assert err < 1e-5, err
     assert torch.equal(r0["g_split"], r1["g_split"])
     assert float((r0["g_split"] - r0["g_sync"]).abs().max() / r0["g_sync"].abs().max()) < 1e-6
+
+
+def _search_worker(rank, world, port, out_dir):
+    for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "vit-search_amd"), HERE,
+              os.path.join(HERE, "golden"), os.path.join(os.path.dirname(HERE), "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emu_kernels
+    import recipe
+    import vitres
+    from vitres import evo_search
+    from vitres.network_utils.compute_flop_mac import ComputationEstimator
+    emu_kernels.install(_Patch())
+    nd, keep = recipe.MICRO_DEFS[0], recipe.micro_keep_config()
+    sup = vitres.create_model("flexible_vit_sr_patch14_224_patch_output_supernet", img_size=recipe.MICRO_IMG,
+                              num_classes=recipe.MICRO_CLASSES, network_def=nd, num_channels_to_keep=keep, example_per_arch=2,
+                              num_warmup_epochs=30)
+    sup.load_state_dict(recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in sup.state_dict().items()], 100))
+    sup.set_compute_dtype(torch.float32).eval()
+    batches = []
+    for s in (9, 10):
+        x, _, _, labels = recipe.inputs(s, 6, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+        batches.append((x, labels))
+    est = ComputationEstimator(distill=False, input_resolution=recipe.MICRO_IMG, patch_size=14)
+    best = evo_search.search(sup, batches, nd, keep, 0.8 * est(nd), search_iter=2, init_popu_size=5, parent_size=3, mutate_size=2,
+                             mutate_prob=0.3, input_size=recipe.MICRO_IMG, output_dir=os.path.join(out_dir, "w%d" % world), seed=0)
+    torch.save([(b.network_def, b.score) for b in best], os.path.join(out_dir, "best_w%d_r%d.pt" % (world, rank)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_search_shards_candidates_and_agrees_with_one_rank(tmp_path):
+    """evo_search.search on 2 ranks (candidates dealt round robin, scores summed over ranks -- evo_eval.score_population)
+    selects the same winners with the same scores as one rank; only rank 0 writes the result files."""
+    mp.spawn(_search_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_search_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    one = torch.load(os.path.join(str(tmp_path), "best_w1_r0.pt"))
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "best_w2_r%d.pt" % r)) for r in range(2))
+    assert one == r0 == r1
+    assert open(os.path.join(str(tmp_path), "w1", "summary.txt")).read() == open(os.path.join(str(tmp_path), "w2", "summary.txt")).read()

@@ -425,3 +425,43 @@ def test_fused_layernorm_kernels_match_separate_kernels(monkeypatch):
     assert rel(c3, c0) < 2e-2
     worst = max(rel(g3[n], g0[n]) for n in g0 if float(g0[n].abs().max()) > 0)
     assert worst < 6e-2, worst
+
+
+@pytest.mark.gpu
+def test_evolutionary_search_loop_on_resident_supernet(tmp_path):
+    """vitres.evo_search.search end to end on the micro supernet: every candidate of every generation is scored by the HIP
+    forward under its keep descriptor, scores equal evo_eval.score_candidate, and the oracle's logits for the winner's
+    prefix-sliced sub-network agree with the descriptor run (fp32 mode)."""
+    from vitres import evo_eval, evo_search
+    from vitres.network_utils.compute_flop_mac import ComputationEstimator
+    nd, keep = recipe.MICRO_DEFS[0], recipe.micro_keep_config()
+    sup = vitres.create_model("flexible_vit_sr_patch14_224_patch_output_supernet", img_size=recipe.MICRO_IMG,
+                              num_classes=recipe.MICRO_CLASSES, network_def=nd, num_channels_to_keep=keep, example_per_arch=2,
+                              num_warmup_epochs=30)
+    sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in sup.state_dict().items()], 100)
+    sup.load_state_dict(sd)
+    sup = sup.to(DEV).set_compute_dtype(torch.float32).eval()
+    batches = []
+    for s in (9, 10):
+        x, _, _, labels = recipe.inputs(s, 6, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+        batches.append((x.to(DEV), labels.to(DEV)))
+    est = ComputationEstimator(distill=False, input_resolution=recipe.MICRO_IMG, patch_size=14)
+    budget = 0.8 * est(nd)
+    best = evo_search.search(sup, batches, nd, keep, budget, search_iter=3, init_popu_size=5, parent_size=3, mutate_size=2,
+                             mutate_prob=0.3, input_size=recipe.MICRO_IMG, output_dir=str(tmp_path), seed=0)
+    assert len(best) == 3 and best[0].score <= best[1].score <= best[2].score
+    win = best[-1]
+    assert 0.975 * budget <= est(win.network_def) <= budget
+    assert win.score == evo_eval.score_candidate(sup, win.network_def, batches)
+    rows = open(os.path.join(tmp_path, "iter@0", "popu.txt")).read().splitlines()
+    assert rows[0] == "Idx, Acc, Network_def" and len(rows) == 6
+    # the winner as a standalone prefix-sliced network in the oracle == the descriptor run on the resident supernet
+    import vitres_oracle as O
+    sub = O.OracleViTSR(win.network_def, img_size=recipe.MICRO_IMG, num_classes=recipe.MICRO_CLASSES, patch_output=True)
+    sub.load_state_dict(O.sub_state_dict({k: v.cpu() for k, v in sup.state_dict().items()}, sub.state_dict()))
+    sub.eval()
+    with torch.no_grad():
+        want = sub(batches[0][0].cpu())
+        got = sup(batches[0][0], plan=evo_eval.plan_for_subnet(sup, win.network_def, 6))
+    want = want[0] if isinstance(want, tuple) else want
+    assert rel(got, want) < 1e-4
