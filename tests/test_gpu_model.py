@@ -465,3 +465,50 @@ def test_evolutionary_search_loop_on_resident_supernet(tmp_path):
         got = sup(batches[0][0], plan=evo_eval.plan_for_subnet(sup, win.network_def, 6))
     want = want[0] if isinstance(want, tuple) else want
     assert rel(got, want) < 1e-4
+
+
+@pytest.mark.gpu
+def test_training_resumes_from_a_torch_adamw_checkpoint(tmp_path):
+    """A run interrupted under torch.optim.AdamW (the 'optimizer' entry of a reference checkpoint.pth.tar) continues under
+    FlatAdamW exactly as torch would have continued: same parameters after the next steps with the same gradients."""
+    from vitres import checkpoint, engine
+    from vitres.optim import FlatAdamW
+    from vitres.losses import SoftTargetCrossEntropy
+    crit = SoftTargetCrossEntropy()
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1))
+
+    def fresh():
+        prod, orc, sd = build_pair(0, "multi", 100)
+        prod.set_compute_dtype(torch.bfloat16)
+        prod.train()
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+        return prod
+    m_ref, m_new = fresh(), fresh()
+    ref_opt = torch.optim.AdamW(engine.param_groups_weight_decay(m_ref, 0.05), lr=2e-3)
+
+    def grads_of(model, seed):
+        torch.manual_seed(seed)
+        model.zero_grad(set_to_none=True)
+        out = model(x, patch_output_type="seq")
+        (crit(out[0], t) + crit(out[1], pt)).backward()
+    for it in range(2):                                        # the 'reference' part of the run
+        grads_of(m_ref, 300 + it)
+        ref_opt.step()
+    path = checkpoint.save_checkpoint(str(tmp_path), m_ref, ref_opt, None, epoch=4)
+    opt = FlatAdamW(m_new, engine.param_groups_weight_decay(m_new, 0.05), lr=1.0)
+    assert checkpoint.resume(path, m_new, opt, None) == 5 and opt.param_groups[0]["lr"] == 2e-3
+    for it in range(2, 4):
+        grads_of(m_new, 300 + it)
+        for p_r, p_f in zip(m_ref.parameters(), m_new.parameters()):
+            p_r.grad = p_f.grad.detach().clone()
+        ref_opt.step()
+        opt.step()
+    p_ref = dict(m_ref.named_parameters())
+    for n, p in m_new.named_parameters():
+        assert rel(p, p_ref[n].detach().cpu()) < 2e-6, n
+    back = checkpoint.checkpoint_dict(m_new, opt, None, 5)["optimizer"]
+    want = ref_opt.state_dict()
+    for i in want["state"]:
+        assert rel(back["state"][i]["exp_avg_sq"], want["state"][i]["exp_avg_sq"].cpu()) < 1e-5      # fp32 rounding (fma)
+        assert float(back["state"][i]["step"]) == float(want["state"][i]["step"]) == 4.0

@@ -1,0 +1,76 @@
+"""Checkpoints in the reference's own layout (main.py:400-424,496-515): one dict
+    {'model', 'optimizer', 'lr_scheduler', 'epoch', 'args'[, 'model_ema']}
+written with torch.save as `checkpoint.pth.tar` (+ `epoch@E_checkpoint.pth.tar` every tenth epoch), so that runs move between
+the reference and this stack in either direction.  'model' / 'model_ema' use the reference's state_dict keys;
+'optimizer' is torch.optim.AdamW's layout -- vitres.optim.FlatAdamW converts to and from its arena-shaped moments.
+"""
+import os
+
+import torch
+
+from .nets.net_utils import get_sub_state_dict
+
+CHECKPOINT_NAME = 'checkpoint.pth.tar'
+
+
+def _optimizer_state(optimizer):
+    return optimizer.torch_state_dict() if hasattr(optimizer, 'torch_state_dict') else optimizer.state_dict()
+
+
+def _cpu(tree):
+    if isinstance(tree, torch.Tensor):
+        return tree.detach().cpu()
+    if isinstance(tree, dict):
+        return {k: _cpu(v) for k, v in tree.items()}
+    if isinstance(tree, (list, tuple)):
+        return type(tree)(_cpu(v) for v in tree)
+    return tree
+
+
+def checkpoint_dict(model, optimizer, lr_scheduler, epoch, args=None, model_ema=None):
+    """model_ema: a state_dict (e.g. FlatAdamW.ema_state_dict()) or a module holding the averaged weights."""
+    out = {'model': _cpu(model.state_dict()), 'optimizer': _cpu(_optimizer_state(optimizer)),
+           'lr_scheduler': lr_scheduler.state_dict() if lr_scheduler is not None else {}, 'epoch': epoch, 'args': args}
+    if model_ema is not None:
+        out['model_ema'] = _cpu(model_ema if isinstance(model_ema, dict) else model_ema.state_dict())
+    return out
+
+
+def save_checkpoint(output_dir, model, optimizer, lr_scheduler, epoch, args=None, model_ema=None):
+    """Writes <output_dir>/checkpoint.pth.tar and, for epoch % 10 == 9, epoch@<epoch>_checkpoint.pth.tar (main.py:504-515)."""
+    d = checkpoint_dict(model, optimizer, lr_scheduler, epoch, args=args, model_ema=model_ema)
+    os.makedirs(output_dir, exist_ok=True)
+    path = os.path.join(output_dir, CHECKPOINT_NAME)
+    torch.save(d, path)
+    if epoch % 10 == 9:
+        torch.save(d, os.path.join(output_dir, 'epoch@{}_checkpoint.pth.tar'.format(epoch)))
+    return path
+
+
+def resume(path_or_dict, model, optimizer=None, lr_scheduler=None, eval_mode=False, load_ema=None):
+    """--resume (main.py:401-417): loads 'model'; unless eval_mode, and when the checkpoint carries all of 'optimizer',
+    'lr_scheduler' and 'epoch', restores them and returns the epoch to start from (saved epoch + 1; else None); load_ema(state)
+    receives 'model_ema' on that path.  With eval_mode, 'model_ema' (when present) replaces the model's weights."""
+    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location='cpu', weights_only=False)
+    model.load_state_dict(ck['model'])
+    start = None
+    if not eval_mode and all(k in ck for k in ('optimizer', 'lr_scheduler', 'epoch')):
+        if optimizer is not None:
+            optimizer.load_state_dict(ck['optimizer'])
+        if lr_scheduler is not None:
+            lr_scheduler.load_state_dict(ck['lr_scheduler'])
+        start = ck['epoch'] + 1
+        if load_ema is not None and 'model_ema' in ck:
+            load_ema(ck['model_ema'])
+    if eval_mode and 'model_ema' in ck:
+        model.load_state_dict(ck['model_ema'])
+    return start
+
+
+def inherit_supernet_weights(model, path_or_dict, use_ema=False):
+    """--resume-supernet-weights (main.py:418-424): a searched sub-network starts from the prefix slices of a supernet
+    checkpoint (nets/net_utils.py:get_sub_state_dict)."""
+    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location='cpu', weights_only=False)
+    src = ck['model_ema'] if use_ema else ck['model']
+    model.load_state_dict(get_sub_state_dict(source_dict=src, sub_dict=model.state_dict()))
+    return model

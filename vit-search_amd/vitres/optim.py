@@ -104,6 +104,10 @@ class FlatAdamW(torch.optim.Optimizer):
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
+        """Accepts its own flat layout or torch.optim.AdamW's (the 'optimizer' entry of a reference checkpoint.pth.tar,
+        main.py:506-512): per-parameter exp_avg / exp_avg_sq are scattered into the arena-shaped moments."""
+        if "state" in sd:
+            return self.load_torch_state_dict(sd)
         self._bind()
         st = self._flat_state
         self._step = int(sd["step"])
@@ -113,6 +117,59 @@ class FlatAdamW(torch.optim.Optimizer):
             st["ema"].copy_(sd["ema"])
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
+
+    def _ordered_params(self):
+        return [p for g in self.param_groups for p in g["params"]]      # torch numbers parameters in this order
+
+    def torch_state_dict(self):
+        """The state in torch.optim.AdamW.state_dict() layout ({'state': {i: {step, exp_avg, exp_avg_sq}}, 'param_groups'}),
+        i.e. what the reference writes under 'optimizer' -- a checkpoint saved here resumes in the reference and vice versa."""
+        a = self._bind()
+        st = self._flat_state
+        state, groups, i = {}, [], 0
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                off, n = a["offsets"][a["index"][id(p)]]
+                if self._step > 0:
+                    state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": st["m"][off:off + n].view(p.shape).clone(),
+                                "exp_avg_sq": st["v"][off:off + n].view(p.shape).clone()}
+                ids.append(i)
+                i += 1
+            pg = {k: v for k, v in g.items() if k != "params"}
+            pg.setdefault("amsgrad", False)
+            pg["params"] = ids
+            groups.append(pg)
+        return {"state": state, "param_groups": groups}
+
+    def load_torch_state_dict(self, sd):
+        a = self._bind()
+        st = self._flat_state
+        params = self._ordered_params()
+        n_saved = sum(len(g["params"]) for g in sd["param_groups"])
+        if n_saved != len(params) or len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters")
+        steps = set()
+        st["m"].zero_()
+        st["v"].zero_()
+        saved_ids = [i for g in sd["param_groups"] for i in g["params"]]
+        for p, i in zip(params, saved_ids):
+            ps = sd["state"].get(i)
+            if ps is None:
+                continue
+            if tuple(ps["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("optimizer state of parameter %d has shape %s, expected %s" % (i, tuple(ps["exp_avg"].shape),
+                                                                                                tuple(p.shape)))
+            off, n = a["offsets"][a["index"][id(p)]]
+            st["m"][off:off + n].copy_(ps["exp_avg"].reshape(-1))
+            st["v"][off:off + n].copy_(ps["exp_avg_sq"].reshape(-1))
+            steps.add(int(ps["step"]))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ (%s): not an AdamW state this optimizer can continue" % sorted(steps))
+        self._step = steps.pop() if steps else 0
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in s.items() if k not in ("params", "amsgrad", "foreach", "maximize", "capturable",
+                                                               "differentiable", "fused", "decoupled_weight_decay")})
 
     def ema_state_dict(self):
         """EMA parameters under the model's state_dict keys (buffers are taken from the live model, as ModelEmaV2's
