@@ -256,22 +256,24 @@ int vr_batchsum(const float* in, float* out, int32_t B, int64_t inner, vr_stream
 int vr_im2col_patch(const float* img, void* col, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t P,
                     int32_t ldk, int32_t dtype, vr_stream_t stream);
 
-/* token row 0 of the embedding: x[b,0,c] = (tokens[c] + pos[0,c]) masked by keep (vit_sr_supernet.py:399-407) */
+/* token rows of the embedding: x[b,t,c] = (tokens[t,c] + pos[t,c]) masked by keep, t < num_tokens (1: class token; 2: class +
+ * distillation token of the *_distill_* factories) (vit_sr_supernet.py:399-407) */
 int vr_embed_cls(const float* tokens, const float* pos, float* x, const int32_t* keep, int32_t B, int32_t N,
-                 int32_t C, vr_stream_t stream);
+                 int32_t C, int32_t num_tokens, vr_stream_t stream);
 
 /*
  * SpatialReductionPatchEmbedding pieces (nets/vit_sr_supernet.py:114-172), grid g x g -> g/2 x g/2:
- *  vr_sr_im2col : y (dtype) [B,1+g*g,C] -> col (dtype) [B*(g/2)^2, 9*C], k = (kh,kw,c), 3x3 stride 2 pad 1
- *  vr_sr_col2im : dcol -> dy rows 1.. (gather form, no atomics); row 0 left untouched
- *  vr_sr_resid  : out fp32 [B,1+(g/2)^2,Cout] = zero-padded residual (cls row copy; 2x2 avg-pool of patches)
- *  vr_sr_resid_bwd : dx[b,0,:C] (+)= dout[b,0,:C]; dx[b,1+p,:C] (+)= 0.25*dout[b,1+p/2..]
+ * T = num_tokens leading token rows per sample (1 or 2), then the g*g patch rows:
+ *  vr_sr_im2col : y (dtype) [B,T+g*g,C] -> col (dtype) [B*(g/2)^2, 9*C], k = (kh,kw,c), 3x3 stride 2 pad 1
+ *  vr_sr_col2im : dcol -> dy rows T.. (gather form, no atomics); token rows left untouched
+ *  vr_sr_resid  : out fp32 [B,T+(g/2)^2,Cout] = zero-padded residual (token rows copied; 2x2 avg-pool of patches)
+ *  vr_sr_resid_bwd : dx[b,t,:C] (+)= dout[b,t,:C] for t < T; dx[b,T+p,:C] (+)= 0.25*dout[b,T+p/2..]
  */
-int vr_sr_im2col(const void* y, void* col, int32_t B, int32_t g, int32_t C, int32_t dtype, vr_stream_t stream);
-int vr_sr_col2im(const void* dcol, void* dy, int32_t B, int32_t g, int32_t C, int32_t dtype, vr_stream_t stream);
-int vr_sr_resid(const float* x, float* out, int32_t B, int32_t g, int32_t Cin, int32_t Cout, vr_stream_t stream);
+int vr_sr_im2col(const void* y, void* col, int32_t B, int32_t g, int32_t C, int32_t num_tokens, int32_t dtype, vr_stream_t stream);
+int vr_sr_col2im(const void* dcol, void* dy, int32_t B, int32_t g, int32_t C, int32_t num_tokens, int32_t dtype, vr_stream_t stream);
+int vr_sr_resid(const float* x, float* out, int32_t B, int32_t g, int32_t Cin, int32_t Cout, int32_t num_tokens, vr_stream_t stream);
 int vr_sr_resid_bwd(const float* dout, float* dx, int32_t B, int32_t g, int32_t Cin, int32_t Cout,
-                    int32_t accumulate, vr_stream_t stream);
+                    int32_t accumulate, int32_t num_tokens, vr_stream_t stream);
 
 /* x[m, c] = 0 for c >= keep[sample(m)]  (ChannelDrop.forward `x * mask`, nets/channel_drop.py:82) */
 int vr_mask_rows(float* x, const int32_t* keep, int32_t M, int32_t C, int32_t rows_per_sample, vr_stream_t stream);

@@ -248,47 +248,49 @@ def im2col_patch(img, P, ldk, out_dtype):
     return out
 
 
-def embed_cls(tokens, pos, x, keep):
+def embed_cls(tokens, pos, x, keep, num_tokens=1):
     B, N, C = x.shape
-    row = (tokens.reshape(-1)[:C] + pos.reshape(-1)[:C])[None, :].expand(B, C)
+    T = num_tokens
+    rows = (tokens.reshape(-1, C)[:T] + pos.reshape(-1, C)[:T])[None].expand(B, T, C)
     if keep is not None:
-        row = row * (torch.arange(C)[None, :] < keep.long()[:, None])
-    x[:, 0, :] = row
+        rows = rows * (torch.arange(C)[None, :] < keep.long()[:, None])[:, None, :]
+    x[:, :T, :] = rows
     return x
 
 
-def sr_im2col(y, B, g, C):
-    img = y.view(B, 1 + g * g, C)[:, 1:, :].float().transpose(1, 2).reshape(B, C, g, g)
+def sr_im2col(y, B, g, C, num_tokens=1):
+    T = num_tokens
+    img = y.view(B, T + g * g, C)[:, T:, :].float().transpose(1, 2).reshape(B, C, g, g)
     u = F.unfold(img, kernel_size=3, stride=2, padding=1)                    # [B, C*9, go*go], k = (c, kh, kw)
     go = g // 2
     u = u.view(B, C, 9, go * go).permute(0, 3, 2, 1).reshape(B * go * go, 9 * C)   # k = (tap, c)
     return u.to(y.dtype)
 
 
-def sr_col2im(dcol, dy, B, g, C):
-    go = g // 2
+def sr_col2im(dcol, dy, B, g, C, num_tokens=1):
+    go, T = g // 2, num_tokens
     u = dcol.float().view(B, go * go, 9, C).permute(0, 3, 2, 1).reshape(B, C * 9, go * go)
     img = F.fold(u, output_size=(g, g), kernel_size=3, stride=2, padding=1)  # [B, C, g, g]
-    dy.view(B, 1 + g * g, C)[:, 1:, :] = img.flatten(2).transpose(1, 2).to(dy.dtype)
+    dy.view(B, T + g * g, C)[:, T:, :] = img.flatten(2).transpose(1, 2).to(dy.dtype)
     return dy
 
 
-def sr_resid(x, B, g, cin, cout):
-    go = g // 2
-    out = torch.zeros(B, 1 + go * go, cout)
-    out[:, 0, :cin] = x[:, 0, :]
-    img = x[:, 1:, :].transpose(1, 2).reshape(B, cin, g, g)
-    out[:, 1:, :cin] = F.avg_pool2d(img, 2, 2).flatten(2).transpose(1, 2)
+def sr_resid(x, B, g, cin, cout, num_tokens=1):
+    go, T = g // 2, num_tokens
+    out = torch.zeros(B, T + go * go, cout)
+    out[:, :T, :cin] = x[:, :T, :]
+    img = x[:, T:, :].transpose(1, 2).reshape(B, cin, g, g)
+    out[:, T:, :cin] = F.avg_pool2d(img, 2, 2).flatten(2).transpose(1, 2)
     return out
 
 
-def sr_resid_bwd(dout, B, g, cin, cout):
-    go = g // 2
-    dx = torch.zeros(B, 1 + g * g, cin)
-    dx[:, 0, :] = dout[:, 0, :cin]
-    gi = dout[:, 1:, :cin].transpose(1, 2).reshape(B, cin, go, go)
+def sr_resid_bwd(dout, B, g, cin, cout, num_tokens=1):
+    go, T = g // 2, num_tokens
+    dx = torch.zeros(B, T + g * g, cin)
+    dx[:, :T, :] = dout[:, :T, :cin]
+    gi = dout[:, T:, :cin].transpose(1, 2).reshape(B, cin, go, go)
     gi = gi.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) * 0.25
-    dx[:, 1:, :] = gi.flatten(2).transpose(1, 2)
+    dx[:, T:, :] = gi.flatten(2).transpose(1, 2)
     return dx
 
 

@@ -531,6 +531,114 @@ def f12_init():
 
 
 # ------------------------------------------------------------------------------------------------
+# F14: two-token (class + distillation token) variants -- factories flexible_vit_sr_distill_patch14_224[_supernet]
+#      (vit_sr_supernet.py:204-359 with distill_token=True; forward :455-460 returns (cls_pred, dst_pred) in train AND eval)
+# ------------------------------------------------------------------------------------------------
+def f14_distill_token():
+    B = 8
+    for et in (0, 4):
+        nd = recipe.MICRO_DEFS[et]
+        for mode in ("plain", "multi"):
+            torch.manual_seed(1234)
+            kw = {}
+            if mode != "plain":
+                kw = dict(num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30)
+            m = R.vit_sr.FlexibleDistillVisionTransformerSR(
+                img_size=recipe.MICRO_IMG, patch_size=14, num_classes=recipe.MICRO_CLASSES, distill_token=True, network_def=nd,
+                patch_output=False, supernet=(mode != "plain"), **kw)
+            sd, shapes = load_recipe(m, seed=140 + et)
+            x, t, pt, labels = recipe.inputs(7, B, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+            t2 = pt[:, 0, :].contiguous()                        # soft target of the distillation head
+            out = {"state_crc": recipe.checksum(sd), "keys": np.array([k for k, _ in shapes]),
+                   "shapes": np.array([str(s) for _, s in shapes]), "no_weight_decay": np.array(sorted(m.no_weight_decay()))}
+            m.train()
+            if mode != "plain":
+                m.set_epoch(31)
+                m.load_state_dict(sd)
+            m.zero_grad()
+            torch.manual_seed(555 + 31)
+            with KeepRecorder() as rec:
+                cls, dst = m(x.clone())
+            loss = soft_ce(cls, t) + soft_ce(dst, t2)
+            loss.backward()
+            out["cls"], out["dst"], out["loss"] = cls.detach().numpy(), dst.detach().numpy(), loss.item()
+            if rec.log:
+                out["keeps"] = torch.stack(rec.log).numpy()
+            names = [n for n in GRAD_NAMES_COMMON if n in dict(m.named_parameters())] + ["dst_head.weight", "dst_head.bias", "cls_head.bias"]
+            names += ["patch_embed.proj.weight"] if et == 0 else ["patch_embed.conv_proj.weight", "patch_embed.conv1.conv.weight"]
+            for k, v in grads_of(m, names).items():
+                out[k] = v
+            m.load_state_dict(sd)
+            m.eval()
+            with torch.no_grad():
+                ec, ed = m(x.clone())
+            out["eval.cls"], out["eval.dst"] = ec.numpy(), ed.numpy()
+            save("f14_distill_t%d_%s" % (et, mode), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# F15: knowledge distillation through the engine (engine.py:25-46 KnowledgeDistillationLoss; :112-148 teacher forward,
+#      loss = (1 - alpha) * criterion(cls, targets) + alpha * kd(dst, teacher_output)) on the two-token micro net
+# ------------------------------------------------------------------------------------------------
+def f15_distillation_engine():
+    import contextlib
+    import importlib
+    import io
+    engine = importlib.import_module("engine")
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    xs, ts = torch.randn(8, 10, generator=g), torch.randn(8, 10, generator=g) * 2
+    for hard in (True, False):
+        xv = xs.clone().requires_grad_(True)
+        loss = engine.KnowledgeDistillationLoss(hard_distill=hard)(xv, ts)
+        loss.backward()
+        out["kd.%s.loss" % ("hard" if hard else "soft")] = loss.item()
+        out["kd.%s.grad" % ("hard" if hard else "soft")] = xv.grad.numpy().copy()
+    for mode in ("plain", "multi"):
+        for hard in (True, False):
+            torch.manual_seed(2024)
+            sup = mode != "plain"
+            kw = dict(num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30) if sup else {}
+            m = R.vit_sr.FlexibleDistillVisionTransformerSR(
+                img_size=recipe.MICRO_IMG, patch_size=14, num_classes=recipe.MICRO_CLASSES, distill_token=True,
+                network_def=recipe.MICRO_DEFS[0], patch_output=False, supernet=sup, **kw)
+            sd, _ = load_recipe(m, seed=140)
+            skip = m.no_weight_decay()
+            decay, no_decay = [], []
+            for n, p in m.named_parameters():
+                (no_decay if (p.ndim == 1 or n.endswith(".bias") or n in skip) else decay).append(p)
+            opt = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": 0.05}], lr=1e-3)
+            loader = []
+            for it in range(3):
+                x, t, pt, labels = recipe.inputs(300 + it, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+                loader.append((x, t))
+
+            def scaler(loss, optimizer, clip_grad=None, parameters=None, create_graph=False):
+                loss.backward()
+                optimizer.step()
+
+            class Crit(torch.nn.Module):
+                def forward(self, x, t):
+                    return soft_ce(x, t)
+            if sup:
+                m.set_epoch(31)
+            torch.manual_seed(4321)
+            with KeepRecorder() as rec, contextlib.redirect_stdout(io.StringIO()):
+                stats = engine.train_one_epoch(m, Crit(), loader, opt, torch.device("cpu"), 31, scaler, max_norm=None,
+                                               model_ema=None, mixup_fn=None, print_freq=1,
+                                               teacher_model=recipe.toy_teacher(recipe.MICRO_CLASSES), hard_distill=hard, alpha=0.5,
+                                               arch_sample=("multi" if sup else None), patch_mixup_fn=None)
+            tag = "%s.%s." % (mode, "hard" if hard else "soft")
+            out[tag + "avg_loss"] = stats["loss"]
+            if rec.log:
+                out[tag + "keeps"] = torch.stack(rec.log).numpy()
+            after = m.state_dict()
+            for k in ("tokens", "blocks.0.attn.qkv.weight", "blocks.6.mlp.fc2.bias", "cls_head.weight", "dst_head.weight", "norm.weight"):
+                out[tag + "after." + k] = after[k].numpy().copy()
+    save("f15_distillation_engine", **out)
+
+
+# ------------------------------------------------------------------------------------------------
 # F13: evolutionary-search population bookkeeping + candidate generation (search_utils/evolver.py, gen_utils.py) under a seed:
 #      the reference's own classes, numpy global RNG, sr_tiny and sr_small spaces, toy scores from recipe.toy_candidate_score
 # ------------------------------------------------------------------------------------------------
@@ -578,8 +686,8 @@ def f13_evolver():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15"]
     table = dict(f1=f1_micro, f2=f2_masked_ln, f3=f3_channel_drop, f4=f4_fullsize, f5=f5_subnet,
-                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init, f13=f13_evolver)
+                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init, f13=f13_evolver, f14=f14_distill_token, f15=f15_distillation_engine)
     for w in which:
         table[w]()

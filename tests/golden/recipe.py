@@ -118,3 +118,23 @@ def toy_candidate_score(network_def):
         if e[0] == 1 and e[3]:
             s += (1.0 + 0.013 * i) * (e[1][1] * e[1][2] * 1.7 + e[2][1] * 0.41) * (e[1][0] ** 0.5)
     return round(s / 1e4, 6)
+
+
+def toy_teacher(classes):
+    """Fixed stand-in for the KD teacher (the reference uses a pretrained RegNet from timm, main.py:370-382): global average of the
+    image -> Linear(3 -> classes) with recipe weights.  Any module mapping images to logits works; this one travels with the repo."""
+    import torch
+    lin = torch.nn.Linear(3, classes)
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(classes, 3, generator=g))
+        lin.bias.copy_(torch.randn(classes, generator=g) * 0.1)
+
+    class Teacher(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = lin
+
+        def forward(self, x):
+            return self.lin(x.float().mean(dim=(2, 3)))
+    return Teacher()

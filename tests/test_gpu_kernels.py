@@ -474,3 +474,31 @@ def test_gemm_ln_backward(B, Nt, C, Kd, masked, nxt):
             for i in range(B):
                 tail = real[1].view(B, Nt, C)[i, :, int(nc[1][i]):]
                 assert tail.numel() == 0 or float(tail.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T", [1, 2])
+def test_token_rows_of_embed_and_spatial_reduction_kernels(dtype, T):
+    """num_tokens = 1 (class token) and 2 (class + distillation token) in vr_embed_cls and the vr_sr_* gathers."""
+    B, g, C, Cin = 3, 6, 72, 40
+    N = T + g * g
+    keep = torch.tensor([72, 40, 8], dtype=torch.int32)
+    tokens, pos, x = rnd(1, T, C, seed=4), rnd(1, N, C, seed=5), rnd(B, N, C, seed=6)
+    r, e = both("embed_cls", (tokens, pos, x.clone(), keep, T))
+    assert relerr(r, e) < 1e-6 and torch.equal(r[:, T:].cpu(), x[:, T:])          # patch rows untouched
+    y = rnd(B, N, C, seed=7).to(dtype)
+    r, e = both("sr_im2col", (y, B, g, C, T))
+    assert relerr(r, e) < 1e-6
+    go = g // 2
+    dcol = rnd(B * go * go, 9 * C, seed=8).to(dtype)
+    dyr = torch.full((B, N, C), 7.0, dtype=dtype)
+    E.sr_col2im(dcol, dyr, B, g, C, T)
+    dy = torch.full((B, N, C), 7.0, dtype=dtype, device=DEV)
+    K.sr_col2im(dcol.to(DEV), dy, B, g, C, T)
+    assert relerr(dy, dyr) < tol(dtype) and float((dy[:, :T].float() - 7.0).abs().max()) == 0.0      # token rows untouched
+    xs = rnd(B, N, Cin, seed=9)
+    r, e = both("sr_resid", (xs, B, g, Cin, C, T))
+    assert r.shape == (B, T + go * go, C) and relerr(r, e) < 1e-6
+    do = rnd(B, T + go * go, C, seed=10)
+    r, e = both("sr_resid_bwd", (do, B, g, Cin, C, T))
+    assert r.shape == (B, N, Cin) and relerr(r, e) < 1e-6

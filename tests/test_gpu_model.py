@@ -512,3 +512,114 @@ def test_training_resumes_from_a_torch_adamw_checkpoint(tmp_path):
     for i in want["state"]:
         assert rel(back["state"][i]["exp_avg_sq"], want["state"][i]["exp_avg_sq"].cpu()) < 1e-5      # fp32 rounding (fma)
         assert float(back["state"][i]["step"]) == float(want["state"][i]["step"]) == 4.0
+
+
+def build_distill_pair(et, mode, seed):
+    nd = recipe.MICRO_DEFS[et]
+    sup = mode != "plain"
+    kw = dict(num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30) if sup else {}
+    prod = vitres.create_model("flexible_vit_sr_distill_patch14_224" + ("_supernet" if sup else ""), img_size=recipe.MICRO_IMG,
+                               num_classes=recipe.MICRO_CLASSES, network_def=nd, drop_path_rate=0.0, **kw)
+    orc = O.OracleViTSR(nd, img_size=recipe.MICRO_IMG, num_classes=recipe.MICRO_CLASSES, supernet=sup, distill_token=True,
+                        patch_output=False, **kw)
+    sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in orc.state_dict().items()], seed)
+    prod.load_state_dict(sd)
+    orc.load_state_dict(sd)
+    return prod.to(DEV), orc, sd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("et,mode", [(0, "plain"), (0, "multi"), (4, "plain"), (4, "multi")])
+def test_two_token_variant_vs_reference_golden_and_oracle(et, mode, dtype):
+    """flexible_vit_sr_distill_patch14_224[_supernet] (class + distillation token) through the HIP kernels: masks bit-exact,
+    (cls, dst) logits and gradients against fixture F14 (fp32 mode: 1e-4 / 5e-4; bf16: 3e-2 logits), eval-mode outputs, and
+    engine.evaluate's distillation / joint accuracies."""
+    g = np.load(os.path.join(G, "f14_distill_t%d_%s.npz" % (et, mode)))
+    prod, orc, sd = build_distill_pair(et, mode, 140 + et)
+    prod.set_compute_dtype(dtype)
+    f32 = dtype == torch.float32
+    x, t, pt, labels = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    t2 = pt[:, 0, :].contiguous()
+    prod.train()
+    if mode != "plain":
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+    torch.manual_seed(555 + 31)
+    cls, dst = prod(x.to(DEV))
+    if mode != "plain":
+        assert np.array_equal(torch.stack(prod.last_keeps).cpu().numpy(), g["keeps"])
+    tol_l = 1e-4 if f32 else 3e-2
+    assert rel(cls, g["cls"]) < tol_l and rel(dst, g["dst"]) < tol_l
+    loss = O.soft_target_ce(cls, t.to(DEV)) + O.soft_target_ce(dst, t2.to(DEV))
+    assert abs(loss.item() - float(g["loss"])) < (1e-4 if f32 else 2e-2) * abs(float(g["loss"]))
+    loss.backward()
+    params = dict(prod.named_parameters())
+    worst = max(rel(params[k[5:]].grad, g[k]) for k in g.files if k.startswith("grad."))
+    assert worst < (5e-4 if f32 else 8e-2), worst
+    for n, p in prod.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+    prod.eval()
+    prod.load_state_dict(sd)
+    with torch.no_grad():
+        ec, ed = prod(x.to(DEV))
+    assert rel(ec, g["eval.cls"]) < tol_l and rel(ed, g["eval.dst"]) < tol_l
+    if f32:
+        from vitres import engine
+        stats = engine.evaluate([(x, labels)], prod, DEV, logger=None)
+        for k in ("acc1", "dst_acc1", "jnt_acc1", "jnt_acc5"):
+            assert 0.0 <= stats[k] <= 100.0
+        want = float((torch.from_numpy(g["eval.dst"]).argmax(1) == labels).float().mean()) * 100
+        assert abs(stats["dst_acc1"] - want) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,hard", [("plain", True), ("multi", False)])
+def test_distillation_epoch_matches_reference_engine(mode, hard):
+    """engine.train_one_epoch with a teacher on the two-token micro net through the HIP kernels (fp32 mode): masks bit-exact,
+    mean loss and parameters after three AdamW steps against the imported reference's engine (fixture F15)."""
+    from vitres import engine
+    g = np.load(os.path.join(G, "f15_distillation_engine.npz"))
+    torch.manual_seed(2024)
+    prod, orc, sd = build_distill_pair(0, mode, 140)
+    prod.set_compute_dtype(torch.float32)
+    opt = torch.optim.AdamW(engine.param_groups_weight_decay(prod, 0.05), lr=1e-3)
+    loader = []
+    for it in range(3):
+        x, t, _, _ = recipe.inputs(300 + it, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+        loader.append((x, t))
+
+    def scaler(loss, optimizer, clip_grad=None, parameters=None, create_graph=False):
+        loss.backward()
+        optimizer.step()
+
+    class Crit(torch.nn.Module):
+        def forward(self, x, t):
+            return O.soft_target_ce(x, t)
+    if mode != "plain":
+        prod.set_epoch(31)
+    torch.manual_seed(4321)
+    keeps = []
+    orig = type(prod).forward
+
+    def fwd(self, *a, **k):
+        out = orig(self, *a, **k)
+        if self.last_keeps:
+            keeps.extend(v.cpu() for v in self.last_keeps)
+        return out
+    type(prod).forward = fwd
+    try:
+        quiet = type("L", (), {"info": staticmethod(lambda *_: None)})
+        stats = engine.train_one_epoch(prod, Crit(), loader, opt, torch.device(DEV), 31, scaler, max_norm=None, print_freq=0,
+                                       teacher_model=recipe.toy_teacher(recipe.MICRO_CLASSES).to(DEV), hard_distill=hard,
+                                       alpha=0.5, arch_sample=("multi" if mode != "plain" else None), logger=quiet)
+    finally:
+        type(prod).forward = orig
+    tag = "%s.%s." % (mode, "hard" if hard else "soft")
+    assert abs(stats["loss"] - float(g[tag + "avg_loss"])) < 2e-5 * abs(float(g[tag + "avg_loss"]))
+    if mode != "plain":
+        assert np.array_equal(torch.stack(keeps).numpy(), g[tag + "keeps"])
+    after = prod.state_dict()
+    for k in g.files:
+        if k.startswith(tag + "after."):
+            assert rel(after[k[len(tag) + 6:]], g[k]) < 1e-4, k

@@ -190,3 +190,127 @@ def test_emulated_fused_layernorm_path_equals_separate_kernels(monkeypatch):
     c3, g3 = run(3)
     assert "f" in calls and "b" in calls
     assert rel(c3, c0) < 2e-2 and rel(g3, g0) < 5e-2          # bf16 mode: the fused backward keeps dy in fp32 instead of bf16
+
+
+def build_distill_pair(et, mode, seed):
+    nd = recipe.MICRO_DEFS[et]
+    sup = mode != "plain"
+    kw = dict(num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30) if sup else {}
+    prod = vitres.create_model("flexible_vit_sr_distill_patch14_224" + ("_supernet" if sup else ""), img_size=recipe.MICRO_IMG,
+                               num_classes=recipe.MICRO_CLASSES, network_def=nd, drop_path_rate=0.0, **kw)
+    orc = O.OracleViTSR(nd, img_size=recipe.MICRO_IMG, num_classes=recipe.MICRO_CLASSES, supernet=sup, distill_token=True,
+                        patch_output=False, **kw)
+    shapes = [(k, tuple(v.shape)) for k, v in orc.state_dict().items()]
+    assert shapes == [(k, tuple(v.shape)) for k, v in prod.state_dict().items()]
+    sd = recipe.fill_state_dict(shapes, seed)
+    prod.load_state_dict(sd)
+    orc.load_state_dict(sd)
+    return prod, orc, sd
+
+
+@pytest.mark.parametrize("et,mode", [(0, "plain"), (0, "multi"), (4, "plain"), (4, "multi")])
+def test_emulated_two_token_variant_matches_reference_golden(monkeypatch, et, mode):
+    """Class + distillation token (flexible_vit_sr_distill_patch14_224[_supernet]): schema, masks, (cls, dst) logits in train
+    and eval mode and every gradient against fixture F14 (imported reference) and the oracle."""
+    emu_kernels.install(monkeypatch)
+    g = np.load(os.path.join(G, "f14_distill_t%d_%s.npz" % (et, mode)))
+    prod, orc, sd = build_distill_pair(et, mode, 140 + et)
+    assert list(prod.state_dict().keys()) == list(g["keys"]) and recipe.checksum(sd) == int(g["state_crc"])
+    assert sorted(prod.no_weight_decay()) == list(g["no_weight_decay"])
+    prod.set_compute_dtype(torch.float32)
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    t2 = pt[:, 0, :].contiguous()
+    prod.train(); orc.train()
+    if mode != "plain":
+        prod.set_epoch(31); orc.set_epoch(31)
+        prod.load_state_dict(sd); orc.load_state_dict(sd)
+    torch.manual_seed(555 + 31)
+    cls, dst = prod(x)
+    if mode != "plain":
+        assert np.array_equal(torch.stack(prod.last_keeps).numpy(), g["keeps"])
+    assert rel(cls.detach(), torch.from_numpy(g["cls"])) < 5e-5 and rel(dst.detach(), torch.from_numpy(g["dst"])) < 5e-5
+    (O.soft_target_ce(cls, t) + O.soft_target_ce(dst, t2)).backward()
+    params = dict(prod.named_parameters())
+    for k in g.files:
+        if k.startswith("grad."):
+            assert rel(params[k[5:]].grad, torch.from_numpy(g[k])) < 2e-4, k
+    ocls, odst = orc(x, keeps=prod.last_keeps if mode != "plain" else None)
+    (O.soft_target_ce(ocls, t) + O.soft_target_ce(odst, t2)).backward()
+    op = dict(orc.named_parameters())
+    for n, p in prod.named_parameters():
+        assert p.grad is not None and rel(p.grad, op[n].grad) < 2e-4, n
+    prod.eval()
+    prod.load_state_dict(sd)
+    with torch.no_grad():
+        ec, ed = prod(x)
+    assert rel(ec, torch.from_numpy(g["eval.cls"])) < 5e-5 and rel(ed, torch.from_numpy(g["eval.dst"])) < 5e-5
+
+
+def _kd_epoch(prod, dev, mode, hard):
+    from vitres import engine
+    opt = torch.optim.AdamW(engine.param_groups_weight_decay(prod, 0.05), lr=1e-3)
+    loader = []
+    for it in range(3):
+        x, t, _, _ = recipe.inputs(300 + it, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+        loader.append((x, t))
+
+    def scaler(loss, optimizer, clip_grad=None, parameters=None, create_graph=False):
+        loss.backward()
+        optimizer.step()
+
+    class Crit(torch.nn.Module):
+        def forward(self, x, t):
+            return O.soft_target_ce(x, t)
+    if mode != "plain":
+        prod.set_epoch(31)
+    torch.manual_seed(4321)
+    keeps = []
+    orig = type(prod).forward
+
+    def fwd(self, *a, **k):
+        out = orig(self, *a, **k)
+        if self.last_keeps:
+            keeps.extend(self.last_keeps)
+        return out
+    type(prod).forward = fwd
+    try:
+        stats = engine.train_one_epoch(prod, Crit(), loader, opt, dev, 31, scaler, max_norm=None, print_freq=0,
+                                       teacher_model=recipe.toy_teacher(recipe.MICRO_CLASSES).to(dev), hard_distill=hard, alpha=0.5,
+                                       arch_sample=("multi" if mode != "plain" else None), logger=type("L", (), {"info": staticmethod(lambda *_: None)}))
+    finally:
+        type(prod).forward = orig
+    return stats, keeps
+
+
+def test_knowledge_distillation_loss_matches_reference():
+    from vitres.engine import KnowledgeDistillationLoss
+    g = np.load(os.path.join(G, "f15_distillation_engine.npz"))
+    gen = torch.Generator().manual_seed(5)
+    xs, ts = torch.randn(8, 10, generator=gen), torch.randn(8, 10, generator=gen) * 2
+    for hard, tag in ((True, "hard"), (False, "soft")):
+        xv = xs.clone().requires_grad_(True)
+        loss = KnowledgeDistillationLoss(hard_distill=hard)(xv, ts)
+        loss.backward()
+        assert abs(loss.item() - float(g["kd.%s.loss" % tag])) < 1e-6
+        assert rel(xv.grad, torch.from_numpy(g["kd.%s.grad" % tag])) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["plain", "multi"])
+@pytest.mark.parametrize("hard", [True, False])
+def test_emulated_distillation_epoch_matches_reference_engine(monkeypatch, mode, hard):
+    """engine.train_one_epoch with a teacher (hard / soft distillation through the distillation token, alpha = 0.5) on the
+    two-token micro net: masks, mean loss and parameters after three AdamW steps against the imported reference (F15)."""
+    emu_kernels.install(monkeypatch)
+    g = np.load(os.path.join(G, "f15_distillation_engine.npz"))
+    torch.manual_seed(2024)
+    prod, orc, sd = build_distill_pair(0, mode, 140)
+    prod.set_compute_dtype(torch.float32)
+    stats, keeps = _kd_epoch(prod, torch.device("cpu"), mode, hard)
+    tag = "%s.%s." % (mode, "hard" if hard else "soft")
+    assert abs(stats["loss"] - float(g[tag + "avg_loss"])) < 1e-5 * abs(float(g[tag + "avg_loss"]))
+    if mode != "plain":
+        assert np.array_equal(torch.stack(keeps).numpy(), g[tag + "keeps"])
+    after = prod.state_dict()
+    for k in g.files:
+        if k.startswith(tag + "after."):
+            assert rel(after[k[len(tag) + 6:]], torch.from_numpy(g[k])) < 2e-5, k

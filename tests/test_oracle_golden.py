@@ -344,3 +344,53 @@ def test_f12_same_seed_same_initialisation(et, sup):
     assert np.array_equal(sd["tokens"].numpy(), g[tag + "tokens"])
     assert np.array_equal(sd["cls_head.weight"].numpy(), g[tag + "head"])
     assert recipe.checksum(sd) == int(g[tag + "crc"])
+
+
+DISTILL_CASES = [(0, "plain"), (0, "multi"), (4, "plain"), (4, "multi")]
+
+
+def build_distill(et, mode):
+    kw = {}
+    if mode != "plain":
+        kw = dict(num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30)
+    return O.OracleViTSR(recipe.MICRO_DEFS[et], img_size=recipe.MICRO_IMG, num_classes=recipe.MICRO_CLASSES,
+                         supernet=(mode != "plain"), distill_token=True, patch_output=False, **kw)
+
+
+@pytest.mark.parametrize("et,mode", DISTILL_CASES)
+def test_f14_two_token_variant(et, mode):
+    """Class + distillation token (factories flexible_vit_sr_distill_patch14_224[_supernet]): schema, keep tables, both logits,
+    loss and gradients of the oracle against the imported reference."""
+    g = load("f14_distill_t%d_%s" % (et, mode))
+    m = build_distill(et, mode)
+    sd, shapes = load_recipe(m, 140 + et)
+    assert recipe.checksum(sd) == int(g["state_crc"])
+    assert [k for k, _ in shapes] == list(g["keys"]) and [str(s) for _, s in shapes] == list(g["shapes"])
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    t2 = pt[:, 0, :].contiguous()
+    m.train()
+    if mode != "plain":
+        m.set_epoch(31)
+        m.load_state_dict(sd)
+    torch.manual_seed(555 + 31)
+    (cls, dst), used = m(x, return_keeps=True)
+    if mode != "plain":
+        assert np.array_equal(torch.stack(used).numpy(), g["keeps"])
+    loss = O.soft_target_ce(cls, t) + O.soft_target_ce(dst, t2)
+    close(cls.detach(), g["cls"])
+    close(dst.detach(), g["dst"])
+    assert abs(loss.item() - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    loss.backward()
+    params = dict(m.named_parameters())
+    n = 0
+    for k in g.files:
+        if k.startswith("grad."):
+            close(params[k[5:]].grad, g[k], tol=5e-5)
+            n += 1
+    assert n > 15
+    m.load_state_dict(sd)
+    m.eval()
+    with torch.no_grad():
+        ec, ed = m(x)
+    close(ec, g["eval.cls"])
+    close(ed, g["eval.dst"])

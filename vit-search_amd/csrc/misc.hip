@@ -196,10 +196,10 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restri
 __global__ __launch_bounds__(256) void embed_cls_kernel(const float* __restrict__ tokens, const float* __restrict__ pos,
                                                         float* __restrict__ x, const int* __restrict__ keep, int B, int N,
                                                         int C) {
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, t = blockIdx.y;        // token row t (class token, distillation token)
     const int kc = keep ? keep[b] : C;
     for (int c = threadIdx.x; c < C; c += blockDim.x)
-        x[(long long)b * N * C + c] = (c < kc) ? tokens[c] + pos[c] : 0.f;
+        x[((long long)b * N + t) * C + c] = (c < kc) ? tokens[t * C + c] + pos[t * C + c] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, const int* __restrict__ keep, int M, int C,
@@ -212,25 +212,25 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, c
 // ---- spatial-reduction block pieces (3x3 stride 2 pad 1 conv as GEMM; 2x2 avg-pool residual) ------------
 // col[(b,oh,ow)][(kh,kw,c)] = y[b, 1 + (2oh-1+kh)*g + (2ow-1+kw), c]  (0 outside)
 template <typename T>
-__global__ __launch_bounds__(256) void sr_im2col_kernel(const T* __restrict__ y, T* __restrict__ col, int B, int g, int C) {
+__global__ __launch_bounds__(256) void sr_im2col_kernel(const T* __restrict__ y, T* __restrict__ col, int B, int g, int C, int NT) {
     const int go = g / 2;
     const int row = blockIdx.x;  // (b, oh, ow)
     const int tap = blockIdx.y;  // kh*3+kw
     const int ow = row % go, oh = (row / go) % go, b = row / (go * go);
     const int ih = 2 * oh - 1 + tap / 3, iw = 2 * ow - 1 + tap % 3;
     const bool in = ih >= 0 && ih < g && iw >= 0 && iw < g;
-    const T* src = y + ((long long)b * (1 + g * g) + 1 + ih * g + iw) * C;
+    const T* src = y + ((long long)b * (NT + g * g) + NT + ih * g + iw) * C;
     T* dst = col + (long long)row * 9 * C + tap * C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) dst[c] = in ? src[c] : (T)0;
 }
 
 // dy[b,1+ih*g+iw,c] = sum over taps (kh,kw) with 2oh-1+kh==ih, 2ow-1+kw==iw of dcol[(b,oh,ow)][(kh,kw,c)]
 template <typename T>
-__global__ __launch_bounds__(256) void sr_col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dy, int B, int g, int C) {
+__global__ __launch_bounds__(256) void sr_col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dy, int B, int g, int C, int NT) {
     const int go = g / 2;
     const int pix = blockIdx.x;  // (b, ih, iw)
     const int iw = pix % g, ih = (pix / g) % g, b = pix / (g * g);
-    T* dst = dy + ((long long)b * (1 + g * g) + 1 + ih * g + iw) * C;
+    T* dst = dy + ((long long)b * (NT + g * g) + NT + ih * g + iw) * C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = 0.f;
 #pragma unroll
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void sr_col2im_kernel(const T* __restrict__ dc
 // bf16, C % 8 == 0: one 16-byte chunk (8 channels) per thread -- the element-per-thread kernels above launch one 512-byte
 // workgroup per (pixel, tap) and were launch-rate bound (0.8 TB/s)
 __global__ __launch_bounds__(256) void sr_im2col_v8_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ col, int B, int g,
-                                                           int C, long long total) {
+                                                           int C, long long total, int NT) {
     const int go = g / 2, c8n = C / 8;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int c8 = (int)(idx % c8n);
@@ -266,13 +266,13 @@ __global__ __launch_bounds__(256) void sr_im2col_v8_kernel(const bf16_t* __restr
         const int ih = 2 * oh - 1 + tap / 3, iw = 2 * ow - 1 + tap % 3;
         const bool in = ih >= 0 && ih < g && iw >= 0 && iw < g;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (in) v = *reinterpret_cast<const uint4*>(y + ((long long)b * (1 + g * g) + 1 + ih * g + iw) * C + c8 * 8);
+        if (in) v = *reinterpret_cast<const uint4*>(y + ((long long)b * (NT + g * g) + NT + ih * g + iw) * C + c8 * 8);
         *reinterpret_cast<uint4*>(col + row * 9 * C + (long long)tap * C + c8 * 8) = v;
     }
 }
 
 __global__ __launch_bounds__(256) void sr_col2im_v8_kernel(const bf16_t* __restrict__ dcol, bf16_t* __restrict__ dy, int B, int g,
-                                                           int C, long long total) {
+                                                           int C, long long total, int NT) {
     const int go = g / 2, c8n = C / 8;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int c8 = (int)(idx % c8n);
@@ -303,25 +303,25 @@ __global__ __launch_bounds__(256) void sr_col2im_v8_kernel(const bf16_t* __restr
                 }
             }
         }
-        *reinterpret_cast<uint4*>(dy + ((long long)b * (1 + g * g) + 1 + ih * g + iw) * C + c8 * 8) =
+        *reinterpret_cast<uint4*>(dy + ((long long)b * (NT + g * g) + NT + ih * g + iw) * C + c8 * 8) =
             make_uint4(pack_bf2(s[0], s[1]), pack_bf2(s[2], s[3]), pack_bf2(s[4], s[5]), pack_bf2(s[6], s[7]));
     }
 }
 
 // out[b,0,:] = pad(x[b,0,:]); out[b,1+(oh,ow),:] = pad(mean of the 2x2 patch rows)
 __global__ __launch_bounds__(256) void sr_resid_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int g,
-                                                       int Cin, int Cout) {
-    const int go = g / 2, No = 1 + go * go, Ni = 1 + g * g;
+                                                       int Cin, int Cout, int NT) {
+    const int go = g / 2, No = NT + go * go, Ni = NT + g * g;
     const int row = blockIdx.x;  // b*No + r
     const int r = row % No, b = row / No;
     float* dst = out + (long long)row * Cout;
     const float* xb = x + (long long)b * Ni * Cin;
-    if (r == 0) {
-        for (int c = threadIdx.x; c < Cout; c += blockDim.x) dst[c] = c < Cin ? xb[c] : 0.f;
+    if (r < NT) {                // token rows are copied
+        for (int c = threadIdx.x; c < Cout; c += blockDim.x) dst[c] = c < Cin ? xb[(long long)r * Cin + c] : 0.f;
         return;
     }
-    const int ow = (r - 1) % go, oh = (r - 1) / go;
-    const float* p00 = xb + (long long)(1 + (2 * oh) * g + 2 * ow) * Cin;
+    const int ow = (r - NT) % go, oh = (r - NT) / go;
+    const float* p00 = xb + (long long)(NT + (2 * oh) * g + 2 * ow) * Cin;
     const float* p01 = p00 + Cin;
     const float* p10 = p00 + (long long)g * Cin;
     const float* p11 = p10 + Cin;
@@ -330,19 +330,19 @@ __global__ __launch_bounds__(256) void sr_resid_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void sr_resid_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int B,
-                                                           int g, int Cin, int Cout, int accumulate) {
-    const int go = g / 2, No = 1 + go * go, Ni = 1 + g * g;
+                                                           int g, int Cin, int Cout, int accumulate, int NT) {
+    const int go = g / 2, No = NT + go * go, Ni = NT + g * g;
     const int row = blockIdx.x;  // b*Ni + r  (input rows)
     const int r = row % Ni, b = row / Ni;
     float* dst = dx + (long long)row * Cin;
     const float* src;
     float f;
-    if (r == 0) {
-        src = dout + (long long)b * No * Cout;
+    if (r < NT) {
+        src = dout + ((long long)b * No + r) * Cout;
         f = 1.0f;
     } else {
-        const int iw = (r - 1) % g, ih = (r - 1) / g;
-        src = dout + ((long long)b * No + 1 + (ih / 2) * go + iw / 2) * Cout;
+        const int iw = (r - NT) % g, ih = (r - NT) / g;
+        src = dout + ((long long)b * No + NT + (ih / 2) * go + iw / 2) * Cout;
         f = 0.25f;
     }
     for (int c = threadIdx.x; c < Cin; c += blockDim.x) {
@@ -468,9 +468,9 @@ extern "C" int vr_im2col_patch(const float* img, void* col, int32_t B, int32_t C
 }
 
 extern "C" int vr_embed_cls(const float* tokens, const float* pos, float* x, const int32_t* keep, int32_t B, int32_t N,
-                            int32_t C, vr_stream_t stream) {
-    if (!tokens || !pos || !x || B <= 0) return VR_EINVAL;
-    hipLaunchKernelGGL(embed_cls_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, pos, x, keep, B, N, C);
+                            int32_t C, int32_t num_tokens, vr_stream_t stream) {
+    if (!tokens || !pos || !x || B <= 0 || num_tokens < 1 || num_tokens > N) return VR_EINVAL;
+    hipLaunchKernelGGL(embed_cls_kernel, dim3(B, num_tokens), dim3(256), 0, (hipStream_t)stream, tokens, pos, x, keep, B, N, C);
     VR_CHECK_LAUNCH();
     return VR_OK;
 }
@@ -482,53 +482,60 @@ extern "C" int vr_mask_rows(float* x, const int32_t* keep, int32_t M, int32_t C,
     return VR_OK;
 }
 
-extern "C" int vr_sr_im2col(const void* y, void* col, int32_t B, int32_t g, int32_t C, int32_t dtype, vr_stream_t stream) {
-    if (!y || !col || B <= 0 || g <= 0 || (g & 1)) return VR_EINVAL;
+extern "C" int vr_sr_im2col(const void* y, void* col, int32_t B, int32_t g, int32_t C, int32_t num_tokens, int32_t dtype,
+                            vr_stream_t stream) {
+    if (!y || !col || B <= 0 || g <= 0 || (g & 1) || num_tokens < 1) return VR_EINVAL;
+    const int NT = num_tokens;
     dim3 grid(B * (g / 2) * (g / 2), 9);
     if (dtype == VR_BF16 && C % 8 == 0 && !((uintptr_t)y & 15) && !((uintptr_t)col & 15)) {
         const long long total = (long long)B * (g / 2) * (g / 2) * 9 * (C / 8);
         const long long blocks = (total + 255) / 256;
         hipLaunchKernelGGL(sr_im2col_v8_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)y, (bf16_t*)col, B, g, C, total);
+                           (const bf16_t*)y, (bf16_t*)col, B, g, C, total, NT);
     } else if (dtype == VR_F32)
-        hipLaunchKernelGGL((sr_im2col_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, (float*)col, B, g, C);
+        hipLaunchKernelGGL((sr_im2col_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, (float*)col, B, g, C, NT);
     else if (dtype == VR_BF16)
-        hipLaunchKernelGGL((sr_im2col_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (bf16_t*)col, B, g, C);
+        hipLaunchKernelGGL((sr_im2col_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (bf16_t*)col, B, g, C, NT);
     else
         return VR_EUNSUPPORTED;
     VR_CHECK_LAUNCH();
     return VR_OK;
 }
 
-extern "C" int vr_sr_col2im(const void* dcol, void* dy, int32_t B, int32_t g, int32_t C, int32_t dtype, vr_stream_t stream) {
-    if (!dcol || !dy || B <= 0 || g <= 0 || (g & 1)) return VR_EINVAL;
+extern "C" int vr_sr_col2im(const void* dcol, void* dy, int32_t B, int32_t g, int32_t C, int32_t num_tokens, int32_t dtype,
+                            vr_stream_t stream) {
+    if (!dcol || !dy || B <= 0 || g <= 0 || (g & 1) || num_tokens < 1) return VR_EINVAL;
+    const int NT = num_tokens;
     dim3 grid(B * g * g);
     if (dtype == VR_BF16 && C % 8 == 0 && !((uintptr_t)dcol & 15) && !((uintptr_t)dy & 15)) {
         const long long total = (long long)B * g * g * (C / 8);
         const long long blocks = (total + 255) / 256;
         hipLaunchKernelGGL(sr_col2im_v8_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)dcol, (bf16_t*)dy, B, g, C, total);
+                           (const bf16_t*)dcol, (bf16_t*)dy, B, g, C, total, NT);
     } else if (dtype == VR_F32)
-        hipLaunchKernelGGL((sr_col2im_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dcol, (float*)dy, B, g, C);
+        hipLaunchKernelGGL((sr_col2im_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dcol, (float*)dy, B, g, C, NT);
     else if (dtype == VR_BF16)
-        hipLaunchKernelGGL((sr_col2im_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dcol, (bf16_t*)dy, B, g, C);
+        hipLaunchKernelGGL((sr_col2im_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dcol, (bf16_t*)dy, B, g, C, NT);
     else
         return VR_EUNSUPPORTED;
     VR_CHECK_LAUNCH();
     return VR_OK;
 }
 
-extern "C" int vr_sr_resid(const float* x, float* out, int32_t B, int32_t g, int32_t Cin, int32_t Cout, vr_stream_t stream) {
-    if (!x || !out || B <= 0 || g <= 0 || (g & 1) || Cout < Cin) return VR_EINVAL;
-    hipLaunchKernelGGL(sr_resid_kernel, dim3(B * (1 + (g / 2) * (g / 2))), dim3(256), 0, (hipStream_t)stream, x, out, B, g, Cin, Cout);
+extern "C" int vr_sr_resid(const float* x, float* out, int32_t B, int32_t g, int32_t Cin, int32_t Cout, int32_t num_tokens,
+                           vr_stream_t stream) {
+    if (!x || !out || B <= 0 || g <= 0 || (g & 1) || Cout < Cin || num_tokens < 1) return VR_EINVAL;
+    hipLaunchKernelGGL(sr_resid_kernel, dim3(B * (num_tokens + (g / 2) * (g / 2))), dim3(256), 0, (hipStream_t)stream, x, out, B, g, Cin,
+                       Cout, num_tokens);
     VR_CHECK_LAUNCH();
     return VR_OK;
 }
 
 extern "C" int vr_sr_resid_bwd(const float* dout, float* dx, int32_t B, int32_t g, int32_t Cin, int32_t Cout,
-                               int32_t accumulate, vr_stream_t stream) {
-    if (!dout || !dx || B <= 0 || g <= 0 || (g & 1) || Cout < Cin) return VR_EINVAL;
-    hipLaunchKernelGGL(sr_resid_bwd_kernel, dim3(B * (1 + g * g)), dim3(256), 0, (hipStream_t)stream, dout, dx, B, g, Cin, Cout, accumulate);
+                               int32_t accumulate, int32_t num_tokens, vr_stream_t stream) {
+    if (!dout || !dx || B <= 0 || g <= 0 || (g & 1) || Cout < Cin || num_tokens < 1) return VR_EINVAL;
+    hipLaunchKernelGGL(sr_resid_bwd_kernel, dim3(B * (num_tokens + g * g)), dim3(256), 0, (hipStream_t)stream, dout, dx, B, g, Cin, Cout,
+                       accumulate, num_tokens);
     VR_CHECK_LAUNCH();
     return VR_OK;
 }

@@ -61,11 +61,11 @@ SYMBOLS = {
     "vr_token_mean_bwd": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "vr_batchsum": [c_void_p, c_void_p, c_int32, c_int64, c_void_p],
     "vr_im2col_patch": [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p],
-    "vr_embed_cls": [c_void_p] * 4 + [c_int32] * 3 + [c_void_p],
-    "vr_sr_im2col": [c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p],
-    "vr_sr_col2im": [c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p],
-    "vr_sr_resid": [c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p],
-    "vr_sr_resid_bwd": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
+    "vr_embed_cls": [c_void_p] * 4 + [c_int32] * 4 + [c_void_p],
+    "vr_sr_im2col": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
+    "vr_sr_col2im": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
+    "vr_sr_resid": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
+    "vr_sr_resid_bwd": [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p],
     "vr_mask_rows": [c_void_p, c_void_p] + [c_int32] * 3 + [c_void_p],
     "vr_im2col3x3": [c_void_p, c_void_p] + [c_int32] * 8 + [c_void_p],
     "vr_col2im3x3": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],

@@ -107,10 +107,34 @@ class GradSync:
                 p.grad.mul_(1.0 / self.world)
 
 
+class KnowledgeDistillationLoss(torch.nn.Module):
+    """Distillation term on the distillation token's logits (reference engine.py:25-46): hard = cross entropy against the
+    teacher's arg-max class; soft = T^2 * mean_b sum_k -softmax(teacher / T) * log_softmax(x / T) with T = soft_temperature."""
+
+    def __init__(self, hard_distill=True, soft_temperature=3.0):
+        super().__init__()
+        self.hard_distill = hard_distill
+        self.soft_temperature = None if hard_distill else float(soft_temperature)
+
+    def forward(self, x, teacher_output):
+        if self.hard_distill:
+            return torch.nn.functional.cross_entropy(x, torch.argmax(teacher_output, dim=1))
+        t = self.soft_temperature
+        soft = torch.softmax(teacher_output / t, dim=1)
+        return torch.mean(torch.sum(-soft * torch.log_softmax(x / t, dim=1), 1)) * (t * t)
+
+    def extra_repr(self):
+        return 'hard_distill={}'.format(self.hard_distill) + ('' if self.hard_distill else
+                                                              ', soft_temperature={}'.format(self.soft_temperature))
+
+
 def train_step(model, criterion, optimizer, samples, targets, patch_targets=None, patch_output_type=None, epoch=0,
-               train_iter=0, arch_sample=None, grad_sync=None, loss_scaler=None, max_norm=None, average_grads=True):
+               train_iter=0, arch_sample=None, grad_sync=None, loss_scaler=None, max_norm=None, average_grads=True,
+               teacher_output=None, kd_criterion=None, alpha=0.5):
     """One optimisation step; returns the loss tensor (on device, not synchronised).  average_grads=False leaves the
-    all-reduced SUM in the arena (optimizer applies 1/world: vitres.optim.FlatAdamW.grad_scale)."""
+    all-reduced SUM in the arena (optimizer applies 1/world: vitres.optim.FlatAdamW.grad_scale).  teacher_output +
+    kd_criterion: knowledge distillation, loss = (1 - alpha) * criterion(cls) + alpha * kd(dst, teacher) (engine.py:135-148;
+    a one-token model distils through its class logits, as the reference's `output_dst = outputs`)."""
     rng = None
     if arch_sample is not None:                                   # engine.py:119-131
         rng = torch.random.get_rng_state()
@@ -120,8 +144,10 @@ def train_step(model, criterion, optimizer, samples, targets, patch_targets=None
             raise ValueError('arch_sample has invalid value {}.'.format(arch_sample))
     if patch_targets is None:
         outputs = model(samples)
-        output_cls = outputs[0] if isinstance(outputs, tuple) else outputs
+        output_cls, output_dst = (outputs[0], outputs[1]) if isinstance(outputs, tuple) else (outputs, outputs)
         loss = criterion(output_cls, targets)
+        if teacher_output is not None:
+            loss = loss * (1 - alpha) + kd_criterion(output_dst, teacher_output) * alpha
     else:
         cls_pred, patch_pred = model(samples, patch_output_type=patch_output_type)
         loss = criterion(cls_pred, targets)
@@ -248,8 +274,10 @@ class GraphedTrainStep:
 def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler=None, max_norm=0,
                     model_ema=None, mixup_fn=None, print_freq=100, teacher_model=None, hard_distill=True, alpha=0.5,
                     logger=None, arch_sample=False, patch_mixup_fn=None, grad_sync=None, sync_every=1):
-    if teacher_model is not None:
-        raise NotImplementedError('knowledge distillation is out of scope of the HIP hot path (SURVEY.md section 2 item 18)')
+    kd_criterion = None
+    if teacher_model is not None:                                 # engine.py:91-95: any module mapping images to logits
+        kd_criterion = KnowledgeDistillationLoss(hard_distill=hard_distill)
+        teacher_model.eval()
     model.train()
     criterion.train()
     print_out = logger.info if logger else print
@@ -266,8 +294,13 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
             assert patch_mixup_fn is None
         if patch_mixup_fn is not None:
             samples, targets, patch_targets, patch_output_type = patch_mixup_fn(samples, targets)
+        teacher_output = None
+        if teacher_model is not None:
+            with torch.no_grad():
+                teacher_output = teacher_model(samples)
         loss = train_step(model, criterion, optimizer, samples, targets, patch_targets, patch_output_type, epoch,
-                          train_iter, arch_sample, grad_sync, loss_scaler, max_norm)
+                          train_iter, arch_sample, grad_sync, loss_scaler, max_norm, teacher_output=teacher_output,
+                          kd_criterion=kd_criterion, alpha=alpha)
         pending.append(loss)
         if model_ema is not None:
             model_ema.update(model)
@@ -309,17 +342,30 @@ def evaluate(data_loader, model, device, print_freq=100, logger=None):
         images = images.to(device, non_blocking=True)
         target = target.to(device, non_blocking=True)
         output = model(images)
-        output_cls = output[0] if isinstance(output, tuple) else output
+        output_cls, output_dst = (output[0], output[1]) if isinstance(output, tuple) else (output, None)
         loss = criterion(output_cls, target)
         acc1, acc5 = accuracy(output_cls, target, topk=(1, 5))
         n = images.shape[0]
         meters['loss'].update(loss.item())
         meters['acc1'].update(acc1.item(), n=n)
         meters['acc5'].update(acc5.item(), n=n)
+        if output_dst is not None:                       # two-token variants: distillation head and joint softmax (:230-238)
+            d1, d5 = accuracy(output_dst, target, topk=(1, 5))
+            meters['dst_acc1'].update(d1.item(), n=n)
+            meters['dst_acc5'].update(d5.item(), n=n)
+            joint = torch.softmax(output_cls, dim=1) + torch.softmax(output_dst, dim=1)
+            j1, j5 = accuracy(joint, target, topk=(1, 5))
+            meters['jnt_acc1'].update(j1.item(), n=n)
+            meters['jnt_acc5'].update(j5.item(), n=n)
     for m in meters.values():
         m.synchronize_between_processes()
-    print_out('Acc@1: {:.2f}, Acc@5: {:.2f}, loss: {:.2f}\n'.format(meters['acc1'].global_avg, meters['acc5'].global_avg,
-                                                                  meters['loss'].global_avg))
+    info = 'Acc@1: {:.2f}, Acc@5: {:.2f}, loss: {:.2f}'.format(meters['acc1'].global_avg, meters['acc5'].global_avg,
+                                                             meters['loss'].global_avg)
+    if 'dst_acc1' in meters:
+        info += ', Distill Acc@1: {:.2f}, Distill Acc@5: {:.2f}, Joint Acc@1: {:.2f}, Joint Acc@5: {:.2f}'.format(
+            meters['dst_acc1'].global_avg, meters['dst_acc5'].global_avg, meters['jnt_acc1'].global_avg,
+            meters['jnt_acc5'].global_avg)
+    print_out(info + '\n')
     return {k: m.global_avg for k, m in meters.items()}
 
 

@@ -279,17 +279,18 @@ def sr_fwd(x, p, cfg, embed_keep, new_keep, save, pre=None):
     B, Ni, C = x.shape
     g = cfg["grid"]
     go = g // 2
-    No = 1 + go * go
+    T = cfg.get("tokens", 1)                                                 # leading token rows: class (+ distillation) token
+    No = T + go * go
     Co = cfg["cout"]
     dt = cfg["dtype"]
     y, mean, rstd = pre if pre is not None else K.ln_fwd(x, p["nw"], p["nb"], embed_keep, Ni, cfg["eps"], dt)
-    out = K.sr_resid(x, B, g, C, Co)
-    col = K.sr_im2col(y, B, g, C)
+    out = K.sr_resid(x, B, g, C, Co, T)
+    col = K.sr_im2col(y, B, g, C, T)
     K.gemm(col, p["reduce"].w_c, out, M=B * go * go, N=Co, K=9 * C, lda=9 * C, ldb=p["reduce"].ld, ldc=Co,
-           bias=p["reduce"].b, pos=p["pos"], resid=out, rows_in=go * go, c_map=(go * go, No, 1), keep_k=embed_keep,
+           bias=p["reduce"].b, pos=p["pos"], resid=out, rows_in=go * go, c_map=(go * go, No, T), keep_k=embed_keep,
            k_period=C)
-    K.gemm(y, p["token"].w_c, out, M=B, N=Co, K=C, lda=C, ldb=p["token"].ld, ldc=Co, bias=p["token"].b, resid=out,
-           rows_in=1, a_map=(1, Ni, 0), c_map=(1, No, 0))
+    K.gemm(y, p["token"].w_c, out, M=B * T, N=Co, K=C, lda=C, ldb=p["token"].ld, ldc=Co, bias=p["token"].b, resid=out,
+           rows_in=T, a_map=(T, Ni, 0), c_map=(T, No, 0))
     if new_keep is not None:
         K.mask_rows(out, new_keep, No)
     saved = (x, mean, rstd, y, col) if save else None
@@ -302,17 +303,18 @@ def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep, gt=None, next_cast=
     g = cfg["grid"]
     go = g // 2
     P = go * go
-    No = 1 + P
+    T = cfg.get("tokens", 1)
+    No = T + P
     Co = cfg["cout"]
     dt = cfg["dtype"]
     if gt is None:
         gt = K.scale_mask_cast(gout, None, new_keep, No, dt)                # [B, No, Co]
-    # token_transform (row 0 of every sample)
+    # token_transform (the T token rows of every sample)
     def wgrads():
-        linear_wgrad(gt, y, grads["token.w"], B, Co, C, Co, C, a_map=(1, No, 0), b_map=(1, Ni, 0), db=grads["token.b"])
-        # patch_reduce (rows 1..)
-        K.batchsum(gout, grads["pos_sum"])                                  # [No, Co]; rows 1.. are d pos_embed
-        linear_wgrad(gt, col, grads["reduce.w"], B * P, Co, 9 * C, Co, 9 * C, a_map=(P, No, 1), db=grads["reduce.b"],
+        linear_wgrad(gt, y, grads["token.w"], B * T, Co, C, Co, C, a_map=(T, No, 0), b_map=(T, Ni, 0), db=grads["token.b"])
+        # patch_reduce (rows T..)
+        K.batchsum(gout, grads["pos_sum"])                                  # [No, Co]; rows T.. are d pos_embed
+        linear_wgrad(gt, col, grads["reduce.w"], B * P, Co, 9 * C, Co, 9 * C, a_map=(P, No, T), db=grads["reduce.b"],
                      sched=1 if _overlap(gout) else 0)
         if "finish" in grads:
             grads["finish"]()                                               # re-layout of the conv weight gradient
@@ -321,11 +323,11 @@ def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep, gt=None, next_cast=
     else:
         wgrads()
     dcol = torch.empty((B * P, 9 * C), dtype=dt, device=x.device)
-    linear_dgrad(gt, p["reduce"], dcol, B * P, 9 * C, Co, Co, 9 * C, a_map=(P, No, 1), rows_in=P)
+    linear_dgrad(gt, p["reduce"], dcol, B * P, 9 * C, Co, Co, 9 * C, a_map=(P, No, T), rows_in=P)
     dy = torch.empty((B, Ni, C), dtype=dt, device=x.device)
-    K.sr_col2im(dcol, dy, B, g, C)
-    linear_dgrad(gt, p["token"], dy, B, C, Co, Co, C, a_map=(1, No, 0), c_map=(1, Ni, 0), rows_in=1)
-    gres = K.sr_resid_bwd(gout, B, g, C, Co)
+    K.sr_col2im(dcol, dy, B, g, C, T)
+    linear_dgrad(gt, p["token"], dy, B * T, C, Co, Co, C, a_map=(T, No, 0), c_map=(T, Ni, 0), rows_in=T)
+    gres = K.sr_resid_bwd(gout, B, g, C, Co, T)
     out = K.ln_bwd(dy, x, p["nw"], mean, rstd, embed_keep, Ni, gres, grads["nw"], grads["nb"], next_cast=next_cast)
     if _overlap(gout):
         join_side()
@@ -337,27 +339,29 @@ def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep, gt=None, next_cast=
 # --------------------------------------------------------------------------------------------------
 def embed0_fwd(img, p, cfg, keep, save):
     B = img.shape[0]
-    P, C, N = cfg["patches"], cfg["dim"], cfg["patches"] + 1
+    T = cfg.get("tokens", 1)
+    P, C, N = cfg["patches"], cfg["dim"], cfg["patches"] + T
     dt = cfg["dtype"]
     ldk = p["proj"].ld
     col = K.im2col_patch(img, cfg["patch"], ldk, dt)
     x = torch.empty((B, N, C), dtype=torch.float32, device=img.device)
-    K.gemm(col, p["proj"].w_c, x, M=B * P, N=C, K=ldk, lda=ldk, ldb=ldk, ldc=C, bias=p["proj"].b, pos=p["pos"][0, 1:],
-           keep_n=keep, rows_in=P, c_map=(P, N, 1))
-    K.embed_cls(p["tokens"], p["pos"], x, keep)
+    K.gemm(col, p["proj"].w_c, x, M=B * P, N=C, K=ldk, lda=ldk, ldb=ldk, ldc=C, bias=p["proj"].b, pos=p["pos"][0, T:],
+           keep_n=keep, rows_in=P, c_map=(P, N, T))
+    K.embed_cls(p["tokens"], p["pos"], x, keep, T)
     return x, ((col,) if save else None)
 
 
 def embed0_bwd(g, saved, p, grads, cfg, keep, gt=None):
     (col,) = saved
     B, N, C = g.shape
-    P = N - 1
+    T = cfg.get("tokens", 1)
+    P = N - T
     dt = cfg["dtype"]
     ldk = p["proj"].ld
     if gt is None:
         gt = K.scale_mask_cast(g, None, keep, N, dt)
-    linear_wgrad(gt, col, grads["proj.w"], B * P, C, ldk, C, ldk, a_map=(P, N, 1), db=grads["proj.b"])
-    K.batchsum(g, grads["pos"])                                             # d pos_embed [N, C] (row 0 also = d tokens)
+    linear_wgrad(gt, col, grads["proj.w"], B * P, C, ldk, C, ldk, a_map=(P, N, T), db=grads["proj.b"])
+    K.batchsum(g, grads["pos"])                                             # d pos_embed [N, C] (rows 0..T-1 also = d tokens)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -368,17 +372,21 @@ def head_fwd(x, p, cfg, keep, with_patch, save, pre=None):
     dt = cfg["dtype"]
     nc = cfg["classes"]
     y, mean, rstd = pre if pre is not None else K.ln_fwd(x, p["nw"], p["nb"], keep, N, cfg["eps"], dt)
+    T = cfg.get("tokens", 1)
     cls = torch.empty((B, nc), dtype=torch.float32, device=x.device)
     K.gemm(y, p["cls"].w_c, cls, M=B, N=nc, K=C, lda=C, ldb=p["cls"].ld, ldc=nc, bias=p["cls"].b, a_map=(1, N, 0))
     pat, ym = None, None
-    if with_patch == 2:                 # patch_output_type='avg': patch head on the mean patch token (:447-449)
-        ym = K.token_mean(y, 1)
+    if with_patch == 3:                 # two-token variants: second result = dst_head(distillation token) (:455-458)
+        pat = torch.empty((B, nc), dtype=torch.float32, device=x.device)
+        K.gemm(y, p["dst"].w_c, pat, M=B, N=nc, K=C, lda=C, ldb=p["dst"].ld, ldc=nc, bias=p["dst"].b, a_map=(1, N, 1))
+    elif with_patch == 2:               # patch_output_type='avg': patch head on the mean patch token (:447-449)
+        ym = K.token_mean(y, T)
         pat = torch.empty((B, nc), dtype=torch.float32, device=x.device)
         K.gemm(ym, p["patch"].w_c, pat, M=B, N=nc, K=C, lda=C, ldb=p["patch"].ld, ldc=nc, bias=p["patch"].b)
     elif with_patch:
-        pat = torch.empty((B, N - 1, nc), dtype=torch.float32, device=x.device)
-        K.gemm(y, p["patch"].w_c, pat, M=B * (N - 1), N=nc, K=C, lda=C, ldb=p["patch"].ld, ldc=nc, bias=p["patch"].b,
-               a_map=(N - 1, N, 1))
+        pat = torch.empty((B, N - T, nc), dtype=torch.float32, device=x.device)
+        K.gemm(y, p["patch"].w_c, pat, M=B * (N - T), N=nc, K=C, lda=C, ldb=p["patch"].ld, ldc=nc, bias=p["patch"].b,
+               a_map=(N - T, N, T))
     saved = (x, mean, rstd, y, ym) if save else None
     return cls, pat, saved
 
@@ -399,15 +407,20 @@ def head_bwd(dcls, dpat, saved, p, grads, cfg, keep, next_cast=None):
         gc = padded(dcls.reshape(B, nc))
         linear_wgrad(gc, y, grads["cls.w"], B, nc, C, ldp, C, b_map=(1, N, 0), db=grads["cls.b"])
         linear_dgrad(gc, p["cls"], dy, B, C, nc, ldp, C, c_map=(1, N, 0))
-    if dpat is not None and ym is not None:                                  # 'avg'
+    T = cfg.get("tokens", 1)
+    if dpat is not None and "dst" in p:                                      # distillation head on token row 1
+        gd = padded(dpat.reshape(B, nc))
+        linear_wgrad(gd, y, grads["dst.w"], B, nc, C, ldp, C, b_map=(1, N, 1), db=grads["dst.b"])
+        linear_dgrad(gd, p["dst"], dy, B, C, nc, ldp, C, c_map=(1, N, 1))
+    elif dpat is not None and ym is not None:                                # 'avg'
         gp = padded(dpat.reshape(B, nc))
         linear_wgrad(gp, ym, grads["patch.w"], B, nc, C, ldp, C, db=grads["patch.b"])
         dmean = torch.empty((B, C), dtype=dt, device=x.device)
         linear_dgrad(gp, p["patch"], dmean, B, C, nc, ldp, C)
-        K.token_mean_bwd(dmean, dy, 1)
+        K.token_mean_bwd(dmean, dy, T)
     elif dpat is not None:
-        R = B * (N - 1)
+        R = B * (N - T)
         gp = padded(dpat.reshape(R, nc))
-        linear_wgrad(gp, y, grads["patch.w"], R, nc, C, ldp, C, b_map=(N - 1, N, 1), db=grads["patch.b"])
-        linear_dgrad(gp, p["patch"], dy, R, C, nc, ldp, C, c_map=(N - 1, N, 1))
+        linear_wgrad(gp, y, grads["patch.w"], R, nc, C, ldp, C, b_map=(N - T, N, T), db=grads["patch.b"])
+        linear_dgrad(gp, p["patch"], dy, R, C, nc, ldp, C, c_map=(N - T, N, T))
     return K.ln_bwd(dy, x, p["nw"], mean, rstd, keep, N, None, grads["nw"], grads["nb"], next_cast=next_cast)

@@ -288,32 +288,33 @@ def im2col_patch(img, P, ldk, out_dtype):
     return col
 
 
-def embed_cls(tokens, pos, x, keep):
+def embed_cls(tokens, pos, x, keep, num_tokens=1):
+    """token rows 0..num_tokens-1 of x [B, N, C] <- tokens + pos (masked)."""
     B, N, C = x.shape
-    _lib.check(_lib.lib().vr_embed_cls(_p(tokens), _p(pos), _p(x), _p(keep), B, N, C, _stream()), "vr_embed_cls")
+    _lib.check(_lib.lib().vr_embed_cls(_p(tokens), _p(pos), _p(x), _p(keep), B, N, C, num_tokens, _stream()), "vr_embed_cls")
     return x
 
 
-def sr_im2col(y, B, g, C):
+def sr_im2col(y, B, g, C, num_tokens=1):
     col = torch.empty((B * (g // 2) ** 2, 9 * C), dtype=y.dtype, device=y.device)
-    _lib.check(_lib.lib().vr_sr_im2col(_p(y), _p(col), B, g, C, _dt(y), _stream()), "vr_sr_im2col")
+    _lib.check(_lib.lib().vr_sr_im2col(_p(y), _p(col), B, g, C, num_tokens, _dt(y), _stream()), "vr_sr_im2col")
     return col
 
 
-def sr_col2im(dcol, dy, B, g, C):
-    _lib.check(_lib.lib().vr_sr_col2im(_p(dcol), _p(dy), B, g, C, _dt(dcol), _stream()), "vr_sr_col2im")
+def sr_col2im(dcol, dy, B, g, C, num_tokens=1):
+    _lib.check(_lib.lib().vr_sr_col2im(_p(dcol), _p(dy), B, g, C, num_tokens, _dt(dcol), _stream()), "vr_sr_col2im")
     return dy
 
 
-def sr_resid(x, B, g, cin, cout):
-    out = torch.empty((B, 1 + (g // 2) ** 2, cout), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().vr_sr_resid(_p(x), _p(out), B, g, cin, cout, _stream()), "vr_sr_resid")
+def sr_resid(x, B, g, cin, cout, num_tokens=1):
+    out = torch.empty((B, num_tokens + (g // 2) ** 2, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().vr_sr_resid(_p(x), _p(out), B, g, cin, cout, num_tokens, _stream()), "vr_sr_resid")
     return out
 
 
-def sr_resid_bwd(dout, B, g, cin, cout):
-    dx = torch.empty((B, 1 + g * g, cin), dtype=torch.float32, device=dout.device)
-    _lib.check(_lib.lib().vr_sr_resid_bwd(_p(dout), _p(dx), B, g, cin, cout, 0, _stream()), "vr_sr_resid_bwd")
+def sr_resid_bwd(dout, B, g, cin, cout, num_tokens=1):
+    dx = torch.empty((B, num_tokens + g * g, cin), dtype=torch.float32, device=dout.device)
+    _lib.check(_lib.lib().vr_sr_resid_bwd(_p(dout), _p(dx), B, g, cin, cout, 0, num_tokens, _stream()), "vr_sr_resid_bwd")
     return dx
 
 

@@ -138,10 +138,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                  num_warmup_epochs=_NUM_WARMUP_EPOCHS, single_arch=False, hybrid_arch=False, patch_output=False):
         super().__init__()
         assert patch_size == 14
-        if distill_token:
-            raise NotImplementedError('the HIP path implements the non-distillation (1 token) variants only '
-                                      '(reference factories *_patch14_224[_patch_output][_supernet]); the KD teacher '
-                                      'path is out of scope (SURVEY.md section 2 item 18)')
+        assert not (patch_output and distill_token), 'Currently support only either ShiftTokenMixup or Distillation.'
         if drop_rate != 0. or attn_drop_rate != 0.:
             raise NotImplementedError('drop_rate / attn_drop_rate must be 0 (every shipped recipe uses 0)')
         self.network_def = network_def
@@ -167,7 +164,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         grid = img_size // patch_size
 
         self.distill_token = distill_token
-        self.num_tokens = 1
+        self.num_tokens = 2 if distill_token else 1           # class token (+ distillation token: *_distill_* factories)
         self.tokens = nn.Parameter(torch.zeros(1, self.num_tokens, embed_dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + self.num_tokens, embed_dim))
         self.pos_drop = nn.Dropout(p=drop_rate)
@@ -225,7 +222,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         self.norm = norm_layer(embed_dim)
         assert embed_dim == network_def[_BLOCK_HEAD_INDEX][_HEAD_IN_CHANNEL]
         self.cls_head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
-        self.dst_head = None
+        self.dst_head = (nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()) if distill_token else None
         self.patch_head = nn.Linear(embed_dim, num_classes) if patch_output else None
 
         trunc_normal_(self.pos_embed, std=.02)
@@ -263,6 +260,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
     def reset_classifier(self, num_classes, global_pool=''):
         self.num_classes = num_classes
         self.cls_head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        if self.distill_token:                                # (the reference re-creates dst_head unconditionally, :391-394)
+            self.dst_head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
         self._arena = None
 
     def set_epoch(self, epoch):
@@ -463,7 +462,11 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         if patch_output_type not in (None, 'seq', 'avg'):
             raise ValueError()
         self._ensure_arena(x.device)
+        # second result of the forward: 0 none, 1 patch head per token ('seq'), 2 patch head on the mean token ('avg'),
+        # 3 distillation head (two-token variants, training and eval alike, reference :455-458)
         with_patch = int(bool(self.patch_output and self.training)) * (2 if patch_output_type == 'avg' else 1)
+        if self.num_tokens == 2:
+            with_patch = 3
         if plan is None:
             plan = self.sample_plan(x.shape[0])
         self._upload_plan(plan, x.device)
@@ -494,7 +497,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         return None
 
     def _layer_cfg(self, blk, grid):
-        base = {"dtype": self.compute_dtype, "eps": 1e-6}
+        base = {"dtype": self.compute_dtype, "eps": 1e-6, "tokens": self.num_tokens}
         if isinstance(blk, Block):
             base.update(heads=blk.attn.num_heads, head_dim=blk.attn.head_dim, scale=float(blk.attn.scale),
                         hidden=blk.mlp.fc1.out_features)
@@ -529,7 +532,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         tape = [] if save else None
         side_params = {}
         ecfg = {"dtype": self.compute_dtype, "patch": self.patch_size, "patches": self.patch_embed.num_patches,
-                "dim": self.embed_dim}
+                "dim": self.embed_dim, "tokens": self.num_tokens}
         ep = self._embed_params()
         ekeep = plan.k(plan.layers[0]["embed"])
         if self.embed_type == _TYPE_IS_EMBED:
@@ -560,9 +563,11 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"])
         grid = self.img_size // self.patch_size
         hp = {"nw": self.norm.weight.detach(), "nb": self.norm.bias.detach(), "cls": self._lin(self.cls_head)}
-        if with_patch:
+        if with_patch == 3:
+            hp["dst"] = self._lin(self.dst_head)
+        elif with_patch:
             hp["patch"] = self._lin(self.patch_head)
-        hcfg = {"dtype": self.compute_dtype, "eps": 1e-6, "classes": self.num_classes}
+        hcfg = {"dtype": self.compute_dtype, "eps": 1e-6, "classes": self.num_classes, "tokens": self.num_tokens}
         hk = plan.k(plan.head)
         seq = []
         for blk, L in zip(self.blocks, plan.layers[1:]):
@@ -656,7 +661,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         if cut is None:
             cut = len(blocks) // 2
         tail = [p for m in blocks[cut:] for p in m.parameters()] + list(self.norm.parameters()) + \
-            list(self.cls_head.parameters()) + (list(self.patch_head.parameters()) if self.patch_head is not None else [])
+            list(self.cls_head.parameters()) + (list(self.patch_head.parameters()) if self.patch_head is not None else []) + \
+            (list(self.dst_head.parameters()) if self.dst_head is not None else [])
         tail_ids = {id(p) for p in tail}
         if not tail:
             return None
@@ -697,6 +703,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                          "cls.b": gv(self.cls_head.bias)}
                 if self.patch_head is not None:
                     grads["patch.w"], grads["patch.b"] = gv(self.patch_head.weight), gv(self.patch_head.bias)
+                if self.dst_head is not None:
+                    grads["dst.w"], grads["dst.b"] = gv(self.dst_head.weight), gv(self.dst_head.bias)
                 nc = consumer_cast(ti)
                 g = Fn.head_bwd(dcls, dpat, sv, hp, grads, hcfg, hk, next_cast=nc)
                 g, gt = g if nc is not None else (g, None)
@@ -715,10 +723,11 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 _, blk, p, cfg, (ek, nk), sv = entry
                 co, ci = blk.patch_reduce.weight.shape[0], blk.patch_reduce.weight.shape[1]
                 wtmp = torch.zeros((co, 9 * ci), dtype=torch.float32, device=dev)
-                ptmp = torch.zeros((1 + blk.num_patches, co), dtype=torch.float32, device=dev)
-                def finish(blk=blk, wtmp=wtmp, ptmp=ptmp, co=co, ci=ci):     # runs on the stream of the weight gradients
+                nt = self.num_tokens
+                ptmp = torch.zeros((nt + blk.num_patches, co), dtype=torch.float32, device=dev)
+                def finish(blk=blk, wtmp=wtmp, ptmp=ptmp, co=co, ci=ci, nt=nt):     # runs on the stream of the weight gradients
                     gv(blk.patch_reduce.weight).copy_(wtmp.view(co, 3, 3, ci).permute(0, 3, 1, 2))
-                    gv(blk.pos_embed).copy_(ptmp[1:].unsqueeze(0))
+                    gv(blk.pos_embed).copy_(ptmp[nt:].unsqueeze(0))
                 grads = {"nw": gv(blk.norm.weight), "nb": gv(blk.norm.bias), "token.w": gv(blk.token_transform.weight),
                          "token.b": gv(blk.token_transform.bias), "reduce.b": gv(blk.patch_reduce.bias),
                          "reduce.w": wtmp, "pos_sum": ptmp, "finish": finish}
@@ -741,7 +750,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 else:
                     from .. import stem
                     stem.embed_conv_bwd(self, g, sv, ep, ecfg, ekeep, gv, gt=gt)
-                gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:1, :])
+                gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:self.num_tokens, :])
         Fn.join_side()                     # weight-gradient GEMMs trail on the side stream (functional.on_side)
         st["i"], st["g"], st["gt"] = stop, g, gt
 

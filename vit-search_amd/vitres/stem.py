@@ -69,7 +69,8 @@ def embed_conv_fwd(model, x, p, cfg, keep, save):
     Hm, Wm = H // 2, W // 2
     R = B * Hm * Wm
     g = Hm // (model.patch_size // 2)
-    N = P + 1
+    T = cfg.get("tokens", 1)
+    N = P + T
     tr = model.training
 
     def conv(col, w, ld):
@@ -102,8 +103,8 @@ def embed_conv_fwd(model, x, p, cfg, keep, save):
     ldk = ps * ps * m
     out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
     K.gemm(colp, p["proj"].w_c, out, M=B * P, N=C, K=ldk, lda=ldk, ldb=ldk, ldc=C, bias=p["proj"].b,
-           pos=p["pos"][0, 1:], keep_n=keep, rows_in=P, c_map=(P, N, 1))
-    K.embed_cls(p["tokens"], p["pos"], out, keep)
+           pos=p["pos"][0, T:], keep_n=keep, rows_in=P, c_map=(P, N, T))
+    K.embed_cls(p["tokens"], p["pos"], out, keep, T)
     saved = (col1, z1, bn1, col2, z2, bn2, col3, z3, bn3, colp, (B, Hm, Wm, m, g, ps, tr, direct)) if save else None
     return out, saved
 
@@ -113,7 +114,8 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
     col1, z1, bn1, col2, z2, bn2, col3, z3, bn3, colp, (B, Hm, Wm, m, g, ps, tr, direct) = saved
     dev = gx.device
     _, N, C = gx.shape
-    P = N - 1
+    T = cfg.get("tokens", 1)
+    P = N - T
     R = B * Hm * Wm
     ldk = ps * ps * m
     if gt is None:
@@ -123,14 +125,14 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
     wtmp = torch.zeros((C, ldk), dtype=torch.float32, device=dev)
 
     def wgrad_proj():
-        Fn.linear_wgrad(gt, colp, wtmp, B * P, C, ldk, C, ldk, a_map=(P, N, 1), db=gv(pe.conv_proj.bias),
+        Fn.linear_wgrad(gt, colp, wtmp, B * P, C, ldk, C, ldk, a_map=(P, N, T), db=gv(pe.conv_proj.bias),
                         sched=1 if ov else 0)
         gv(pe.conv_proj.weight).copy_(wtmp.view(C, ps, ps, m).permute(0, 3, 1, 2))
         K.batchsum(gx, gv(model.pos_embed))
     # weight gradients run beside the data-gradient chain (functional.on_side); joined at the end of this function
     Fn.on_side(wgrad_proj, gt, wtmp) if ov else wgrad_proj()
     dcolp = torch.empty((B * P, ldk), dtype=dt, device=dev)
-    K.gemm(gt, p["proj"].w_c, dcolp, M=B * P, N=ldk, K=C, lda=C, ldb=ldk, ldc=ldk, b_trans=True, a_map=(P, N, 1))
+    K.gemm(gt, p["proj"].w_c, dcolp, M=B * P, N=ldk, K=C, lda=C, ldb=ldk, ldc=ldk, b_trans=True, a_map=(P, N, T))
     da3 = K.patch_fold(dcolp, B, g, g, ps, m)                      # d(relu(bn3) + a1)
 
     def conv_bwd(da, z, bn, col, w, conv_mod, ld, need_dx, wt=None):
