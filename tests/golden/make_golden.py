@@ -639,6 +639,63 @@ def f15_distillation_engine():
 
 
 # ------------------------------------------------------------------------------------------------
+# F16: the single-stage patch-16 sibling (nets/vision_transformer_supernet.py:45-283): schema, init from a seed, (cls, dst)
+#      logits, loss, gradients, masks, eval outputs
+# ------------------------------------------------------------------------------------------------
+def f16_vit16():
+    import importlib
+    vt = importlib.import_module("nets.vision_transformer_supernet")
+    B = 8
+    for mode in ("plain", "multi"):
+        sup = mode != "plain"
+        kw = dict(num_channels_to_keep=recipe.vit16_keep_config(), example_per_arch=2, num_warmup_epochs=30) if sup else {}
+        torch.manual_seed(77)
+        m = vt.FlexibleDistillVisionTransformer(img_size=recipe.VIT16_IMG, patch_size=16, num_classes=recipe.MICRO_CLASSES,
+                                                distill_token=True, network_def=recipe.VIT16_DEF, supernet=sup, **kw)
+        out = {"init_crc": recipe.checksum(m.state_dict()), "no_weight_decay": np.array(sorted(m.no_weight_decay()))}
+        sd, shapes = load_recipe(m, seed=160)
+        out.update(state_crc=recipe.checksum(sd), keys=np.array([k for k, _ in shapes]), shapes=np.array([str(s_) for _, s_ in shapes]))
+        x, t, pt, labels = recipe.inputs(7, B, recipe.VIT16_IMG, recipe.MICRO_CLASSES, 1)
+        t2 = pt[:, 0, :].contiguous()
+        m.train()
+        if sup:
+            m.set_epoch(31)
+            m.load_state_dict(sd)
+        m.zero_grad()
+        torch.manual_seed(555 + 31)
+        with KeepRecorder() as rec:
+            cls, dst = m(x.clone())
+        loss = soft_ce(cls, t) + soft_ce(dst, t2)
+        loss.backward()
+        out["cls"], out["dst"], out["loss"] = cls.detach().numpy(), dst.detach().numpy(), loss.item()
+        if rec.log:
+            out["keeps"] = torch.stack(rec.log).numpy()
+        for n, p in m.named_parameters():
+            if n.startswith(("tokens", "pos_embed", "patch_embed", "blocks.0.", "blocks.3.mlp.fc2", "norm.", "cls_head", "dst_head")):
+                out["grad." + n] = p.grad.detach().numpy().copy()
+        m.load_state_dict(sd)
+        m.eval()
+        with torch.no_grad():
+            ec, ed = m(x.clone())
+        out["eval.cls"], out["eval.dst"] = ec.numpy(), ed.numpy()
+        save("f16_vit16_%s" % mode, **out)
+    # choice tables of the patch-16 spaces (supernet_config/tiny.py, tiny_deep.py, small_deep.py)
+    tables = {}
+    for name in ("tiny", "tiny_deep", "small_deep"):
+        tbl = importlib.import_module("supernet_config." + name).num_channels_to_keep
+        flat = []
+        for ent in tbl:
+            if ent is None:
+                flat.append("None")
+            elif isinstance(ent, dict):
+                flat.append(str({k: (None if v is None else [int(a) for a in v]) for k, v in ent.items()}))
+            else:
+                flat.append(str([int(a) for a in ent]))
+        tables[name] = np.array(flat)
+    save("f16_patch16_spaces", **tables)
+
+
+# ------------------------------------------------------------------------------------------------
 # F13: evolutionary-search population bookkeeping + candidate generation (search_utils/evolver.py, gen_utils.py) under a seed:
 #      the reference's own classes, numpy global RNG, sr_tiny and sr_small spaces, toy scores from recipe.toy_candidate_score
 # ------------------------------------------------------------------------------------------------
@@ -686,8 +743,8 @@ def f13_evolver():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15", "f16"]
     table = dict(f1=f1_micro, f2=f2_masked_ln, f3=f3_channel_drop, f4=f4_fullsize, f5=f5_subnet,
-                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init, f13=f13_evolver, f14=f14_distill_token, f15=f15_distillation_engine)
+                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init, f13=f13_evolver, f14=f14_distill_token, f15=f15_distillation_engine, f16=f16_vit16)
     for w in which:
         table[w]()

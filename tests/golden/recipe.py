@@ -138,3 +138,15 @@ def toy_teacher(classes):
         def forward(self, x):
             return self.lin(x.float().mean(dim=(2, 3)))
     return Teacher()
+
+
+# single-stage patch-16 sibling (nets/vision_transformer_supernet.py), micro size: 64 px -> 4 x 4 patches
+VIT16_IMG = 64
+VIT16_DEF = ((0, 48),) + ((1, (48, 2, 32), (48, 96), 1),) * 4 + ((2, 48, MICRO_CLASSES),)
+
+
+def vit16_keep_config():
+    import numpy as np
+    blk = {'attn': np.array([64, 32]), 'mlp': np.array([96, 64, 48]), 'layer': None}
+    skip = {'attn': np.array([64, 32]), 'mlp': np.array([96, 64, 48]), 'layer': np.array([48, 0])}
+    return [np.array([48, 40, 32]), blk, skip, blk, skip, None]

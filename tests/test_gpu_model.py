@@ -623,3 +623,44 @@ def test_distillation_epoch_matches_reference_engine(mode, hard):
     for k in g.files:
         if k.startswith(tag + "after."):
             assert rel(after[k[len(tag) + 6:]], g[k]) < 1e-4, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["plain", "multi"])
+def test_single_stage_patch16_sibling_vs_reference_golden(mode, dtype):
+    """flexible_vit_patch16_224[_supernet] (nets/vision_transformer_supernet.py) through the HIP kernels against the imported
+    reference (F16): masks bit-exact, (cls, dst) logits / loss / gradients (fp32: 1e-4 / 5e-4; bf16: 3e-2 logits), eval outputs."""
+    g = np.load(os.path.join(G, "f16_vit16_%s.npz" % mode))
+    sup = mode != "plain"
+    kw = dict(num_channels_to_keep=recipe.vit16_keep_config(), example_per_arch=2, num_warmup_epochs=30) if sup else {}
+    prod = vitres.create_model("flexible_vit_patch16_224" + ("_supernet" if sup else ""), img_size=recipe.VIT16_IMG,
+                               num_classes=recipe.MICRO_CLASSES, network_def=recipe.VIT16_DEF, **kw)
+    sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in prod.state_dict().items()], 160)
+    assert recipe.checksum(sd) == int(g["state_crc"])
+    prod.load_state_dict(sd)
+    prod = prod.to(DEV).set_compute_dtype(dtype)
+    f32 = dtype == torch.float32
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.VIT16_IMG, recipe.MICRO_CLASSES, 1)
+    t2 = pt[:, 0, :].contiguous()
+    prod.train()
+    if sup:
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+    torch.manual_seed(555 + 31)
+    cls, dst = prod(x.to(DEV))
+    if sup:
+        assert np.array_equal(torch.stack(prod.last_keeps).cpu().numpy(), g["keeps"])
+    tol_l = 1e-4 if f32 else 3e-2
+    assert rel(cls, g["cls"]) < tol_l and rel(dst, g["dst"]) < tol_l
+    loss = O.soft_target_ce(cls, t.to(DEV)) + O.soft_target_ce(dst, t2.to(DEV))
+    assert abs(loss.item() - float(g["loss"])) < (1e-4 if f32 else 2e-2) * abs(float(g["loss"]))
+    loss.backward()
+    params = dict(prod.named_parameters())
+    worst = max(rel(params[k[5:]].grad, g[k]) for k in g.files if k.startswith("grad."))
+    assert worst < (5e-4 if f32 else 8e-2), worst
+    prod.eval()
+    prod.load_state_dict(sd)
+    with torch.no_grad():
+        ec, ed = prod(x.to(DEV))
+    assert rel(ec, g["eval.cls"]) < tol_l and rel(ed, g["eval.dst"]) < tol_l

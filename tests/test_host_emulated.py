@@ -314,3 +314,56 @@ def test_emulated_distillation_epoch_matches_reference_engine(monkeypatch, mode,
     for k in g.files:
         if k.startswith(tag + "after."):
             assert rel(after[k[len(tag) + 6:]], torch.from_numpy(g[k])) < 2e-5, k
+
+
+def build_vit16(mode):
+    sup = mode != "plain"
+    kw = dict(num_channels_to_keep=recipe.vit16_keep_config(), example_per_arch=2, num_warmup_epochs=30) if sup else {}
+    return vitres.create_model("flexible_vit_patch16_224" + ("_supernet" if sup else ""), img_size=recipe.VIT16_IMG,
+                               num_classes=recipe.MICRO_CLASSES, network_def=recipe.VIT16_DEF, **kw)
+
+
+@pytest.mark.parametrize("mode", ["plain", "multi"])
+def test_emulated_single_stage_patch16_sibling_matches_reference(monkeypatch, mode):
+    """flexible_vit_patch16_224[_supernet] (nets/vision_transformer_supernet.py): same-seed initialisation, schema,
+    no_weight_decay, masks, (cls, dst) logits, loss, gradients and eval outputs against the imported reference (F16)."""
+    emu_kernels.install(monkeypatch)
+    g = np.load(os.path.join(G, "f16_vit16_%s.npz" % mode))
+    torch.manual_seed(77)
+    prod = build_vit16(mode)
+    assert recipe.checksum(prod.state_dict()) == int(g["init_crc"])          # the constructor draws like the reference's
+    assert sorted(prod.no_weight_decay()) == list(g["no_weight_decay"])
+    shapes = [(k, tuple(v.shape)) for k, v in prod.state_dict().items()]
+    assert [k for k, _ in shapes] == list(g["keys"]) and [str(s) for _, s in shapes] == list(g["shapes"])
+    sd = recipe.fill_state_dict(shapes, 160)
+    assert recipe.checksum(sd) == int(g["state_crc"])
+    prod.load_state_dict(sd)
+    prod.set_compute_dtype(torch.float32)
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.VIT16_IMG, recipe.MICRO_CLASSES, 1)
+    t2 = pt[:, 0, :].contiguous()
+    prod.train()
+    if mode != "plain":
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+    torch.manual_seed(555 + 31)
+    cls, dst = prod(x)
+    if mode != "plain":
+        assert np.array_equal(torch.stack(prod.last_keeps).numpy(), g["keeps"])
+    assert rel(cls.detach(), torch.from_numpy(g["cls"])) < 5e-5 and rel(dst.detach(), torch.from_numpy(g["dst"])) < 5e-5
+    loss = O.soft_target_ce(cls, t) + O.soft_target_ce(dst, t2)
+    assert abs(loss.item() - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    loss.backward()
+    params = dict(prod.named_parameters())
+    n = 0
+    for k in g.files:
+        if k.startswith("grad."):
+            assert rel(params[k[5:]].grad, torch.from_numpy(g[k])) < 2e-4, k
+            n += 1
+    assert n > 20
+    prod.eval()
+    prod.load_state_dict(sd)
+    with torch.no_grad():
+        ec, ed = prod(x)
+    assert rel(ec, torch.from_numpy(g["eval.cls"])) < 5e-5 and rel(ed, torch.from_numpy(g["eval.dst"])) < 5e-5
+    with pytest.raises(AssertionError):                                        # SR entries are not part of this grammar
+        vitres.create_model("flexible_vit_patch16_224", img_size=64, num_classes=recipe.MICRO_CLASSES, network_def=recipe.MICRO_DEFS[0])

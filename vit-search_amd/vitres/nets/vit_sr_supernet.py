@@ -132,12 +132,15 @@ class _ViTResFn(torch.autograd.Function):
 
 
 class FlexibleDistillVisionTransformerSR(nn.Module):
+    _PATCH_SIZES = (14,)
+    _ALWAYS_DST_HEAD = False          # the patch-16 sibling registers dst_head even without a distillation token
+
     def __init__(self, img_size=224, patch_size=14, in_chans=3, num_classes=1000, drop_rate=0., attn_drop_rate=0.,
                  drop_path_rate=0., norm_layer=MaskedLayerNorm, distill_token=True, network_def=None,
                  supernet=False, num_channels_to_keep=None, example_per_arch=None,
                  num_warmup_epochs=_NUM_WARMUP_EPOCHS, single_arch=False, hybrid_arch=False, patch_output=False):
         super().__init__()
-        assert patch_size == 14
+        assert patch_size in self._PATCH_SIZES
         assert not (patch_output and distill_token), 'Currently support only either ShiftTokenMixup or Distillation.'
         if drop_rate != 0. or attn_drop_rate != 0.:
             raise NotImplementedError('drop_rate / attn_drop_rate must be 0 (every shipped recipe uses 0)')
@@ -222,7 +225,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         self.norm = norm_layer(embed_dim)
         assert embed_dim == network_def[_BLOCK_HEAD_INDEX][_HEAD_IN_CHANNEL]
         self.cls_head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
-        self.dst_head = (nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()) if distill_token else None
+        self.dst_head = (nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()) \
+            if (distill_token or self._ALWAYS_DST_HEAD) else None
         self.patch_head = nn.Linear(embed_dim, num_classes) if patch_output else None
 
         trunc_normal_(self.pos_embed, std=.02)

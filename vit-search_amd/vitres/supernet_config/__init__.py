@@ -65,3 +65,28 @@ sr_small_mh = _space('sr_small_mh', (4, 320), [
     (640, 16, 48, 1920, 7, _S2, [768, 672, 576, 480], [1920, 1760, 1600, 1440, 1280, 1120, 960], [640, 640, 0, 0], _odd),
     (1280, 16, 64, 3840, 7, _S3, [1024, 896, 768, 640], [3840, 3520, 3200, 2880, 2560, 2240, 1920],
      [1280, 1280, 0, 0], _odd)])
+
+
+# ---- single-stage patch-16 spaces of the sibling ViT supernet (reference supernet_config/tiny.py, tiny_deep.py, small_deep.py) ----
+# The reference ships only the choice tables; `network_def` here is the largest member of each table (heads of 64 channels).
+def _flat_space(name, dim, embed, attn, mlp, pattern, layer_a, layer_b):
+    """pattern: per block 'b' (no layer choice), 'a' / 'c' (removable with layer choices layer_a / layer_b)."""
+    blk = {'attn': np.array(attn), 'mlp': np.array(mlp), 'layer': None}
+    tab = {'b': blk}
+    for key, layer in (('a', layer_a), ('c', layer_b)):
+        t = copy.deepcopy(blk)
+        t['layer'] = np.array(layer)
+        tab[key] = t
+    keep = [np.array(embed)] + [tab[ch] for ch in pattern] + [None]
+    m = types.ModuleType(__name__ + '.' + name)
+    m.num_channels_to_keep = keep
+    m.network_def = ((0, dim),) + ((1, (dim, attn[0] // 64, 64), (dim, mlp[0]), 1),) * len(pattern) + ((2, dim, 1000),)
+    return m
+
+
+tiny = _flat_space('tiny', 240, [240, 224, 208, 192], [512, 384, 256, 128], [1024, 768, 512, 256],
+                   'b' + 'bbac' * 3 + 'b', [240, 240, 0], [240, 0])
+tiny_deep = _flat_space('tiny_deep', 240, [240, 224, 208, 192], [384, 320, 256, 192], [960, 800, 640, 480],
+                        'bb' + 'baba' * 3 + 'bb', [240, 240, 240, 0], [240, 240, 0, 0])
+small_deep = _flat_space('small_deep', 384, [384, 352, 320, 288], [512, 448, 384, 320], [1536, 1280, 1024, 768],
+                         'bb' + 'baba' * 3 + 'bb', [384, 384, 384, 0], [384, 384, 0, 0])
