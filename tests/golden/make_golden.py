@@ -696,6 +696,24 @@ def f16_vit16():
 
 
 # ------------------------------------------------------------------------------------------------
+# F17: repeated-augmentation sampler (samplers.py:12-64)
+# ------------------------------------------------------------------------------------------------
+def f17_ra_sampler():
+    import importlib
+    smp = importlib.import_module("samplers")
+    out = {}
+    for n, world in ((1000, 4), (777, 3), (5000, 8), (300, 2)):
+        ds = list(range(n))
+        for rank in (0, world - 1):
+            for shuffle in (True, False):
+                sp = smp.RASampler(ds, num_replicas=world, rank=rank, shuffle=shuffle)
+                sp.set_epoch(5)
+                out["n%d_w%d_r%d_s%d" % (n, world, rank, int(shuffle))] = np.array(list(iter(sp)), dtype=np.int64)
+                out["n%d_w%d_r%d_s%d.len" % (n, world, rank, int(shuffle))] = len(sp)
+    save("f17_ra_sampler", **out)
+
+
+# ------------------------------------------------------------------------------------------------
 # F13: evolutionary-search population bookkeeping + candidate generation (search_utils/evolver.py, gen_utils.py) under a seed:
 #      the reference's own classes, numpy global RNG, sr_tiny and sr_small spaces, toy scores from recipe.toy_candidate_score
 # ------------------------------------------------------------------------------------------------
@@ -743,8 +761,8 @@ def f13_evolver():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15", "f16"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15", "f16", "f17"]
     table = dict(f1=f1_micro, f2=f2_masked_ln, f3=f3_channel_drop, f4=f4_fullsize, f5=f5_subnet,
-                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init, f13=f13_evolver, f14=f14_distill_token, f15=f15_distillation_engine, f16=f16_vit16)
+                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init, f13=f13_evolver, f14=f14_distill_token, f15=f15_distillation_engine, f16=f16_vit16, f17=f17_ra_sampler)
     for w in which:
         table[w]()
