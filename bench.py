@@ -118,8 +118,11 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"], help="flat: vitres.optim.FlatAdamW (one "
                     "fused HIP pass over the arena); torch: torch.optim.AdamW(fused=True)")
-    ap.add_argument("--split-sync", type=int, default=-1, help="two-graph backward with overlapped gradient exchange "
-                    "(-1: when --gpus > 1)")
+    ap.add_argument("--split-sync", type=int, default=-1, help="backward captured as this many hipGraphs (cut in front of the "
+                    "spatial reductions), each followed by the all-reduce of the gradient range it completed, overlapped with the "
+                    "next one; 0/1: one graph, one all-reduce; -1: 2 when --gpus > 1 (3 exposes less of the exchange -- ~24 MB instead of ~116 MB "
+                    "of the 279 MB -- but could not be timed over RCCL from the 1-GPU development box; 2 ranks over gloo on one GPU run "
+                    "it 10x slower than 2, a host-side interaction of gloo's copy threads with graph launches)")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -172,7 +175,7 @@ def main():
                                  grad_sync=sync if exchange else None, average_grads=average)
 
     graphed = None
-    split = (world > 1) if args.split_sync < 0 else bool(args.split_sync)
+    split = (2 if world > 1 else 0) if args.split_sync < 0 else (args.split_sync if args.split_sync >= 2 else 0)
     if not args.no_graph:
         # N > 1: the backward is captured as two graphs so that the all-reduce of the last stage's gradients (the tail of
         # the flat arena, most of the parameters) runs on RCCL's stream while the rest of the backward is still computing
@@ -282,7 +285,7 @@ def main():
         "config": {"workload": args.workload, "global_batch": B * world, "per_gpu_batch": B,
                    "example_per_arch": w["epa"], "epoch": 31, "drop_path": w["drop_path"], "parallelism": "dp%d" % world,
                    "optimizer": "AdamW (vitres.optim.FlatAdamW: vr_adamw_flat)" if args.optimizer == "flat" else "AdamW(torch fused)", "hipgraph": graphed is not None, "host_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
-                   "grad_exchange": ("1 all-reduce of the flat fp32 arena, tail overlapped with the second backward graph"
+                   "grad_exchange": ("all-reduce of the flat fp32 gradient arena in %d ranges, each overlapped with the next backward graph" % split
                                      if (graphed is not None and graphed.graph_b is not None) else
                                      "1 all-reduce of the flat fp32 arena" if world > 1 else "none (1 rank)"), "final_loss": round(lossv[-1], 4)},
         "roofline": roof, "cpu_baseline": cpu,

@@ -72,12 +72,28 @@ def _worker(rank, world, port, out_dir):
     sync.finish(works)
     g_split = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
     model.zero_grad(set_to_none=True)
+    # three parts: one exchange per completed arena range
+    torch.random.set_rng_state(rng)
+    cuts = model.split_plan(parts=3)
+    cls, pat = model(x, patch_output_type="seq")
+    model._bwd_split = [c for c, _ in cuts]
+    (crit(cls, t) + crit(pat, pt)).backward()
+    model._bwd_split = None
+    works, end = [], model._arena["gcur"].numel()
+    for _, st in cuts:
+        works.append(sync.all_reduce_range(st, end))
+        end = st
+        model.resume_backward()
+    works.append(sync.all_reduce_range(0, end))
+    sync.finish(works)
+    g_split3 = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    model.zero_grad(set_to_none=True)
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
     torch.random.set_rng_state(rng)
     engine.train_step(model, crit, opt, x, t, pt, "seq", epoch=31, train_iter=0, arch_sample="multi", grad_sync=sync)
     g_sync = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
     p1 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
-    torch.save({"p0": p0, "p1": p1, "g_local": g_local, "g_sync": g_sync, "keeps": keeps, "g_split": g_split},
+    torch.save({"p0": p0, "p1": p1, "g_local": g_local, "g_sync": g_sync, "keeps": keeps, "g_split": g_split, "g_split3": g_split3},
                os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -98,6 +114,7 @@ def test_two_rank_gradient_exchange(tmp_path):
     assert err < 1e-5, err
     assert torch.equal(r0["g_split"], r1["g_split"])
     assert float((r0["g_split"] - r0["g_sync"]).abs().max() / r0["g_sync"].abs().max()) < 1e-6
+    assert torch.equal(r0["g_split3"], r1["g_split3"]) and torch.equal(r0["g_split3"], r0["g_split"])
 
 
 def _search_worker(rank, world, port, out_dir):

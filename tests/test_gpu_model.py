@@ -267,6 +267,20 @@ def test_split_hipgraphs_match_eager():
         assert abs(loss_g - loss_e) < 1e-5 * abs(loss_e)
         for n, p in prod.named_parameters():
             assert rel(p.grad, grads_e[n]) < 1e-4, n
+    # three graphs (a cut in front of every spatial reduction): three arena ranges, same gradients
+    for p in prod.parameters():
+        p.grad = None
+    g3 = engine.GraphedTrainStep(prod, crit, x, t, pt, "seq", split_for_sync=3)
+    assert len(g3.more_graphs) == 2 and len(g3.ranges) == 3
+    assert g3.ranges[0][1] == prod._arena["gcur"].numel() and g3.ranges[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(g3.ranges, g3.ranges[1:]))       # contiguous, from the arena's end to its start
+    for it in range(2):
+        torch.manual_seed(700 + it)
+        loss_g = g3.step_with_sync(sync, x, t, pt, epoch=31, train_iter=it, arch_sample=None).item()
+        loss_e, grads_e = eager[it]
+        assert abs(loss_g - loss_e) < 1e-5 * abs(loss_e)
+        for n, p in prod.named_parameters():
+            assert rel(p.grad, grads_e[n]) < 1e-4, n
 
 
 def test_evo_candidates_on_resident_supernet_match_reference_sliced_subnets():

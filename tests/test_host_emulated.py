@@ -132,6 +132,22 @@ def test_emulated_split_backward_equals_monolithic(monkeypatch):
     assert torch.equal(full, mono)
     assert torch.equal(part1[start:], mono[start:])          # the tail is final after part 1 ...
     assert not torch.equal(part1[:start], mono[:start])      # ... the rest is not
+    # three parts (a cut in front of every spatial reduction): range k of the arena is final after part k
+    cuts = prod.split_plan(parts=3)
+    assert len(cuts) == 2 and cuts[0] == (cut, start) and cuts[1][0] < cut and 0 < cuts[1][1] < start
+    torch.manual_seed(5)
+    prod.zero_grad(set_to_none=True)
+    cls, pat = prod(x, patch_output_type="seq")
+    prod._bwd_split = [c for c, _ in cuts]
+    (O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)).backward()
+    prod._bwd_split = None
+    p1 = prod._arena["gcur"].clone()
+    assert prod.resume_backward() is True
+    p2 = prod._arena["gcur"].clone()
+    assert prod.resume_backward() is False and prod._bwd_state is None
+    s2 = cuts[1][1]
+    assert torch.equal(prod._arena["gcur"], mono)
+    assert torch.equal(p1[start:], mono[start:]) and torch.equal(p2[s2:], mono[s2:]) and not torch.equal(p2[:s2], mono[:s2])
 
 
 @pytest.mark.parametrize("mode", ["plain", "multi"])

@@ -185,7 +185,7 @@ class GraphedTrainStep:
         step_with_sync() can all-reduce the finished tail of the gradient arena (most of the parameters) while the rest
         of the backward -- most of the time -- is still running."""
         self.model, self.criterion, self.pot = model, criterion, patch_output_type
-        self.graph_b, self.split = None, None
+        self.graph_b, self.split, self.more_graphs, self.ranges = None, None, [], []
         self.x, self.t = samples.clone(), targets.clone()
         self.pt = patch_targets.clone() if patch_targets is not None else None
         B = samples.shape[0]
@@ -202,21 +202,36 @@ class GraphedTrainStep:
         if plan.rows:
             self.keep_static = torch.stack(plan.rows).to(torch.int32).to(samples.device)
         model.zero_grad(set_to_none=True)
-        if split_for_sync:
-            self.split = model.split_plan()
+        # split_for_sync = number of backward parts (True = 2): part k's graph is followed by the all-reduce of the arena range
+        # it completed, overlapping part k+1 (a cut in front of every spatial reduction, counted from the end)
+        parts = 2 if split_for_sync is True else int(split_for_sync or 0)
+        cuts = None
+        if parts >= 2:
+            cuts = model.split_plan(parts=max(parts, 3))
+            cuts = cuts[:parts - 1] if cuts else None
+        if cuts:
+            self.split = cuts[0]
         self.graph = torch.cuda.CUDAGraph()
-        model._bwd_split = self.split[0] if self.split is not None else None
+        model._bwd_split = [c for c, _ in cuts] if cuts else None
         try:
             with torch.cuda.graph(self.graph):
                 plan.keep_dev = self.keep_static
                 self.loss = self._loss(model(self.x, patch_output_type=self.pot, plan=plan))
                 self.loss.backward()
-            if getattr(model, "_bwd_state", None) is not None:
-                self.graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_b, pool=self.graph.pool()):
+            while getattr(model, "_bwd_state", None) is not None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.graph.pool()):
                     model.resume_backward()
+                self.more_graphs.append(g)
         finally:
             model._bwd_split = None
+        if self.more_graphs:
+            self.graph_b = self.more_graphs[0]
+            end = model._arena["gcur"].numel()
+            for _, start in cuts:                                  # arena range completed by part 1, 2, ... (the rest: last part)
+                self.ranges.append((start, end))
+                end = start
+            self.ranges.append((0, end))
         self.loss = self.loss.detach()
         torch.random.set_rng_state(rng)
 
@@ -245,10 +260,10 @@ class GraphedTrainStep:
             if self.pt is not None:
                 self.pt.copy_(patch_targets, non_blocking=True)
         self.graph.replay()
-        if self.graph_b is not None:
-            if self._sync is not None:                            # tail of the arena is final: exchange it now
-                self._works.append(self._sync.all_reduce_range(self.split[1], self.model._arena["gcur"].numel()))
-            self.graph_b.replay()
+        for k, g in enumerate(self.more_graphs):
+            if self._sync is not None:                            # the arena range of the part just replayed is final: exchange it now
+                self._works.append(self._sync.all_reduce_range(*self.ranges[k]))
+            g.replay()
         return self.loss
 
     _sync, _works = None, ()
@@ -262,8 +277,8 @@ class GraphedTrainStep:
             loss = self(samples, targets, patch_targets, **kw)
         finally:
             self._sync = None
-        if self.graph_b is not None:
-            self._works.append(grad_sync.all_reduce_range(0, self.split[1]))
+        if self.more_graphs:
+            self._works.append(grad_sync.all_reduce_range(*self.ranges[-1]))
             grad_sync.finish(self._works, average=average)
         else:
             grad_sync.all_reduce_grads(average=average)

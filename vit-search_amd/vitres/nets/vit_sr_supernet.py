@@ -634,47 +634,54 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         st = {"rtape": list(reversed(tape)), "plan": plan, "dcls": dcls, "dpat": dpat, "i": 0, "g": None, "gt": None}
         # _bwd_split = j: stop after the head and blocks[j:]; the rest runs in resume_backward() (a second hipGraph, so that the
         # all-reduce of the finished tail of the gradient arena overlaps it -- engine.GraphedTrainStep)
-        cut = getattr(self, "_bwd_split", None)
-        n1 = len(st["rtape"])
-        if cut is not None:                # head + the entries of blocks[cut:] form a prefix of the reversed tape
+        cuts = getattr(self, "_bwd_split", None)
+        cuts = [] if cuts is None else ([cuts] if isinstance(cuts, int) else list(cuts))
+        stops = []
+        for cut in cuts:                   # head + the entries of blocks[cut:] form a prefix of the reversed tape
             late = {id(b) for b in list(self.blocks)[cut:]}
-            n1 = sum(1 for e in st["rtape"] if e[0] == "head" or (e[0] in ("block", "sr") and id(e[1]) in late))
-        self._bwd_loop(st, n1)
+            stops.append(sum(1 for e in st["rtape"] if e[0] == "head" or (e[0] in ("block", "sr") and id(e[1]) in late)))
+        assert stops == sorted(stops), "_bwd_split: block indices must descend (the backward walks the blocks from the end)"
+        st["stops"] = stops + [len(st["rtape"])]
+        self._bwd_loop(st, st["stops"].pop(0))
         self._bwd_state = st if st["i"] < len(st["rtape"]) else None
         return [self._gview(p) for p in params]
 
     def resume_backward(self):
-        """Second part of a backward that was split by _bwd_split (gradients land in the same arena views)."""
+        """Next part of a backward that was split by _bwd_split (gradients land in the same arena views); returns True while
+        further parts are pending."""
         st = self._bwd_state
         if st is None:
             raise RuntimeError("no split backward is pending")
-        self._bwd_loop(st, len(st["rtape"]))
-        self._bwd_state = None
+        self._bwd_loop(st, st["stops"].pop(0))
+        if st["i"] >= len(st["rtape"]):
+            self._bwd_state = None
+        return self._bwd_state is not None
 
-    def split_plan(self):
-        """Where to cut the backward for gradient-exchange overlap: (first block index of part 1, first element of the
-        gradient arena that part 1 completes) -- head + the last stage (+ the spatial reduction in front of it), whose
-        parameters form the tail of the arena.  None if the layout does not allow it."""
+    def split_plan(self, parts=2):
+        """Where to cut the backward for gradient-exchange overlap.  parts=2: (first block index of part 1, first element of
+        the gradient arena that part 1 completes) -- head + the last stage (+ the spatial reduction in front of it), whose
+        parameters form the tail of the arena.  parts=3 (or more): a list of such pairs, one cut in front of every spatial
+        reduction counted from the end; pair k's arena range [start_k, start_{k-1}) is final after part k.  None if the layout
+        does not allow it."""
         a = self._arena
         blocks = list(self.blocks)
-        cut = None
-        for j in range(len(blocks) - 1, -1, -1):
-            if isinstance(blocks[j], SpatialReductionPatchEmbedding):
-                cut = j
-                break
-        if cut is None:
-            cut = len(blocks) // 2
-        tail = [p for m in blocks[cut:] for p in m.parameters()] + list(self.norm.parameters()) + \
-            list(self.cls_head.parameters()) + (list(self.patch_head.parameters()) if self.patch_head is not None else []) + \
+        sr = [j for j in range(len(blocks)) if isinstance(blocks[j], SpatialReductionPatchEmbedding)]
+        cuts = list(reversed(sr))[:max(parts - 1, 1)] if sr else [len(blocks) // 2]
+        heads = list(self.norm.parameters()) + list(self.cls_head.parameters()) + \
+            (list(self.patch_head.parameters()) if self.patch_head is not None else []) + \
             (list(self.dst_head.parameters()) if self.dst_head is not None else [])
-        tail_ids = {id(p) for p in tail}
-        if not tail:
-            return None
-        start = min(a["offsets"][a["index"][id(p)]][0] for p in tail)
-        for p, (off, _) in zip(a["params"], a["offsets"]):
-            if (off >= start) != (id(p) in tail_ids):
-                return None                                     # tail parameters are not contiguous in the arena
-        return cut, start
+        out = []
+        for cut in cuts:
+            tail = [p for m in blocks[cut:] for p in m.parameters()] + heads
+            tail_ids = {id(p) for p in tail}
+            if not tail:
+                return None
+            start = min(a["offsets"][a["index"][id(p)]][0] for p in tail)
+            for p, (off, _) in zip(a["params"], a["offsets"]):
+                if (off >= start) != (id(p) in tail_ids):
+                    return None                                 # tail parameters are not contiguous in the arena
+            out.append((cut, start))
+        return out[0] if parts == 2 else out
 
     def _bwd_loop(self, st, stop):
         a = self._arena
