@@ -261,18 +261,32 @@ def main():
                     traffic = round(tv["read_bytes_per_launch"] + tv["write_bytes_per_launch"], 1)
                     traffic_note = "HBM bytes per launch (read + write) of %s from profiles/r01_hbm_traffic.json: %s" % (
                         fam, tj["source"])
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
+        # which roof binds the dominant kernel: its arithmetic intensity (dense-equivalent FLOPs per algorithmic byte of a launch)
+        # against the machine balance peak_flops / peak_bandwidth; the other roof is reported beside it
+        HBM_PEAK = 8000.0                                                   # GB/s, /opt/skills/guides/MI355X_MICROARCH.md
+        intensity = dense / by
+        ridge = peak * 1e12 / (HBM_PEAK * 1e9)
+        gbps = by / sec / 1e9
+        if intensity < ridge:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbps, 1), "peak": HBM_PEAK, "unit": "GB/s",
+                    "frac": round(gbps / HBM_PEAK, 4)}
+        else:
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4)}
+        roof.update({"traffic": traffic, "traffic_note": traffic_note,
+                "arithmetic_intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
                 "launches_per_step": n // args.profile_steps, "avg_launch_us": round(sec / n * 1e6, 2),
                 "flops_per_launch": fl / n, "dense_flops_per_launch": dense / n, "algorithmic_bytes_per_launch": by / n,
-                "hbm_bound_check": {"algorithmic_GBps": round(by / sec / 1e9, 1), "peak_GBps": 8000.0},
+                "mfma_check": {"achieved_TFLOPs_kept": round(ach, 2), "achieved_TFLOPs_dense_equiv": round(dense / sec / 1e12, 2),
+                               "peak_TFLOPs": peak, "frac_kept": round(ach / peak, 4)},
+                "hbm_bound_check": {"algorithmic_GBps": round(gbps, 1), "peak_GBps": HBM_PEAK},
                 "note": "FLOPs = kept (un-masked) sub-problems only; HIP events (recorded on the stream each kernel is launched "
                         "on) around every vr_gemm launch of %d extra eager steps after the timed region" % args.profile_steps,
                 "all_gemm_ms_per_step": round(gemm_sec * 1e3, 3),
                 "all_gemm_kinds": {k: {
                     "tflops_kept": round(v[1] / v[0] / 1e12, 2), "tflops_dense_equiv": round(v[4] / v[0] / 1e12, 2),
                     "algorithmic_GBps": round(v[2] / v[0] / 1e9, 1), "ms_per_step": round(v[0] / args.profile_steps * 1e3, 3)}
-                    for k, v in byname.items()}}
+                    for k, v in byname.items()}})
     cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.workload)      # rank 0 at N = 1 only
     from vitres.network_utils.compute_flop_mac import train_flops_per_image
     dense_flops = train_flops_per_image(nd)
