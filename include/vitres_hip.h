@@ -210,6 +210,18 @@ int vr_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* ls
 int vr_softce(const float* logits, const float* target, float* loss_rows, float* dlogits, int32_t R,
               int32_t K, float gscale, vr_stream_t stream);
 
+/*
+ * The loss step of the training loop in one pass (engine.py:153-157 with timm's SoftTargetCrossEntropy): row r of `logits`
+ * [R, K] belongs to internal sample s = r / rows_per_sample and is scored against target row
+ * (sample_map ? sample_map[s] : s) * rows_per_sample + r % rows_per_sample  (the model runs a batch grouped by architecture,
+ * targets stay in the caller's order);  *loss_acc += loss_scale * loss_row (atomics; caller zeroes it);
+ * dlogits[r, k] = gscale * (softmax(x[r])[k] * sum_k t[.,k] - t[.,k]) in `grad_dtype` with row pitch ld_grad >= K, columns
+ * K..ld_grad-1 zeroed -- exactly what the head's backward GEMMs read.
+ */
+int vr_softce_train(const float* logits, const float* target, const int64_t* sample_map, int32_t rows_per_sample,
+                    float* loss_acc, void* dlogits, int32_t ld_grad, int32_t grad_dtype, int32_t R, int32_t K,
+                    float gscale, float loss_scale, vr_stream_t stream);
+
 /* out[n] += sum_m in[map(m), n]  (bias gradients; atomics, caller zeroes out).  in: dtype [*, ld]. */
 int vr_colsum(const void* in, float* out, int32_t M, int32_t N, int32_t ld, int32_t dtype, vr_rowmap map, vr_stream_t stream);
 

@@ -188,6 +188,21 @@ def softce(logits, target, gscale, want_grad=True):
     return loss, d
 
 
+def softce_train(logits, target, sample_map, rows_per_sample, loss_acc, grad_dtype):
+    K = logits.shape[-1]
+    X = logits.reshape(-1, K).float()
+    R = X.shape[0]
+    s = torch.arange(R) // rows_per_sample
+    src = (sample_map.long()[s] if sample_map is not None else s) * rows_per_sample + torch.arange(R) % rows_per_sample
+    T = target.reshape(-1, K).float()[src]
+    lsm = torch.log_softmax(X, -1)
+    loss_acc += (-(T * lsm).sum(-1)).sum() / R
+    ld = (K + 7) // 8 * 8
+    d = torch.zeros(R, ld)
+    d[:, :K] = (torch.softmax(X, -1) * T.sum(-1, keepdim=True) - T) / R
+    return d.to(grad_dtype)
+
+
 def colsum(x, out, M, N, ld, row_map=None):
     out += _flat2d(x, ld)[_rows(M, row_map)][:, :N].float().sum(0)
     return out
@@ -355,7 +370,7 @@ def patch_fold(col, B, gh, gw, P, C):
     return x.reshape(B * gh * P * gw * P, C).clone()
 
 
-ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "colsum", "scale_mask_cast",
+ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "softce_train", "colsum", "scale_mask_cast",
        "batchsum", "conv3x3", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
 
 

@@ -502,3 +502,29 @@ def test_token_rows_of_embed_and_spatial_reduction_kernels(dtype, T):
     do = rnd(B, T + go * go, C, seed=10)
     r, e = both("sr_resid_bwd", (do, B, g, Cin, C, T))
     assert r.shape == (B, N, Cin) and relerr(r, e) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,rps,K_,mapped", [(8, 1, 1000, True), (8 * 16, 16, 1000, True), (6, 1, 10, False), (12, 4, 37, True)])
+def test_softce_train(dtype, R, rps, K_, mapped):
+    """vr_softce_train: mean soft-target CE of internally ordered logits against caller-ordered targets, loss accumulated into
+    one scalar, gradient in the head GEMMs' layout (row pitch rounded up to 8, pad zeroed)."""
+    B = R // rps
+    logits, target = rnd(R, K_, seed=1, scale=2.0), torch.softmax(rnd(R, K_, seed=2), -1)
+    smap = torch.randperm(B, generator=torch.Generator().manual_seed(3)) if mapped else None
+    acc_ref = torch.full((1,), 0.5)
+    ref = E.softce_train(logits, target, smap, rps, acc_ref, dtype)
+    acc = torch.full((1,), 0.5, device=DEV)
+    real = K.softce_train(logits.to(DEV), target.to(DEV), None if smap is None else smap.to(DEV), rps, acc, dtype)
+    torch.cuda.synchronize()
+    assert real.shape == ref.shape == (R, (K_ + 7) // 8 * 8)
+    assert abs(acc.item() - acc_ref.item()) < 1e-5 * abs(acc_ref.item())
+    assert relerr(real, ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert float(real[:, K_:].float().abs().max() if K_ % 8 else 0.0) == 0.0
+    # against the two-step torch statement: gather targets, mean CE, autograd
+    x = logits.clone().requires_grad_(True)
+    src = (smap.repeat_interleave(rps) * rps + torch.arange(R) % rps) if smap is not None else torch.arange(R)
+    loss = torch.sum(-target[src] * torch.log_softmax(x, -1), -1).mean()
+    loss.backward()
+    assert abs(acc.item() - 0.5 - loss.item()) < 1e-5 * abs(loss.item())
+    assert relerr(real[:, :K_], x.grad) < (1e-5 if dtype == torch.float32 else 1e-2)

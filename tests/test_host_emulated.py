@@ -383,3 +383,34 @@ def test_emulated_single_stage_patch16_sibling_matches_reference(monkeypatch, mo
     assert rel(ec, torch.from_numpy(g["eval.cls"])) < 5e-5 and rel(ed, torch.from_numpy(g["eval.dst"])) < 5e-5
     with pytest.raises(AssertionError):                                        # SR entries are not part of this grammar
         vitres.create_model("flexible_vit_patch16_224", img_size=64, num_classes=recipe.MICRO_CLASSES, network_def=recipe.MICRO_DEFS[0])
+
+
+@pytest.mark.parametrize("et,mode,pot", [(0, "multi", "seq"), (0, "multi", "avg"), (4, "plain", "seq"), (0, "single", "seq")])
+def test_emulated_loss_and_grad_equals_autograd_path(monkeypatch, et, mode, pot):
+    """model.loss_and_grad (forward + vr_softce_train + backward without autograd, logits kept in the internal sample order)
+    gives the loss and the gradients of criterion(forward()).backward()."""
+    emu_kernels.install(monkeypatch)
+    prod, orc, sd = build_pair(et, mode, 100 + et)
+    prod.set_compute_dtype(torch.float32)
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    prod.train()
+    if mode != "plain":
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+    torch.manual_seed(11)
+    prod.zero_grad(set_to_none=True)
+    cls, pat = prod(x, patch_output_type=pot)
+    loss = O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt if pot == "seq" else t)
+    loss.backward()
+    want = {n: p.grad.clone() for n, p in prod.named_parameters()}
+    keeps = [k.clone() for k in prod.last_keeps] if prod.last_keeps else None
+    torch.manual_seed(11)
+    prod.zero_grad(set_to_none=True)
+    got = prod.loss_and_grad(x, t, pt if pot == "seq" else None, pot)
+    if keeps is not None:
+        assert all(torch.equal(a, b) for a, b in zip(keeps, prod.last_keeps))
+    assert abs(got.item() - loss.item()) < 1e-5 * abs(loss.item())
+    for n, p in prod.named_parameters():
+        assert p.grad is not None and rel(p.grad, want[n]) < 1e-5, n
+    with pytest.raises(RuntimeError):
+        prod.loss_and_grad(x, t, pt, pot)                      # gradients not cleared

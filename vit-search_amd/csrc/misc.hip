@@ -75,6 +75,42 @@ __global__ __launch_bounds__(256) void softce_kernel(const float* __restrict__ x
     }
 }
 
+// Loss step of the training loop in one pass: logits rows are in the model's internal (architecture-grouped) sample order, targets
+// in the caller's; the mean loss is accumulated into one scalar and the gradient is written in the dtype / row pitch the head's
+// backward GEMMs read (pad columns zeroed) -- no torch glue (gather, mean, add, mul, pad, cast) between the heads and the backward.
+template <typename TG>
+__global__ __launch_bounds__(256) void softce_train_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                           const long long* __restrict__ sample_map, int rps,
+                                                           float* __restrict__ loss_acc, TG* __restrict__ dx, int ld_grad, int R,
+                                                           int K, float gscale, float loss_scale) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int s = r / rps;
+    const long long trow = (sample_map ? sample_map[s] : (long long)s) * rps + (r - s * rps);
+    const float* xr = x + (long long)r * K;
+    const float* tr = t + trow * K;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, xr[k]);
+    mx = wave_max(mx);
+    float se = 0.f, st = 0.f, stx = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float xv = xr[k], tv = tr[k];
+        se += __expf(xv - mx);
+        st += tv;
+        stx += tv * xv;
+    }
+    se = wave_sum(se);
+    st = wave_sum(st);
+    stx = wave_sum(stx);
+    const float lse = mx + __logf(se);
+    if (lane == 0) atomicAdd(loss_acc, (lse * st - stx) * loss_scale);
+    TG* dr = dx + (long long)r * ld_grad;
+    const float inv = 1.0f / se;
+    for (int k = lane; k < ld_grad; k += 64)
+        Elem<TG>::st(dr + k, k < K ? gscale * (__expf(xr[k] - mx) * inv * st - tr[k]) : 0.f);
+}
+
 // ---- column sums (bias gradients) ----------------------------------------------------------------------
 // grid.x over column groups of 256, grid.y over row chunks; thread = one column; atomics at the end.
 template <typename T>
@@ -380,6 +416,23 @@ extern "C" int vr_softce(const float* logits, const float* target, float* loss_r
     if (!logits || !target || !loss_rows || R <= 0 || K <= 0) return VR_EINVAL;
     hipLaunchKernelGGL(softce_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, target, loss_rows,
                        dlogits, R, K, gscale);
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_softce_train(const float* logits, const float* target, const int64_t* sample_map, int32_t rows_per_sample,
+                               float* loss_acc, void* dlogits, int32_t ld_grad, int32_t grad_dtype, int32_t R, int32_t K,
+                               float gscale, float loss_scale, vr_stream_t stream) {
+    if (!logits || !target || !loss_acc || !dlogits || R <= 0 || K <= 0 || rows_per_sample <= 0 || ld_grad < K) return VR_EINVAL;
+    const dim3 grid((R + 3) / 4);
+    if (grad_dtype == VR_F32)
+        hipLaunchKernelGGL((softce_train_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, logits, target,
+                           (const long long*)sample_map, rows_per_sample, loss_acc, (float*)dlogits, ld_grad, R, K, gscale, loss_scale);
+    else if (grad_dtype == VR_BF16)
+        hipLaunchKernelGGL((softce_train_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, logits, target,
+                           (const long long*)sample_map, rows_per_sample, loss_acc, (bf16_t*)dlogits, ld_grad, R, K, gscale, loss_scale);
+    else
+        return VR_EUNSUPPORTED;
     VR_CHECK_LAUNCH();
     return VR_OK;
 }

@@ -52,6 +52,7 @@ SYMBOLS = {
     "vr_attn_fwd": [c_void_p] * 4 + [c_int32] * 4 + [c_float, c_int32, c_void_p],
     "vr_attn_bwd": [c_void_p] * 7 + [c_int32] * 4 + [c_float, c_int32, c_void_p],
     "vr_softce": [c_void_p] * 4 + [c_int32, c_int32, c_float, c_void_p],
+    "vr_softce_train": [c_void_p] * 3 + [c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_void_p],
     "vr_colsum": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, RowMap, c_void_p],
     "vr_scale_mask_cast": [c_void_p] * 4 + [c_int32] * 4 + [c_void_p],
     "vr_conv3x3_wgrad": [c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],

@@ -10,6 +10,7 @@ ranks are averaged by one flat all-reduce (GradSync) instead of DDP buckets; the
 done on the device and read back every `sync_every` iterations (reference: every iteration).
 """
 import math
+import os
 import sys
 import time
 from collections import defaultdict
@@ -186,6 +187,11 @@ class GraphedTrainStep:
         of the backward -- most of the time -- is still running."""
         self.model, self.criterion, self.pot = model, criterion, patch_output_type
         self.graph_b, self.split, self.more_graphs, self.ranges = None, None, [], []
+        # soft-target CE is the training loss of every shipped recipe (main.py:390-398): the whole step then runs without
+        # autograd and without torch glue between the heads and the backward (model.loss_and_grad / vr_softce_train)
+        from .losses import SoftTargetCrossEntropy
+        self.fused_loss = isinstance(criterion, SoftTargetCrossEntropy) and hasattr(model, "loss_and_grad") and \
+            os.environ.get("VITRES_FUSED_LOSS", "1") != "0"
         self.x, self.t = samples.clone(), targets.clone()
         self.pt = patch_targets.clone() if patch_targets is not None else None
         B = samples.shape[0]
@@ -195,7 +201,7 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):                              # eager warm-up (arena, LDS attributes, allocator)
             for _ in range(warmup):
                 model.zero_grad(set_to_none=True)
-                self._loss(model(self.x, patch_output_type=self.pot)).backward()
+                self._step_body(None)
         torch.cuda.current_stream().wait_stream(side)
         plan = model.sample_plan(B)
         self.keep_static = None
@@ -214,10 +220,10 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         model._bwd_split = [c for c, _ in cuts] if cuts else None
         try:
+            self._loss_buf = torch.zeros(1, dtype=torch.float32, device=samples.device)
             with torch.cuda.graph(self.graph):
                 plan.keep_dev = self.keep_static
-                self.loss = self._loss(model(self.x, patch_output_type=self.pot, plan=plan))
-                self.loss.backward()
+                self.loss = self._step_body(plan)
             while getattr(model, "_bwd_state", None) is not None:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=self.graph.pool()):
@@ -234,6 +240,15 @@ class GraphedTrainStep:
             self.ranges.append((0, end))
         self.loss = self.loss.detach()
         torch.random.set_rng_state(rng)
+
+    def _step_body(self, plan):
+        """forward + loss + (first part of the) backward of one step; returns the loss tensor."""
+        if self.fused_loss:
+            return self.model.loss_and_grad(self.x, self.t, self.pt, self.pot, plan=plan,
+                                            loss_out=getattr(self, "_loss_buf", None) if plan is not None else None)
+        loss = self._loss(self.model(self.x, patch_output_type=self.pot, plan=plan))
+        loss.backward()
+        return loss
 
     def _loss(self, out):
         if self.pt is None:

@@ -391,7 +391,9 @@ def head_fwd(x, p, cfg, keep, with_patch, save, pre=None):
     return cls, pat, saved
 
 
-def head_bwd(dcls, dpat, saved, p, grads, cfg, keep, next_cast=None):
+def head_bwd(dcls, dpat, saved, p, grads, cfg, keep, next_cast=None, ready=False):
+    """ready: dcls / dpat are already [rows, classes rounded up to 8] in the compute dtype with zeroed pad columns
+    (kernels.softce_train) -- no padding / cast glue."""
     x, mean, rstd, y, ym = saved
     B, N, C = x.shape
     dt = cfg["dtype"]
@@ -400,27 +402,29 @@ def head_bwd(dcls, dpat, saved, p, grads, cfg, keep, next_cast=None):
     ldp = (nc + 7) // 8 * 8                                                 # logits-gradient rows zero-padded to 16 B
 
     def padded(d2):                                                         # tiny [rows, classes] tensors: torch glue
+        if ready:
+            return d2.view(-1, ldp)
         out = torch.zeros((d2.shape[0], ldp), dtype=dt, device=x.device)
         out[:, :nc] = d2
         return out
     if dcls is not None:
-        gc = padded(dcls.reshape(B, nc))
+        gc = padded(dcls if ready else dcls.reshape(B, nc))
         linear_wgrad(gc, y, grads["cls.w"], B, nc, C, ldp, C, b_map=(1, N, 0), db=grads["cls.b"])
         linear_dgrad(gc, p["cls"], dy, B, C, nc, ldp, C, c_map=(1, N, 0))
     T = cfg.get("tokens", 1)
     if dpat is not None and "dst" in p:                                      # distillation head on token row 1
-        gd = padded(dpat.reshape(B, nc))
+        gd = padded(dpat if ready else dpat.reshape(B, nc))
         linear_wgrad(gd, y, grads["dst.w"], B, nc, C, ldp, C, b_map=(1, N, 1), db=grads["dst.b"])
         linear_dgrad(gd, p["dst"], dy, B, C, nc, ldp, C, c_map=(1, N, 1))
     elif dpat is not None and ym is not None:                                # 'avg'
-        gp = padded(dpat.reshape(B, nc))
+        gp = padded(dpat if ready else dpat.reshape(B, nc))
         linear_wgrad(gp, ym, grads["patch.w"], B, nc, C, ldp, C, db=grads["patch.b"])
         dmean = torch.empty((B, C), dtype=dt, device=x.device)
         linear_dgrad(gp, p["patch"], dmean, B, C, nc, ldp, C)
         K.token_mean_bwd(dmean, dy, T)
     elif dpat is not None:
         R = B * (N - T)
-        gp = padded(dpat.reshape(R, nc))
+        gp = padded(dpat if ready else dpat.reshape(R, nc))
         linear_wgrad(gp, y, grads["patch.w"], R, nc, C, ldp, C, b_map=(N - T, N, T), db=grads["patch.b"])
         linear_dgrad(gp, p["patch"], dy, R, C, nc, ldp, C, c_map=(N - T, N, T))
     return K.ln_bwd(dy, x, p["nw"], mean, rstd, keep, N, None, grads["nw"], grads["nb"], next_cast=next_cast)

@@ -245,6 +245,17 @@ def softce(logits, target, gscale, want_grad=True):
     return loss_rows, dlogits
 
 
+def softce_train(logits, target, sample_map, rows_per_sample, loss_acc, grad_dtype):
+    """dlogits (grad_dtype, row pitch = classes rounded up to 8, pad zeroed) of mean soft-target CE; loss_acc += the mean."""
+    K = logits.shape[-1]
+    R = logits.numel() // K
+    ld = (K + 7) // 8 * 8
+    d = torch.empty((R, ld), dtype=grad_dtype, device=logits.device)
+    _lib.check(_lib.lib().vr_softce_train(_p(logits), _p(target), _p(sample_map), rows_per_sample, _p(loss_acc), _p(d), ld,
+                                          _dtcode(grad_dtype), R, K, 1.0 / R, 1.0 / R, _stream()), "vr_softce_train")
+    return d
+
+
 def colsum(x, out, M, N, ld, row_map=None):
     _lib.check(_lib.lib().vr_colsum(_p(x), _p(out), M, N, ld, _dt(x), _rm(row_map), _stream()), "vr_colsum")
     return out

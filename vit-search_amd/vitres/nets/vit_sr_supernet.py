@@ -484,6 +484,52 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             out = tuple(o.index_select(0, inv_idx) for o in out) if isinstance(out, tuple) else out.index_select(0, inv_idx)
         return out
 
+    def loss_and_grad(self, x, targets, patch_targets=None, patch_output_type=None, plan=None, loss_out=None):
+        """Forward + soft-target cross entropy of the training loop (engine.py:135-157 with timm's SoftTargetCrossEntropy:
+        CE(cls, targets) [+ CE(patch, patch_targets) for 'seq' / CE(patch_mean, targets) for 'avg'; two-token models: CE of the
+        class logits only, as the reference's no-teacher branch] + backward, WITHOUT autograd: the logits never leave the internal
+        sample order, vr_softce_train scores them against the caller-ordered targets, accumulates the mean loss and writes the
+        logit gradients in the layout the head's backward GEMMs read.  Same gradients as `loss.backward()` on forward()'s
+        outputs; they land in the flat arena and are exposed as `p.grad`.  Requires zero_grad(set_to_none=True) since the last
+        backward.  Returns the loss as a 0-d device tensor (loss_out: a preallocated fp32 [1] buffer, e.g. under hipGraph capture)."""
+        if _REQUIRE_CUDA and not x.is_cuda:
+            raise RuntimeError('vitres runs on MI355X through libvitres_hip.so only; got a %s tensor' % x.device)
+        if not self.training:
+            raise RuntimeError('loss_and_grad is a training-step primitive: call model.train() first')
+        if patch_output_type not in (None, 'seq', 'avg'):
+            raise ValueError()
+        a = self._ensure_arena(x.device)
+        if any(p_.grad is not None for p_ in a["params"]):
+            raise RuntimeError('loss_and_grad needs fresh gradients: zero_grad(set_to_none=True) first')
+        use_patch = bool(self.patch_output and patch_targets is not None or (self.patch_output and patch_output_type == 'avg'))
+        with_patch = (2 if patch_output_type == 'avg' else 1) if (self.patch_output and use_patch) else 0
+        if self.num_tokens == 2:
+            with_patch = 3
+        if plan is None:
+            plan = self.sample_plan(x.shape[0])
+        self._upload_plan(plan, x.device)
+        x = x.contiguous().float()
+        smap = None
+        if plan.order is not None:
+            smap, _ = self._order_tensors(plan.order, x.device)
+            x = x.index_select(0, smap)
+        with torch.no_grad():
+            cls, pat, tape = self._run_forward(x, plan, with_patch, True)
+            loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=x.device)
+            loss.zero_()
+            dt = self.compute_dtype
+            dcls = K.softce_train(cls, targets.float(), smap, 1, loss, dt)
+            dpat = None
+            if with_patch == 1:
+                dpat = K.softce_train(pat, patch_targets.float(), smap, pat.shape[1], loss, dt)
+            elif with_patch == 2:
+                dpat = K.softce_train(pat, targets.float(), smap, 1, loss, dt)
+            self._run_backward(tape, plan, dcls, dpat, ready=True)
+            for p_ in a["params"]:
+                if p_.requires_grad:
+                    p_.grad = self._gview(p_)
+        return loss[0]
+
     def _layer_params(self, blk):
         if isinstance(blk, Block):
             return {"n1w": blk.norm1.weight.detach(), "n1b": blk.norm1.bias.detach(),
@@ -618,7 +664,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         return cls, pat, tape
 
     # ---- backward ----------------------------------------------------------------------------------
-    def _run_backward(self, tape, plan, dcls, dpat):
+    def _run_backward(self, tape, plan, dcls, dpat, ready=False):
         a = self._arena
         params = a["params"]
         fresh = all(p.grad is None for p in params)
@@ -631,7 +677,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             a["gcur"].zero_()
         a["gzeroed"] = False
         Fn.join_side()                     # transposed weight shadows (issued beside the forward)
-        st = {"rtape": list(reversed(tape)), "plan": plan, "dcls": dcls, "dpat": dpat, "i": 0, "g": None, "gt": None}
+        st = {"rtape": list(reversed(tape)), "plan": plan, "dcls": dcls, "dpat": dpat, "i": 0, "g": None, "gt": None,
+              "ready": ready}
         # _bwd_split = j: stop after the head and blocks[j:]; the rest runs in resume_backward() (a second hipGraph, so that the
         # all-reduce of the finished tail of the gradient arena overlaps it -- engine.GraphedTrainStep)
         cuts = getattr(self, "_bwd_split", None)
@@ -717,7 +764,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 if self.dst_head is not None:
                     grads["dst.w"], grads["dst.b"] = gv(self.dst_head.weight), gv(self.dst_head.bias)
                 nc = consumer_cast(ti)
-                g = Fn.head_bwd(dcls, dpat, sv, hp, grads, hcfg, hk, next_cast=nc)
+                g = Fn.head_bwd(dcls, dpat, sv, hp, grads, hcfg, hk, next_cast=nc, ready=st.get("ready", False))
                 g, gt = g if nc is not None else (g, None)
             elif kind == "block":
                 _, blk, p, cfg, (ek, ka, km, ko, s1, s2), sa, sm = entry
