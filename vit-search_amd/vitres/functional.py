@@ -54,6 +54,22 @@ def _sides(dev):
     return side
 
 
+# VITRES_SIDE_DEFER=1: the side launch is ENQUEUED after the next kernel(s) of the main chain (its dependency -- an event recorded
+# now -- is unchanged).  In a captured graph the fork node then lists the main chain's successor first; whether the hipGraph
+# executor keeps the first successor on the parent's hardware queue decides if the main chain pays a cross-queue handoff
+# (12-17 us measured) at every fork.
+SIDE_DEFER = _os.environ.get('VITRES_SIDE_DEFER', '1') != '0'
+_deferred = []           # [(event on the main stream, side stream, fn)]
+
+
+def flush_side():
+    while _deferred:
+        ev, side, fn = _deferred.pop(0)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            fn()
+
+
 def on_side(fn, *keepalive):
     """Run fn() on a side stream after everything queued so far on the current stream; the tensors it reads are kept
     alive (so the caching allocator cannot hand them out again) until join_side()."""
@@ -61,14 +77,19 @@ def on_side(fn, *keepalive):
     sides = _sides(main.device)
     side = sides[_rr[0] % len(sides)]
     _rr[0] += 1
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        fn()
+    if SIDE_DEFER:
+        flush_side()                       # the previous one: at least one main kernel has been enqueued since
+        _deferred.append((main.record_event(), side, fn))
+    else:
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            fn()
     _pending.extend(keepalive)
 
 
 def join_side():
     """Current stream waits for ALL side-stream work issued so far (and releases every tensor kept for it)."""
+    flush_side()
     if _pending or _side_streams:
         main = torch.cuda.current_stream()
         for side in _side_streams.get(main.device, ()):
@@ -84,6 +105,7 @@ def join_side_lagged():
     stay alive meanwhile (one or two branches' worth, so buffers still recycle through the Infinity Cache)."""
     if JOIN_LAG <= 0:
         return join_side()
+    flush_side()
     main = torch.cuda.current_stream()
     sides = _side_streams.get(main.device)
     if sides is None:
