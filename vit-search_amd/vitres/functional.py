@@ -23,9 +23,9 @@ from . import kernels as K
 # At ViT-Res shapes each alone leaves most of the chip idle in its prologue / epilogue / tail phases, so they are
 # issued on two streams (parallel branches once the step is captured into a hipGraph) with `sched=1` launches
 # (one workgroup per tile) so the hardware interleaves both kernels' workgroups on every CU.
-OVERLAP = _os.environ.get('VITRES_OVERLAP', '1') != '0'
-DEFER_JOIN = _os.environ.get('VITRES_OVERLAP', '1') == '2'
-JOIN_PER_BLOCK = _os.environ.get('VITRES_OVERLAP', '1') == '3'
+OVERLAP = _os.environ.get('VITRES_OVERLAP', '3') != '0'
+DEFER_JOIN = _os.environ.get('VITRES_OVERLAP', '3') == '2'
+JOIN_PER_BLOCK = _os.environ.get('VITRES_OVERLAP', '3') == '3'
 FUSE_CAST = _os.environ.get('VITRES_FUSE_CAST', '1') != '0'      # LayerNorm backward also emits the next branch's gradient
 PROJ_LATE = _os.environ.get('VITRES_PROJ_LATE', '0') != '0'      # issue proj's weight gradient after the attention core
 # vr_gemm_ln (gemm_nt_ln.hip), opt-in: bit 0 = LayerNorm forward in the epilogue of the Linear that produces its input, bit 1 =
