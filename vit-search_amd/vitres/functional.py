@@ -341,7 +341,7 @@ def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep, gt=None, next_cast=
         if "finish" in grads:
             grads["finish"]()                                               # re-layout of the conv weight gradient
     if _overlap(gout):
-        on_side(wgrads, gt, gout)
+        on_side(wgrads, gt, gout, grads["reduce.w"], grads["pos_sum"], y, col)     # kept alive until the (lagged) join
     else:
         wgrads()
     dcol = torch.empty((B * P, 9 * C), dtype=dt, device=x.device)
@@ -352,7 +352,7 @@ def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep, gt=None, next_cast=
     gres = K.sr_resid_bwd(gout, B, g, C, Co, T)
     out = K.ln_bwd(dy, x, p["nw"], mean, rstd, embed_keep, Ni, gres, grads["nw"], grads["nb"], next_cast=next_cast)
     if _overlap(gout):
-        join_side()
+        join_side_lagged()                 # (a full join here stalled the main chain ~200 us behind the conv weight gradient)
     return out
 
 
