@@ -179,11 +179,18 @@ def main():
     if not args.no_graph:
         # N > 1: the backward is captured as two graphs so that the all-reduce of the last stage's gradients (the tail of
         # the flat arena, most of the parameters) runs on RCCL's stream while the rest of the backward is still computing
-        graphed = engine.GraphedTrainStep(model, crit, x, t, pt, "seq", split_for_sync=split)
+        # VITRES_OPT_IN_GRAPH=1 (one rank, FlatAdamW): the update is captured into the graph as well (measured neutral: 9.10 vs
+        # 9.06 ms; with the arena tail updated beside the rest of the backward, VITRES_OPT_TAIL_OVERLAP=1, slower: 9.43)
+        opt_in_graph = world == 1 and args.optimizer == "flat" and os.environ.get("VITRES_OPT_IN_GRAPH", "0") != "0"
+        graphed = engine.GraphedTrainStep(model, crit, x, t, pt, "seq", split_for_sync=split,
+                                          optimizer=opt if opt_in_graph else None)
 
     def step(i):
         if graphed is None:
             return eager_step(i)
+        if graphed.optimizer is not None:
+            opt.prepare_step()                                   # this step's lr / bias corrections -> device; the graph does the rest
+            return graphed(x, t, pt, epoch=31, train_iter=i, arch_sample=arch)
         # fwd + loss + bwd (hipGraph replay) + gradient exchange (averaged), then the optimizer
         loss = graphed.step_with_sync(sync, x, t, pt, average=average, epoch=31, train_iter=i, arch_sample=arch)
         opt.step()

@@ -678,3 +678,50 @@ def test_single_stage_patch16_sibling_vs_reference_golden(mode, dtype):
     with torch.no_grad():
         ec, ed = prod(x.to(DEV))
     assert rel(ec, g["eval.cls"]) < tol_l and rel(ed, g["eval.dst"]) < tol_l
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_optimizer_inside_the_graph_equals_step_after_the_graph(dtype):
+    """GraphedTrainStep(optimizer=FlatAdamW): the AdamW update captured into the step's hipGraph (arena tail on the side stream
+    beside the rest of the backward, hyper-parameters read from device memory that prepare_step() rewrites per step) walks the
+    same parameter trajectory as graph replay + optimizer.step(), including a learning-rate change between steps."""
+    from vitres import engine
+    from vitres.optim import FlatAdamW
+    from vitres.losses import SoftTargetCrossEntropy
+    crit = SoftTargetCrossEntropy()
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1))
+    runs = []
+    for in_graph in (False, True):
+        prod, orc, sd = build_pair(0, "multi", 100)
+        prod.set_compute_dtype(dtype)
+        prod.train()
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+        opt = FlatAdamW(prod, engine.param_groups_weight_decay(prod, 0.05), lr=2e-3, ema_decay=0.99)
+        if dtype == torch.bfloat16:
+            opt.own_shadow()
+        g = engine.GraphedTrainStep(prod, crit, x, t, pt, "seq", optimizer=opt if in_graph else None)
+        assert (g.optimizer is not None) == in_graph
+        losses = []
+        for it in range(4):
+            torch.manual_seed(900 + it)
+            if it == 2:
+                for grp in opt.param_groups:
+                    grp["lr"] = 5e-4                               # scheduler-style change
+            if in_graph:
+                opt.prepare_step()
+                losses.append(g(x, t, pt, epoch=31, train_iter=it, arch_sample=None).item())
+            else:
+                losses.append(g(x, t, pt, epoch=31, train_iter=it, arch_sample=None).item())
+                opt.step()
+        torch.cuda.synchronize()
+        runs.append((losses, prod._arena["flat"].clone(), opt._flat_state["v"].clone(), opt._flat_state["ema"].clone(), opt._step,
+                     prod._arena["shadow"].clone() if dtype == torch.bfloat16 else None))
+    (l0, p0, v0, e0, s0, sh0), (l1, p1, v1, e1, s1, sh1) = runs
+    assert s0 == s1 == 4
+    tol = 2e-3                                                     # atomics order of the weight gradients differs run to run; Adam amplifies it
+    assert max(abs(a - b) / abs(a) for a, b in zip(l0, l1)) < (1e-5 if dtype == torch.float32 else 2e-2)
+    assert rel(p1, p0.cpu()) < tol and rel(e1, e0.cpu()) < tol and rel(v1, v0.cpu()) < (1e-5 if dtype == torch.float32 else 5e-2)
+    if sh0 is not None:
+        assert torch.equal(sh1.float(), p1.bfloat16().float())     # the in-graph update keeps the bf16 shadow in step

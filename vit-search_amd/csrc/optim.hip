@@ -12,15 +12,18 @@ struct Groups {
     vr_adamw_group g[VR_ADAMW_MAX_GROUPS];
 };
 
+// DEV: the per-group hyper-parameters are read from device memory (groups_dev) instead of the launch arguments, so that a launch
+// captured into a hipGraph follows the learning-rate schedule and the bias corrections of every replayed step.
+template <bool DEV>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, float* __restrict__ ema,
                                                     float ema_decay, const uint8_t* __restrict__ group_of_8, Groups groups,
-                                                    long long n8) {
+                                                    const vr_adamw_group* __restrict__ groups_dev, long long n8) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
         const int gi = group_of_8[i];
         if (gi == 255) continue;                                   // padding / frozen parameters
-        const vr_adamw_group h = groups.g[gi];
+        const vr_adamw_group h = DEV ? groups_dev[gi] : groups.g[gi];
         const long long e = i * 8;
         float pv[8], gv[8], mv[8], vv[8];
 #pragma unroll
@@ -67,21 +70,38 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 }  // namespace
 
-extern "C" int vr_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, float* ema, float ema_decay,
-                             const uint8_t* group_of_8, const vr_adamw_group* groups, int32_t n_groups, int64_t n,
-                             vr_stream_t stream) {
+static int adamw_launch(float* p, const float* g, float* m, float* v, void* shadow, float* ema, float ema_decay,
+                        const uint8_t* group_of_8, const vr_adamw_group* groups, bool on_device, int32_t n_groups, int64_t n,
+                        vr_stream_t stream) {
     if (!p || !g || !m || !v || !group_of_8 || !groups || n <= 0 || n_groups <= 0) return VR_EINVAL;
     if (n_groups > VR_ADAMW_MAX_GROUPS) return VR_EUNSUPPORTED;
     if (n % 8 || ((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) || ((uintptr_t)v & 15) ||
         (shadow && ((uintptr_t)shadow & 15)) || (ema && ((uintptr_t)ema & 15)))
         return VR_EALIGN;
-    Groups gs;
-    for (int i = 0; i < n_groups; ++i) gs.g[i] = groups[i];
+    Groups gs = {};
+    if (!on_device)
+        for (int i = 0; i < n_groups; ++i) gs.g[i] = groups[i];
     const long long n8 = n / 8;
     long long blocks = (n8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow, ema,
-                       ema_decay, group_of_8, gs, n8);
+    if (on_device)
+        hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow,
+                           ema, ema_decay, group_of_8, gs, groups, n8);
+    else
+        hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow,
+                           ema, ema_decay, group_of_8, gs, nullptr, n8);
     VR_CHECK_LAUNCH();
     return VR_OK;
+}
+
+extern "C" int vr_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, float* ema, float ema_decay,
+                             const uint8_t* group_of_8, const vr_adamw_group* groups, int32_t n_groups, int64_t n,
+                             vr_stream_t stream) {
+    return adamw_launch(p, g, m, v, shadow, ema, ema_decay, group_of_8, groups, false, n_groups, n, stream);
+}
+
+extern "C" int vr_adamw_flat_dev(float* p, const float* g, float* m, float* v, void* shadow, float* ema, float ema_decay,
+                                 const uint8_t* group_of_8, const vr_adamw_group* groups_dev, int32_t n_groups, int64_t n,
+                                 vr_stream_t stream) {
+    return adamw_launch(p, g, m, v, shadow, ema, ema_decay, group_of_8, groups_dev, true, n_groups, n, stream);
 }

@@ -181,12 +181,18 @@ class GraphedTrainStep:
     torch's graph-safe device generator.  The gradient exchange and the optimizer stay outside the graph."""
 
     def __init__(self, model, criterion, samples, targets, patch_targets=None, patch_output_type=None, warmup=2,
-                 split_for_sync=False):
+                 split_for_sync=False, optimizer=None):
         """split_for_sync: capture the backward as TWO graphs cut after the last stage (model.split_plan()), so that
         step_with_sync() can all-reduce the finished tail of the gradient arena (most of the parameters) while the rest
         of the backward -- most of the time -- is still running."""
         self.model, self.criterion, self.pot = model, criterion, patch_output_type
         self.graph_b, self.split, self.more_graphs, self.ranges = None, None, [], []
+        # optimizer (a vitres.optim.FlatAdamW, single rank): the update becomes part of the graph -- the arena tail (last stage +
+        # heads, most parameters) is updated on the side stream as soon as its gradients are final, beside the rest of the
+        # backward; the remainder after it.  Call optimizer.prepare_step() before every replay instead of optimizer.step().
+        self.optimizer = optimizer if (optimizer is not None and hasattr(optimizer, "step_device")) else None
+        if self.optimizer is not None and split_for_sync:
+            raise ValueError("optimizer-in-graph is for one rank; with a gradient exchange step the optimizer after step_with_sync")
         # soft-target CE is the training loss of every shipped recipe (main.py:390-398): the whole step then runs without
         # autograd and without torch glue between the heads and the backward (model.loss_and_grad / vr_softce_train)
         from .losses import SoftTargetCrossEntropy
@@ -221,9 +227,32 @@ class GraphedTrainStep:
         model._bwd_split = [c for c, _ in cuts] if cuts else None
         try:
             self._loss_buf = torch.zeros(1, dtype=torch.float32, device=samples.device)
+            opt_cut = None
+            if self.optimizer is not None:
+                self.optimizer.prepare_step()                      # allocates / fills the device hyper-parameters (not captured)
+                self.optimizer._step -= 1
+                # VITRES_OPT_TAIL_OVERLAP=1: update the arena tail on the side stream beside the rest of the backward (measured
+                # slower: the 2 GB optimizer pass takes HBM bandwidth from the critical chain, 8.93 -> 9.43 ms)
+                opt_cut = model.split_plan() if os.environ.get("VITRES_OPT_TAIL_OVERLAP", "0") != "0" else None
+                if opt_cut is not None:
+                    model._bwd_split = opt_cut[0]
+                    model._bwd_join_parts = False                  # the second part follows in the same capture
             with torch.cuda.graph(self.graph):
                 plan.keep_dev = self.keep_static
                 self.loss = self._step_body(plan)
+                if self.optimizer is not None:
+                    from . import functional as Fn
+                    n_arena = model._arena["flat"].numel()
+                    if opt_cut is not None and getattr(model, "_bwd_state", None) is not None:
+                        lo = opt_cut[1]
+                        if Fn.OVERLAP:
+                            Fn.on_side(lambda: self.optimizer.step_device(lo, n_arena))
+                        else:
+                            self.optimizer.step_device(lo, n_arena)
+                        model.resume_backward()
+                        self.optimizer.step_device(0, lo)
+                    else:
+                        self.optimizer.step_device(0, n_arena)
             while getattr(model, "_bwd_state", None) is not None:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=self.graph.pool()):
@@ -231,6 +260,7 @@ class GraphedTrainStep:
                 self.more_graphs.append(g)
         finally:
             model._bwd_split = None
+            model._bwd_join_parts = True
         if self.more_graphs:
             self.graph_b = self.more_graphs[0]
             end = model._arena["gcur"].numel()

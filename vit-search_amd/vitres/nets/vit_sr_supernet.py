@@ -809,7 +809,9 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                     from .. import stem
                     stem.embed_conv_bwd(self, g, sv, ep, ecfg, ekeep, gv, gt=gt)
                 gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:self.num_tokens, :])
-        Fn.join_side()                     # weight-gradient GEMMs trail on the side stream (functional.on_side)
+        if stop >= len(rtape) or getattr(self, "_bwd_join_parts", True):
+            Fn.join_side()                 # weight-gradient GEMMs trail on the side stream (functional.on_side); an intermediate
+                                           # stop joins too unless the next part follows in the same capture (_bwd_join_parts)
         st["i"], st["g"], st["gt"] = stop, g, gt
 
 

@@ -71,12 +71,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if g is None or p0.grad is None or p0.grad.data_ptr() != g.data_ptr() + 4 * a["offsets"][0][0]:
             raise RuntimeError("FlatAdamW needs the gradients in the model's flat arena (one backward since zero_grad)")
         self._step += 1
-        t = self._step
-        arr = (_Group * len(self.param_groups))()
-        for gi, group in enumerate(self.param_groups):
-            b1, b2 = group["betas"]
-            arr[gi] = _Group(group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 - b1 ** t,
-                             math.sqrt(1.0 - b2 ** t), self.grad_scale)
+        arr = self._group_structs(self._step)
         st = self._flat_state
         shadow = a["shadow"] if self.model.compute_dtype == torch.bfloat16 else None
         _lib.check(_lib.lib().vr_adamw_flat(_p(a["flat"]), _p(g), _p(st["m"]), _p(st["v"]), _p(shadow), _p(st["ema"]),
@@ -85,6 +80,58 @@ class FlatAdamW(torch.optim.Optimizer):
         if shadow is not None:
             a["shadow_ok"] = True              # forwards skip their own vr_cast_f32_bf16 from now on (model.invalidate_shadow)
         return loss
+
+    # ---- the update as part of a captured hipGraph ---------------------------------------------------------------------
+    def _group_structs(self, t):
+        arr = (_Group * len(self.param_groups))()
+        for gi, group in enumerate(self.param_groups):
+            b1, b2 = group["betas"]
+            arr[gi] = _Group(group["lr"], b1, b2, group["eps"], group["weight_decay"], 1.0 - b1 ** t,
+                             math.sqrt(1.0 - b2 ** t), self.grad_scale)
+        return arr
+
+    def prepare_step(self):
+        """Advance the step count and upload this step's per-group hyper-parameters (learning rates written by the scheduler,
+        bias corrections) to the device buffer step_device() launches read -- call once before every replay of a graph that
+        contains step_device() launches (engine.GraphedTrainStep(optimizer=...))."""
+        a = self._bind()
+        dev = a["flat"].device
+        if getattr(self, "_hp_dev", None) is None or self._hp_dev.device != dev:
+            self._hp_dev = torch.zeros(MAX_GROUPS * 8, dtype=torch.float32, device=dev)
+        self._step += 1
+        arr = self._group_structs(self._step)
+        vals = []
+        for gi in range(len(self.param_groups)):
+            vals += [getattr(arr[gi], n) for n, _ in _Group._fields_]
+        host = torch.zeros(MAX_GROUPS * 8, dtype=torch.float32)
+        host[:len(vals)] = torch.tensor(vals, dtype=torch.float32)
+        if dev.type == "cuda":
+            host = host.pin_memory()       # a fresh pinned block per step: the host runs several replays ahead of the device, a
+                                           # reused staging buffer would be overwritten before its copy has executed
+        self._hp_dev.copy_(host, non_blocking=True)
+
+    @torch.no_grad()
+    def step_device(self, lo=0, hi=None):
+        """AdamW over the arena range [lo, hi) (multiples of 8) with the hyper-parameters prepare_step() uploaded: capturable."""
+        a = self._bind()
+        g = a.get("gcur")
+        if g is None or getattr(self, "_hp_dev", None) is None:
+            raise RuntimeError("step_device needs gradients in the arena and a prepare_step() before it")
+        n = a["flat"].numel()
+        hi = n if hi is None else hi
+        if lo % 8 or hi % 8 or not (0 <= lo < hi <= n):
+            raise ValueError("range must be non-empty and aligned to 8 elements")
+        st = self._flat_state
+        shadow = a["shadow"] if self.model.compute_dtype == torch.bfloat16 else None
+
+        def at(t, esz):
+            return None if t is None else t.data_ptr() + lo * esz
+        _lib.check(_lib.lib().vr_adamw_flat_dev(at(a["flat"], 4), at(g, 4), at(st["m"], 4), at(st["v"], 4), at(shadow, 2),
+                                                at(st["ema"], 4), float(self.ema_decay or 0.0), st["gid"].data_ptr() + lo // 8,
+                                                _p(self._hp_dev), len(self.param_groups), hi - lo, _stream()),
+                   "vr_adamw_flat_dev")
+        if shadow is not None:
+            a["shadow_ok"] = True
 
     def own_shadow(self):
         """Declare before capturing a hipGraph that this optimizer keeps the bf16 weight shadow up to date: casts it once
