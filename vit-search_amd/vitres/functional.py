@@ -70,17 +70,19 @@ def flush_side():
             fn()
 
 
-def on_side(fn, *keepalive):
+def on_side(fn, *keepalive, defer=True):
     """Run fn() on a side stream after everything queued so far on the current stream; the tensors it reads are kept
-    alive (so the caching allocator cannot hand them out again) until join_side()."""
+    alive (so the caching allocator cannot hand them out again) until join_side().  defer=False: launch at once (callers whose
+    fn() must have RUN on the host when on_side returns, or with no main kernel following before the join)."""
     main = torch.cuda.current_stream()
     sides = _sides(main.device)
     side = sides[_rr[0] % len(sides)]
     _rr[0] += 1
-    if SIDE_DEFER:
+    if SIDE_DEFER and defer:
         flush_side()                       # the previous one: at least one main kernel has been enqueued since
         _deferred.append((main.record_event(), side, fn))
     else:
+        flush_side()
         side.wait_stream(main)
         with torch.cuda.stream(side):
             fn()
@@ -429,24 +431,34 @@ def head_bwd(dcls, dpat, saved, p, grads, cfg, keep, next_cast=None, ready=False
         out = torch.zeros((d2.shape[0], ldp), dtype=dt, device=x.device)
         out[:, :nc] = d2
         return out
+    ov = _overlap(x)
+    side = []                                                               # weight gradients of the heads: beside the dgrad chain
+
+    def wg(fn, *keep):
+        if ov:
+            side.append((fn, keep))
+        else:
+            fn()
     if dcls is not None:
         gc = padded(dcls if ready else dcls.reshape(B, nc))
-        linear_wgrad(gc, y, grads["cls.w"], B, nc, C, ldp, C, b_map=(1, N, 0), db=grads["cls.b"])
+        wg(lambda: linear_wgrad(gc, y, grads["cls.w"], B, nc, C, ldp, C, b_map=(1, N, 0), db=grads["cls.b"]), gc)
         linear_dgrad(gc, p["cls"], dy, B, C, nc, ldp, C, c_map=(1, N, 0))
     T = cfg.get("tokens", 1)
     if dpat is not None and "dst" in p:                                      # distillation head on token row 1
         gd = padded(dpat if ready else dpat.reshape(B, nc))
-        linear_wgrad(gd, y, grads["dst.w"], B, nc, C, ldp, C, b_map=(1, N, 1), db=grads["dst.b"])
+        wg(lambda: linear_wgrad(gd, y, grads["dst.w"], B, nc, C, ldp, C, b_map=(1, N, 1), db=grads["dst.b"]), gd)
         linear_dgrad(gd, p["dst"], dy, B, C, nc, ldp, C, c_map=(1, N, 1))
     elif dpat is not None and ym is not None:                                # 'avg'
         gp = padded(dpat if ready else dpat.reshape(B, nc))
-        linear_wgrad(gp, ym, grads["patch.w"], B, nc, C, ldp, C, db=grads["patch.b"])
+        wg(lambda: linear_wgrad(gp, ym, grads["patch.w"], B, nc, C, ldp, C, db=grads["patch.b"]), gp, ym)
         dmean = torch.empty((B, C), dtype=dt, device=x.device)
         linear_dgrad(gp, p["patch"], dmean, B, C, nc, ldp, C)
         K.token_mean_bwd(dmean, dy, T)
     elif dpat is not None:
         R = B * (N - T)
         gp = padded(dpat if ready else dpat.reshape(R, nc))
-        linear_wgrad(gp, y, grads["patch.w"], R, nc, C, ldp, C, b_map=(N - T, N, T), db=grads["patch.b"])
+        wg(lambda: linear_wgrad(gp, y, grads["patch.w"], R, nc, C, ldp, C, b_map=(N - T, N, T), db=grads["patch.b"]), gp)
         linear_dgrad(gp, p["patch"], dy, R, C, nc, ldp, C, c_map=(N - T, N, T))
+    if side:
+        on_side(lambda: [fn() for fn, _ in side], y, *[t_ for _, keep in side for t_ in keep])
     return K.ln_bwd(dy, x, p["nw"], mean, rstd, keep, N, None, grads["nw"], grads["nb"], next_cast=next_cast)

@@ -607,7 +607,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                             side_params[id(blk_)] = self._layer_params(blk_)
                     if fresh:
                         a["gflat"].zero_()
-                Fn.on_side(side_prep)
+                Fn.on_side(side_prep)                  # enqueued (and side_params filled) by the flush_side() after the first branch
                 a["gzeroed"] = fresh
             else:
                 K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"])
@@ -623,7 +623,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         for blk, L in zip(self.blocks, plan.layers[1:]):
             if L is None:
                 continue
-            seq.append((blk, L, side_params.get(id(blk)) or self._layer_params(blk), self._layer_cfg(blk, grid)))
+            lazy = isinstance(blk, SpatialReductionPatchEmbedding) and save      # its weights are re-laid out by side_prep
+            seq.append((blk, L, None if lazy else self._layer_params(blk), self._layer_cfg(blk, grid)))
             if not isinstance(blk, Block):
                 grid //= 2
 
@@ -635,7 +636,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             blk_, L_, p_, cfg_ = seq[i]
             if isinstance(blk_, Block):
                 return p_["n1w"], p_["n1b"], plan.k(L_["embed"]), cfg_["eps"]
-            return p_["nw"], p_["nb"], plan.k(L_["embed"]), cfg_["eps"]
+            return blk_.norm.weight.detach(), blk_.norm.bias.detach(), plan.k(L_["embed"]), cfg_["eps"]
 
         pre = None
         for i, (blk, L, p, cfg) in enumerate(seq):
@@ -646,13 +647,20 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 ek, ka, km, ko = plan.k(L["embed"]), plan.k(L["attn"]), plan.k(L["mlp"]), plan.k(L["out"])
                 h, sa, pre = Fn.attn_branch_fwd(h, p, cfg, ek, ka, ko, s1, save, pre=pre,
                                                 next_ln=(p["n2w"], p["n2b"], ek, cfg["eps"]))
+                if i == 0:
+                    Fn.flush_side()        # side_prep: enqueued after the main chain's first kernels (functional.SIDE_DEFER)
                 h, sm, pre = Fn.mlp_branch_fwd(h, p, cfg, ek, km, ko, s2, save, pre=pre, next_ln=first_ln(i + 1))
                 if save:
                     tape.append(("block", blk, p, cfg, (ek, ka, km, ko, s1, s2), sa, sm))
             else:
-                if side_params:
-                    Fn.join_side()         # its weights were re-laid out on the side stream
-                    side_params = {}
+                if p is None:
+                    Fn.flush_side()
+                    p = side_params.get(id(blk))
+                    if p is None:
+                        p = self._layer_params(blk)
+                    elif not side_params.get("joined"):
+                        Fn.join_side()     # its weights were re-laid out on the side stream
+                        side_params["joined"] = True
                 ek, nk = plan.k(L["embed"]), plan.k(L["new"])
                 h, sv = Fn.sr_fwd(h, p, cfg, ek, nk, save, pre=pre)
                 pre = None
