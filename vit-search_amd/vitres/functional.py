@@ -34,7 +34,7 @@ PROJ_LATE = _os.environ.get('VITRES_PROJ_LATE', '0') != '0'      # issue proj's 
 # leave a CU 2-3 workgroups: forward fusion +0.5 % at width 256, -3 % with width 512 included; backward fusion -25 % (spills).
 FUSE_LN = int(_os.environ.get('VITRES_FUSE_LN', '0'))
 FUSE_LN_MAXN = int(_os.environ.get('VITRES_FUSE_LN_MAXN', '512'))
-STEM_SIDE = _os.environ.get('VITRES_STEM_SIDE', '0') != '0'      # conv-stem weight gradients on the side stream: measured slower
+STEM_SIDE = _os.environ.get('VITRES_STEM_SIDE', '1') != '0'      # conv-stem weight gradients on the side stream (+2 % since SIDE_DEFER)
 _side_streams = {}
 
 
