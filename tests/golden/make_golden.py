@@ -759,10 +759,110 @@ def f13_evolver():
             out[name + ".pieces"] = json.dumps([a, b, m, c, p])
     save("f13_evolver", **out)
 
+# ------------------------------------------------------------------------------------------------
+# F18: DropPath (nets/drop.py:11-26) with INJECTED uniform draws + full-size gradients + config C4 (sr_small)
+# ------------------------------------------------------------------------------------------------
+class RandInjector:
+    """nets/drop.py:23 is the only torch.rand call on the path: while active, every call returns the next row of a prepared
+    noise table (caller order, shape (B,)) reshaped to the requested shape; rows are consumed in call order."""
+
+    def __init__(self, noise):
+        self.noise, self.used = list(noise), 0
+        self._orig = torch.rand
+
+    def __enter__(self):
+        inj = self
+
+        def rand(shape, *a, **k):
+            row = inj.noise[inj.used]
+            inj.used += 1
+            return row.reshape(shape).to(k.get("dtype") or torch.float32)
+        torch.rand = rand
+        return self
+
+    def __exit__(self, *a):
+        torch.rand = self._orig
+
+
+def grad_samples(model):
+    """Per parameter: L2 norm (float64) and recipe.GRAD_SAMPLES elements at recipe.grad_sample_index positions."""
+    out = {}
+    for n, p_ in model.named_parameters():
+        g = p_.grad.detach().reshape(-1)
+        idx = recipe.grad_sample_index(n, g.numel())
+        out["gn." + n] = float(g.double().norm())
+        out["gs." + n] = g[torch.from_numpy(idx)].numpy().copy()
+    return out
+
+
+def f18_droppath_fullsize_c4():
+    # (a) micro supernets, embed types 0 and 4, 'multi', drop_path 0.2, explicit draws incl. dropped samples
+    B = 8
+    for et in (0, 4):
+        nd = recipe.MICRO_DEFS[et]
+        kw = dict(num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30)
+        m = build_ref(nd, supernet=True, drop_path_rate=0.2, **kw)
+        sd, shapes = load_recipe(m, seed=100 + et)
+        x, t, pt, labels = recipe.inputs(7, B, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+        m.train()
+        m.set_epoch(31)
+        m.load_state_dict(sd)
+        rates = [b.drop_path.drop_prob for b in m.blocks if hasattr(b, "drop_path") and not isinstance(b.drop_path, torch.nn.Identity)]
+        noise = recipe.drop_path_noise(1800 + et, rates, B)
+        torch.manual_seed(555 + 31)
+        with KeepRecorder() as rec, RandInjector([torch.from_numpy(r) for r in noise]) as inj:
+            cls, pat = m(x.clone(), patch_output_type="seq")
+        assert inj.used == len(noise)
+        loss = soft_ce(cls, t) + soft_ce(pat, pt)
+        loss.backward()
+        out = dict(state_crc=recipe.checksum(sd), rates=np.array(rates), noise=np.stack(noise), cls=cls.detach().numpy(),
+                   pat=pat.detach().numpy(), loss=loss.item(), keeps=torch.stack(rec.log).numpy())
+        out.update({"grad." + n: p_.grad.detach().numpy().copy() for n, p_ in m.named_parameters()})
+        save("f18_micro_t%d_multi_dp" % et, **out)
+
+    # (b) full size: sr_tiny supernet (C3 geometry) B=8 with drop_path 0.2, ref-tiny (C1/C2 geometry) B=2, sr_small supernet
+    # (C4: super_net/no_distill/small_flexible-conv-patch.sh:19, drop_path 0.3) B=8 -- logits, loss, keeps, gradient samples
+    cases = [("sr_tiny_c3", recipe.SR_TINY_DEF, "sr_tiny", 0.2, 8, 4343, 12),
+             ("ref_tiny_c2", recipe.REF_TINY_DEF, None, 0.2, 2, 4242, 11),
+             ("sr_small_c4", recipe.SR_SMALL_DEF, "sr_small", 0.3, 8, 4444, 13)]
+    for name, nd, space, dp, B, wseed, iseed in cases:
+        kw = {}
+        if space:
+            kw = dict(num_channels_to_keep=R.cfg[space].num_channels_to_keep, example_per_arch=2, num_warmup_epochs=30)
+        torch.manual_seed(0)
+        m = build_ref(nd, supernet=bool(space), img=224, classes=1000, drop_path_rate=dp, **kw)
+        sd, shapes = load_recipe(m, seed=wseed)
+        x, t, pt, labels = recipe.inputs(iseed, B, 224, 1000, 16)
+        m.train()
+        if space:
+            m.set_epoch(31)
+            m.load_state_dict(sd)
+        rates = [b.drop_path.drop_prob for b in m.blocks if hasattr(b, "drop_path") and not isinstance(b.drop_path, torch.nn.Identity)]
+        noise = recipe.drop_path_noise(1900 + iseed, rates, B)
+        torch.manual_seed(77)
+        with KeepRecorder() as rec, RandInjector([torch.from_numpy(r) for r in noise]) as inj:
+            cls, pat = m(x.clone(), patch_output_type="seq")
+        assert inj.used == len(noise)
+        loss = soft_ce(cls, t) + soft_ce(pat, pt)
+        loss.backward()
+        out = dict(state_crc=recipe.checksum(sd), n_params=sum(p_.numel() for p_ in m.parameters()), rates=np.array(rates),
+                   noise=np.stack(noise), cls=cls.detach().numpy(), pat_head8=pat.detach().numpy()[:, :, :8], loss=loss.item(),
+                   keys=np.array([k for k, _ in shapes]))
+        if rec.log:
+            out["keeps"] = torch.stack(rec.log).numpy()
+        if not space:                                   # conv stem: BatchNorm running statistics after the forward
+            bsd = m.state_dict()
+            for bn in ("conv1", "conv2", "conv3"):
+                out["bn.%s.running_mean" % bn] = bsd["patch_embed.%s.bn.running_mean" % bn].numpy().copy()
+                out["bn.%s.running_var" % bn] = bsd["patch_embed.%s.bn.running_var" % bn].numpy().copy()
+        out.update(grad_samples(m))
+        save("f18_" + name, **out)
+        del m
+
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15", "f16", "f17"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15", "f16", "f17", "f18"]
     table = dict(f1=f1_micro, f2=f2_masked_ln, f3=f3_channel_drop, f4=f4_fullsize, f5=f5_subnet,
-                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init, f13=f13_evolver, f14=f14_distill_token, f15=f15_distillation_engine, f16=f16_vit16, f17=f17_ra_sampler)
+                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init, f13=f13_evolver, f14=f14_distill_token, f15=f15_distillation_engine, f16=f16_vit16, f17=f17_ra_sampler, f18=f18_droppath_fullsize_c4)
     for w in which:
         table[w]()

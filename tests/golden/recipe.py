@@ -150,3 +150,29 @@ def vit16_keep_config():
     blk = {'attn': np.array([64, 32]), 'mlp': np.array([96, 64, 48]), 'layer': None}
     skip = {'attn': np.array([64, 32]), 'mlp': np.array([96, 64, 48]), 'layer': np.array([48, 0])}
     return [np.array([48, 40, 32]), blk, skip, blk, skip, None]
+
+
+# ---- F18: DropPath draws and gradient sampling -------------------------------------------------------------------
+GRAD_SAMPLES = 384
+
+
+def drop_path_noise(seed, rates, batch):
+    """Uniform [0,1) draws of the DropPath calls of one forward, call order (two per block with rate > 0: attention branch, MLP
+    branch), caller sample order.  In every row one sample is forced below the rate (dropped) and one above it (kept), so
+    that zeros and 1/keep_prob scales both occur whatever the seed."""
+    rs = np.random.RandomState(seed)
+    rows = []
+    for j, r in enumerate(rates):
+        for h in range(2):
+            u = rs.uniform(0.0, 1.0, size=batch).astype(np.float32)
+            u[(2 * j + h) % batch] = np.float32(0.5 * r)
+            u[(2 * j + h + 3) % batch] = np.float32(0.5 * (1.0 + r))
+            rows.append(u)
+    return rows
+
+
+def grad_sample_index(name, numel):
+    """Deterministic element positions at which a parameter gradient is sampled into the full-size fixtures."""
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)
+    n = min(GRAD_SAMPLES, numel)
+    return np.sort(rs.choice(numel, size=n, replace=False)).astype(np.int64) if numel > n else np.arange(numel, dtype=np.int64)

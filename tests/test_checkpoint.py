@@ -96,3 +96,38 @@ def test_subnet_inherits_prefix_slices_of_a_supernet_checkpoint(tmp_path):
     import numpy as np
     g = np.load(os.path.join(HERE, "golden", "f5_subnet.npz"))                   # the reference's own sliced state (F5)
     assert recipe.checksum(sub.state_dict()) == int(g["cand1.crc"])
+
+
+def test_flat_adamw_ema_survives_resume(tmp_path):
+    """a FlatAdamW EMA is written as 'model_ema' and must come back through resume (reference
+    utils._load_checkpoint_for_ema), not restart from the raw weights."""
+    torch.manual_seed(5)
+    m = micro()
+    opt = FlatAdamW(m, engine.param_groups_weight_decay(m, 0.05), lr=1e-3, ema_decay=0.99)
+    opt._bind()
+    with torch.no_grad():
+        opt._flat_state["ema"].add_(0.25)                          # an EMA that differs from the weights
+    ema_sd = opt.ema_state_dict()
+    path = checkpoint.save_checkpoint(str(tmp_path), m, opt, None, epoch=3, model_ema=ema_sd)
+    torch.manual_seed(6)
+    m2 = micro()
+    opt2 = FlatAdamW(m2, engine.param_groups_weight_decay(m2, 0.05), lr=1e-3, ema_decay=0.99)
+    assert checkpoint.resume(path, m2, opt2, None) == 4
+    assert not torch.equal(opt2._flat_state["ema"], m2._arena["flat"])      # not restarted from the raw weights
+    back = opt2.ema_state_dict()
+    assert all(torch.equal(back[k], ema_sd[k]) for k in ema_sd)
+    bad = dict(ema_sd)
+    del bad["cls_head.weight"]
+    with pytest.raises(KeyError):
+        opt2.load_ema_state_dict(bad)
+
+
+def test_finetune_loader_reads_reference_layout_with_namespace_args(tmp_path):
+    """reference checkpoints store args as argparse.Namespace; torch >= 2.6 defaults to weights_only=True."""
+    import argparse
+    from vitres.network_utils.finetune_state_dict import load_interpolated_state_dict
+    m = micro(False)
+    path = checkpoint.save_checkpoint(str(tmp_path), m, torch.optim.SGD(m.parameters(), lr=0.1), None, epoch=0,
+                                      args=argparse.Namespace(lr=1e-3, model="x"))
+    sd = load_interpolated_state_dict(m.state_dict(), path)
+    assert recipe.checksum(sd) == recipe.checksum(m.state_dict())

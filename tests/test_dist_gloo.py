@@ -93,8 +93,16 @@ def _worker(rank, world, port, out_dir):
     engine.train_step(model, crit, opt, x, t, pt, "seq", epoch=31, train_iter=0, arch_sample="multi", grad_sync=sync)
     g_sync = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
     p1 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
-    torch.save({"p0": p0, "p1": p1, "g_local": g_local, "g_sync": g_sync, "keeps": keeps, "g_split": g_split, "g_split3": g_split3},
-               os.path.join(out_dir, "r%d.pt" % rank))
+    # the reference signature always passes a NativeScaler (engine.py:175-177): with several ranks the exchange must still happen
+    class Scaler:                                    # timm.utils.NativeScaler's shape: a torch GradScaler under `_scaler`
+        def __init__(self):
+            self._scaler = torch.amp.GradScaler("cpu", enabled=False)
+    torch.random.set_rng_state(rng)
+    engine.train_step(model, crit, opt, x, t, pt, "seq", epoch=31, train_iter=0, arch_sample="multi", grad_sync=sync,
+                      loss_scaler=Scaler())
+    p2 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    torch.save({"p0": p0, "p1": p1, "p2": p2, "g_local": g_local, "g_sync": g_sync, "keeps": keeps, "g_split": g_split,
+                "g_split3": g_split3}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -115,6 +123,43 @@ def test_two_rank_gradient_exchange(tmp_path):
     assert torch.equal(r0["g_split"], r1["g_split"])
     assert float((r0["g_split"] - r0["g_sync"]).abs().max() / r0["g_sync"].abs().max()) < 1e-6
     assert torch.equal(r0["g_split3"], r1["g_split3"]) and torch.equal(r0["g_split3"], r0["g_split"])
+    assert torch.equal(r0["p2"], r1["p2"]) and not torch.equal(r0["p2"], r0["p1"])      # loss_scaler + grad_sync: replicas stay equal
+
+
+def _buffer_worker(rank, world, port, out_dir):
+    for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "vit-search_amd"), HERE, os.path.join(HERE, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import recipe
+    import vitres
+    from vitres import engine
+    torch.manual_seed(7 + rank)
+    model = vitres.create_model("flexible_vit_sr_patch14_224_patch_output", img_size=recipe.MICRO_IMG,
+                                num_classes=recipe.MICRO_CLASSES, network_def=recipe.MICRO_DEFS[4])
+    sync = engine.GradSync(model)
+    sync.broadcast_parameters()
+    with torch.no_grad():
+        for b in model.buffers():                                  # ranks drift apart (each normalises its own batch) ...
+            if b.is_floating_point():
+                b.add_(float(rank + 1))
+            else:
+                b.add_(rank + 3)
+    before = [b.clone() for b in model.buffers()]
+    sync.broadcast_buffers()                                       # ... until the next forward's DDP buffer broadcast (X4)
+    torch.save({"before": before, "after": [b.clone() for b in model.buffers()]}, os.path.join(out_dir, "b%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_buffer_broadcast_per_forward(tmp_path):
+    """DDP broadcast_buffers=True (main.py:367): rank 0's BatchNorm running statistics replace the other ranks'."""
+    mp.spawn(_buffer_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "b%d.pt" % r)) for r in range(2))
+    assert len(r0["after"]) == 9                                   # 3 x (running_mean, running_var, num_batches_tracked)
+    for a0, a1, b0, b1 in zip(r0["after"], r1["after"], r0["before"], r1["before"]):
+        assert torch.equal(a0, b0) and torch.equal(a1, b0) and not torch.equal(b1, b0)
 
 
 def _search_worker(rank, world, port, out_dir):

@@ -1,0 +1,199 @@
+"""Full-size parity of the HIP path (through the C ABI) against fixture F18 -- the reference itself run with drop_path > 0 on
+injected uniform draws: logits, loss, bit-exact masks and EVERY parameter gradient (norm + 384 sampled elements per tensor) for
+the sr_tiny supernet (C3), the ViT-Res-Tiny reference net (C1 / C2) and the sr_small supernet (C4); micro supernets with all
+gradient tensors in full; and the bf16 fast path against the fp32 HIP path at BASELINE's batch sizes (C2 / C3 / C4)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import recipe
+import vitres
+import vitres_oracle as O
+from test_oracle_golden import check_grad_samples
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-6))
+
+
+def make(nd, space, dp, epa=2, img=224, classes=1000, cfg=None):
+    from vitres import supernet_config
+    kw = {}
+    if space or cfg is not None:
+        kw = dict(num_channels_to_keep=cfg if cfg is not None else getattr(supernet_config, space).num_channels_to_keep,
+                  example_per_arch=epa, num_warmup_epochs=30)
+    name = "flexible_vit_sr_patch14_224_patch_output" + ("_supernet" if kw else "")
+    return vitres.create_model(name, img_size=img, num_classes=classes, network_def=nd, drop_path_rate=dp, **kw)
+
+
+@pytest.mark.parametrize("et", [0, 4])
+@pytest.mark.parametrize("fused_loss", [False, True])
+def test_micro_drop_path_fp32_vs_reference(et, fused_loss):
+    """a16: DropPath at model level (rate 0.2, dropped samples included) under the arch-grouped row order, autograd path and the
+    graphed step's loss_and_grad path."""
+    g = np.load(os.path.join(G, "f18_micro_t%d_multi_dp.npz" % et))
+    prod = make(recipe.MICRO_DEFS[et], None, 0.2, img=recipe.MICRO_IMG, classes=recipe.MICRO_CLASSES, cfg=recipe.micro_keep_config())
+    sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in prod.state_dict().items()], 100 + et)
+    prod.load_state_dict(sd)
+    assert recipe.checksum(sd) == int(g["state_crc"])
+    prod = prod.to(DEV).set_compute_dtype(torch.float32)
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1))
+    prod.train()
+    prod.set_epoch(31)
+    prod.load_state_dict(sd)
+    torch.manual_seed(555 + 31)
+    plan = prod.sample_plan(8)
+    plan.dp_noise = torch.from_numpy(g["noise"])
+    if fused_loss:
+        loss = prod.loss_and_grad(x, t, pt, "seq", plan=plan)
+    else:
+        cls, pat = prod(x, patch_output_type="seq", plan=plan)
+        assert rel(cls, g["cls"]) < 1e-4 and rel(pat, g["pat"]) < 1e-4, (rel(cls, g["cls"]), rel(pat, g["pat"]))
+        loss = O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)
+        loss.backward()
+    assert np.array_equal(torch.stack(prod.last_keeps).numpy(), g["keeps"])
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    for n, p in prod.named_parameters():
+        assert rel(p.grad, g["grad." + n]) < 5e-4, (n, rel(p.grad, g["grad." + n]))
+
+
+CASES = {   # name: (network_def, search space, drop_path, batch, weight seed, input seed, parameters)
+    "sr_tiny_c3": (recipe.SR_TINY_DEF, "sr_tiny", 0.2, 8, 4343, 12, 69673168),
+    "ref_tiny_c2": (recipe.REF_TINY_DEF, None, 0.2, 2, 4242, 11, 42781736),
+    "sr_small_c4": (recipe.SR_SMALL_DEF, "sr_small", 0.3, 8, 4444, 13, 144108208),
+}
+
+
+def _load_case(name):
+    nd, space, dp, B, wseed, iseed, nparam = CASES[name]
+    g = np.load(os.path.join(G, "f18_%s.npz" % name))
+    prod = make(nd, space, dp)
+    shapes = [(k, tuple(v.shape)) for k, v in prod.state_dict().items()]
+    assert [k for k, _ in shapes] == list(g["keys"])
+    sd = recipe.fill_state_dict(shapes, wseed)
+    assert recipe.checksum(sd) == int(g["state_crc"])
+    prod.load_state_dict(sd)
+    assert sum(p.numel() for p in prod.parameters()) == int(g["n_params"]) == nparam
+    return prod, sd, g
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_full_size_forward_backward_fp32_vs_reference(name):
+    """Full-size nets, fp32 parity mode: logits <= 1e-3 (north_star gate), loss, bit-exact masks, and every parameter gradient
+    of the assembled backward (128-wide tiles, ring-buffered K loops, split weight gradients, D = 32 / 48 / 64 attention) against
+    the reference's, with DropPath active on injected draws."""
+    nd, space, dp, B, wseed, iseed, _ = CASES[name]
+    prod, sd, g = _load_case(name)
+    prod = prod.to(DEV).set_compute_dtype(torch.float32)
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(iseed, B, 224, 1000, 16))
+    prod.train()
+    if space:
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+    torch.manual_seed(77)
+    plan = prod.sample_plan(B)
+    assert plan.n_dp == g["noise"].shape[0]
+    plan.dp_noise = torch.from_numpy(g["noise"])
+    cls, pat = prod(x, patch_output_type="seq", plan=plan)
+    if space:
+        assert np.array_equal(torch.stack(prod.last_keeps).numpy(), g["keeps"])
+    assert rel(cls, g["cls"]) < 1e-3, rel(cls, g["cls"])
+    assert rel(pat[:, :, :8], g["pat_head8"]) < 1e-3
+    loss = O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
+    loss.backward()
+    worst = check_grad_samples([(n, p.grad) for n, p in prod.named_parameters()], g, 5e-4)
+    print("%s: logits rel %.2e, worst gradient rel %.2e" % (name, rel(cls, g["cls"]), worst))
+    if not space:
+        bsd = prod.state_dict()
+        for bn in ("conv1", "conv2", "conv3"):
+            assert rel(bsd["patch_embed.%s.bn.running_mean" % bn], g["bn.%s.running_mean" % bn]) < 1e-4
+            assert rel(bsd["patch_embed.%s.bn.running_var" % bn], g["bn.%s.running_var" % bn]) < 1e-4
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_full_size_bf16_gradients_vs_reference(name):
+    """The bf16 fast path on the same fixtures: how far the gradients the optimizer sees drift from the fp32 reference
+    (per-tensor gradient norm <= 5e-2; sampled elements <= 1.5e-1 of the tensor's rms -- documented tolerance;
+    measured 3e-3 / 2e-2 on the sr_tiny supernet, 2.5e-2 / 1e-1 on the conv stem's BatchNorm at batch 2)."""
+    nd, space, dp, B, wseed, iseed, _ = CASES[name]
+    prod, sd, g = _load_case(name)
+    prod = prod.to(DEV).set_compute_dtype(torch.bfloat16)
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(iseed, B, 224, 1000, 16))
+    prod.train()
+    if space:
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+    torch.manual_seed(77)
+    plan = prod.sample_plan(B)
+    plan.dp_noise = torch.from_numpy(g["noise"])
+    loss = prod.loss_and_grad(x, t, pt, "seq", plan=plan)
+    assert abs(loss.item() - float(g["loss"])) < 1e-2 * float(g["loss"])
+    worst_n, worst_s = 0.0, 0.0
+    for n, p in prod.named_parameters():
+        gr = p.grad.detach().reshape(-1).cpu()
+        gn = float(g["gn." + n])
+        idx = torch.from_numpy(recipe.grad_sample_index(n, gr.numel()))
+        ref = np.asarray(g["gs." + n], dtype=np.float64)
+        rms = max(gn / np.sqrt(gr.numel()), 1e-12)
+        worst_n = max(worst_n, abs(float(gr.double().norm()) - gn) / max(gn, 1e-12))
+        worst_s = max(worst_s, float(np.abs(gr[idx].double().numpy() - ref).max() / max(rms, np.abs(ref).max())))
+    print("%s bf16: worst norm drift %.3e, worst sampled drift %.3e" % (name, worst_n, worst_s))
+    assert worst_n < 5e-2 and worst_s < 1.5e-1, (worst_n, worst_s)
+
+
+BASELINE_CASES = {   # BASELINE.json configs[1..3] at their batch sizes
+    "C2_ref_tiny_b128": (recipe.REF_TINY_DEF, None, 0.2, 128, 64),
+    "C3_sr_tiny_b128": (recipe.SR_TINY_DEF, "sr_tiny", 0.2, 128, 64),
+    "C4_sr_small_b64": (recipe.SR_SMALL_DEF, "sr_small", 0.3, 64, 32),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BASELINE_CASES))
+def test_bf16_vs_fp32_hip_at_baseline_batch(name):
+    """bf16 fast path against the fp32 HIP path (itself <= 1e-3 from the reference above) on the SAME weights, inputs, masks and
+    DropPath draws at BASELINE's batch sizes: logits <= 3e-2, loss <= 1e-2 (relative); gradient norms reported."""
+    nd, space, dp, B, epa = BASELINE_CASES[name]
+    prod = make(nd, space, dp, epa=epa)
+    sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in prod.state_dict().items()], 5150)
+    prod.load_state_dict(sd)
+    prod = prod.to(DEV)
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(21, B, 224, 1000, 16))
+    prod.train()
+    if space:
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+    rates = [b.drop_path.drop_prob for b in prod.blocks if hasattr(b, "drop_path") and not isinstance(b.drop_path, torch.nn.Identity)]
+    noise = torch.from_numpy(np.stack(recipe.drop_path_noise(99, rates, B)))
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        prod.set_compute_dtype(dt)
+        prod._arena = None
+        prod.load_state_dict(sd)
+        prod.zero_grad(set_to_none=True)
+        torch.manual_seed(4)
+        plan = prod.sample_plan(B)
+        plan.dp_noise = noise
+        cls, pat = prod(x, patch_output_type="seq", plan=plan)
+        loss = O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)
+        loss.backward()
+        res[dt] = (cls.detach().float().cpu(), pat.detach().float().cpu(), loss.item(),
+                   torch.stack(prod.last_keeps).clone() if space else None,
+                   {n: float(p.grad.double().norm()) for n, p in prod.named_parameters()})
+    f, b = res[torch.float32], res[torch.bfloat16]
+    if space:
+        assert torch.equal(f[3], b[3])
+    drift = {n: abs(b[4][n] - f[4][n]) / max(f[4][n], 1e-12) for n in f[4]}
+    worst = max(drift, key=drift.get)
+    print("%s: logits %.3e / %.3e, loss %.3e, worst gradient-norm drift %.3e (%s)" % (
+        name, rel(b[0], f[0]), rel(b[1], f[1]), abs(b[2] - f[2]) / f[2], drift[worst], worst))
+    assert rel(b[0], f[0]) < 3e-2 and rel(b[1], f[1]) < 3e-2
+    assert abs(b[2] - f[2]) < 1e-2 * f[2]
+    assert drift[worst] < 1e-1

@@ -414,3 +414,40 @@ def test_emulated_loss_and_grad_equals_autograd_path(monkeypatch, et, mode, pot)
         assert p.grad is not None and rel(p.grad, want[n]) < 1e-5, n
     with pytest.raises(RuntimeError):
         prod.loss_and_grad(x, t, pt, pot)                      # gradients not cleared
+
+
+@pytest.mark.parametrize("et", [0, 4])
+def test_emulated_drop_path_wiring_matches_reference(monkeypatch, et):
+    """DropPath (nets/drop.py:11-26) at model level: the per-sample scale vectors are drawn in the caller's sample order while the
+    rows run arch-grouped (plan.order) -- with injected draws (fixture F18, incl. dropped samples) logits, loss and EVERY
+    gradient must equal the reference's."""
+    emu_kernels.install(monkeypatch)
+    g = np.load(os.path.join(G, "f18_micro_t%d_multi_dp.npz" % et))
+    nd = recipe.MICRO_DEFS[et]
+    kw = dict(num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30)
+    prod = vitres.create_model("flexible_vit_sr_patch14_224_patch_output_supernet", img_size=recipe.MICRO_IMG,
+                               num_classes=recipe.MICRO_CLASSES, network_def=nd, drop_path_rate=0.2, **kw)
+    sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in prod.state_dict().items()], 100 + et)
+    prod.load_state_dict(sd)
+    prod.set_compute_dtype(torch.float32)
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    prod.train()
+    prod.set_epoch(31)
+    prod.load_state_dict(sd)
+    for use_fused in (False, True):
+        prod.zero_grad(set_to_none=True)
+        torch.manual_seed(555 + 31)
+        plan = prod.sample_plan(8)
+        assert plan.order is not None and plan.n_dp == g["noise"].shape[0]
+        plan.dp_noise = torch.from_numpy(g["noise"])
+        if use_fused:
+            loss = prod.loss_and_grad(x, t, pt, "seq", plan=plan)
+        else:
+            cls, pat = prod(x, patch_output_type="seq", plan=plan)
+            assert np.array_equal(torch.stack(prod.last_keeps).numpy(), g["keeps"])
+            assert rel(cls.detach(), torch.from_numpy(g["cls"])) < 1e-4 and rel(pat.detach(), torch.from_numpy(g["pat"])) < 1e-4
+            loss = O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)
+            loss.backward()
+        assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+        for n, p in prod.named_parameters():
+            assert rel(p.grad, torch.from_numpy(g["grad." + n])) < 5e-4, (n, use_fused)

@@ -394,3 +394,83 @@ def test_f14_two_token_variant(et, mode):
         ec, ed = m(x)
     close(ec, g["eval.cls"])
     close(ed, g["eval.dst"])
+
+
+# ---- F18: DropPath with injected draws (nets/drop.py:11-26), full-size gradients, config C4 ---------------------------
+def oracle_noise(m, noise):
+    """The oracle draws one noise row per branch of EVERY block (rate 0 included): pad the fixture's rows (blocks with rate > 0
+    only) accordingly."""
+    rows, out = list(noise), []
+    for blk in m.blocks:
+        if isinstance(blk, O.OracleBlock):
+            for _ in range(2):
+                out.append(torch.from_numpy(rows.pop(0)) if blk.dp > 0 else None)
+        elif isinstance(blk, O._Bypass):
+            out += [None, None]
+    assert not rows
+    return out
+
+
+def check_grad_samples(named_grads, g, tol):
+    worst = 0.0
+    for n, gr in named_grads:
+        gr = gr.detach().reshape(-1).cpu()
+        idx = torch.from_numpy(recipe.grad_sample_index(n, gr.numel()))
+        ref = np.asarray(g["gs." + n], dtype=np.float64)
+        scale = max(float(g["gn." + n]) / np.sqrt(gr.numel()), np.abs(ref).max(), 1e-12)   # rms of the whole tensor
+        err = np.abs(gr[idx].double().numpy() - ref).max() / scale
+        nerr = abs(float(gr.double().norm()) - float(g["gn." + n])) / max(float(g["gn." + n]), 1e-12)
+        worst = max(worst, err, nerr)
+        assert err < tol and nerr < tol, (n, err, nerr)
+    return worst
+
+
+@pytest.mark.parametrize("et", [0, 4])
+def test_f18_micro_drop_path(et):
+    g = load("f18_micro_t%d_multi_dp" % et)
+    m = build(recipe.MICRO_DEFS[et], "multi", drop_path_rate=0.2)
+    sd, _ = load_recipe(m, 100 + et)
+    assert recipe.checksum(sd) == int(g["state_crc"])
+    rates = [b.dp for b in m.blocks if isinstance(b, O.OracleBlock) and b.dp > 0]
+    assert np.allclose(rates, g["rates"])
+    noise = recipe.drop_path_noise(1800 + et, rates, 8)
+    assert np.array_equal(np.stack(noise), g["noise"])
+    assert (np.floor(1 - np.repeat(g["rates"], 2)[:, None] + g["noise"]) == 0).any()      # dropped samples do occur
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    m.train()
+    m.set_epoch(31)
+    m.load_state_dict(sd)
+    torch.manual_seed(555 + 31)
+    (cls, pat), keeps = m(x, dp_noise=oracle_noise(m, noise), patch_output_type="seq", return_keeps=True)
+    assert np.array_equal(torch.stack(keeps).numpy(), g["keeps"])
+    close(cls.detach(), g["cls"]); close(pat.detach(), g["pat"])
+    loss = O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    for n, p in m.named_parameters():
+        close(p.grad, g["grad." + n], 1e-4)
+
+
+def test_f18_full_size_sr_small_c4_gradients():
+    """C4 geometry on the oracle: sr_small supernet, B = 8, drop_path 0.3, explicit draws: logits, loss, every gradient (sampled)."""
+    from vitres import supernet_config
+    g = load("f18_sr_small_c4")
+    m = build(recipe.SR_SMALL_DEF, "multi", img=224, classes=1000, cfg=supernet_config.sr_small.num_channels_to_keep,
+              drop_path_rate=0.3)
+    sd, shapes = load_recipe(m, 4444)
+    assert recipe.checksum(sd) == int(g["state_crc"]) and [k for k, _ in shapes] == list(g["keys"])
+    rates = [b.dp for b in m.blocks if isinstance(b, O.OracleBlock) and b.dp > 0]
+    noise = recipe.drop_path_noise(1900 + 13, rates, 8)
+    assert np.array_equal(np.stack(noise), g["noise"])
+    x, t, pt, _ = recipe.inputs(13, 8, 224, 1000, 16)
+    m.train()
+    m.set_epoch(31)
+    m.load_state_dict(sd)
+    torch.manual_seed(77)
+    (cls, pat), keeps = m(x, dp_noise=oracle_noise(m, noise), patch_output_type="seq", return_keeps=True)
+    assert np.array_equal(torch.stack(keeps).numpy(), g["keeps"])
+    close(cls.detach(), g["cls"], 1e-4); close(pat.detach()[:, :, :8], g["pat_head8"], 1e-4)
+    loss = O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    check_grad_samples([(n, p.grad) for n, p in m.named_parameters()], g, 2e-4)

@@ -50,7 +50,8 @@ def save_checkpoint(output_dir, model, optimizer, lr_scheduler, epoch, args=None
 def resume(path_or_dict, model, optimizer=None, lr_scheduler=None, eval_mode=False, load_ema=None):
     """--resume (main.py:401-417): loads 'model'; unless eval_mode, and when the checkpoint carries all of 'optimizer',
     'lr_scheduler' and 'epoch', restores them and returns the epoch to start from (saved epoch + 1; else None); load_ema(state)
-    receives 'model_ema' on that path.  With eval_mode, 'model_ema' (when present) replaces the model's weights."""
+    receives 'model_ema' on that path (default: a FlatAdamW built with ema_decay takes it through
+    load_ema_state_dict, the counterpart of utils._load_checkpoint_for_ema).  With eval_mode, 'model_ema' (when present) replaces the model's weights."""
     ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location='cpu', weights_only=False)
     model.load_state_dict(ck['model'])
     start = None
@@ -60,8 +61,11 @@ def resume(path_or_dict, model, optimizer=None, lr_scheduler=None, eval_mode=Fal
         if lr_scheduler is not None:
             lr_scheduler.load_state_dict(ck['lr_scheduler'])
         start = ck['epoch'] + 1
-        if load_ema is not None and 'model_ema' in ck:
-            load_ema(ck['model_ema'])
+        if 'model_ema' in ck:
+            if load_ema is not None:
+                load_ema(ck['model_ema'])
+            elif getattr(optimizer, 'ema_decay', None) is not None and hasattr(optimizer, 'load_ema_state_dict'):
+                optimizer.load_ema_state_dict(ck['model_ema'])     # FlatAdamW keeps the EMA: continue it, do not restart it
     if eval_mode and 'model_ema' in ck:
         model.load_state_dict(ck['model_ema'])
     return start

@@ -72,6 +72,29 @@ class GradSync:
                 dist.broadcast(p.data, src=0)
         for b in self.model.buffers():
             dist.broadcast(b, src=0)
+        if hasattr(self.model, "invalidate_shadow"):
+            self.model.invalidate_shadow()          # ranks > 0 just received new fp32 weights: re-cast a bf16 shadow kept by FlatAdamW
+
+    def broadcast_buffers(self):
+        """DDP's `broadcast_buffers=True` default (reference main.py:367): before every forward rank 0's buffers --
+        here the BatchNorm running statistics of the convolutional patch embedding, the only buffers of the model -- overwrite
+        the other ranks'.  A no-op for buffer-free models (type-0 patch embedding) and on one rank."""
+        if self.world == 1:
+            return
+        bufs = [b for b in self.model.buffers() if b.numel()]
+        if not bufs:
+            return
+        fl = [b for b in bufs if b.is_floating_point()]
+        if fl:
+            flat = torch.cat([b.reshape(-1).float() for b in fl])
+            dist.broadcast(flat, src=0)
+            off = 0
+            for b in fl:
+                b.copy_(flat[off:off + b.numel()].view(b.shape))
+                off += b.numel()
+        for b in bufs:
+            if not b.is_floating_point():
+                dist.broadcast(b, src=0)
 
     def all_reduce_range(self, lo, hi):
         """Asynchronous all-reduce (sum) of elements [lo, hi) of the flat gradient arena; returns the work handle (None
@@ -105,7 +128,8 @@ class GradSync:
         for p in self.model.parameters():                         # autograd cloned the views: per-tensor fallback
             if p.grad is not None:
                 dist.all_reduce(p.grad)
-                p.grad.mul_(1.0 / self.world)
+                if average:
+                    p.grad.mul_(1.0 / self.world)
 
 
 class KnowledgeDistillationLoss(torch.nn.Module):
@@ -161,8 +185,22 @@ def train_step(model, criterion, optimizer, samples, targets, patch_targets=None
     if rng is not None:
         torch.random.set_rng_state(rng)                           # engine.py:164-165
     optimizer.zero_grad(set_to_none=True)
-    if loss_scaler is not None:
+    if loss_scaler is not None and (grad_sync is None or grad_sync.world == 1):
         loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=False)
+    elif loss_scaler is not None:
+        # timm NativeScaler does scale -> backward -> unscale -> clip -> step in one call; with a gradient exchange the
+        # all-reduce has to sit between backward and unscale (DDP does it inside backward, main.py:367), so the call is unrolled
+        scaler = getattr(loss_scaler, '_scaler', None)
+        if scaler is None:
+            raise RuntimeError('loss_scaler with grad_sync on several ranks needs a NativeScaler-like object exposing `_scaler` '
+                               '(torch.cuda.amp.GradScaler); bf16 / fp32 training needs no scaler: pass loss_scaler=None')
+        scaler.scale(loss).backward()
+        grad_sync.all_reduce_grads(average=average_grads)
+        scaler.unscale_(optimizer)
+        if max_norm:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        scaler.step(optimizer)
+        scaler.update()
     else:
         loss.backward()
         if grad_sync is not None:
@@ -358,6 +396,8 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
         if teacher_model is not None:
             with torch.no_grad():
                 teacher_output = teacher_model(samples)
+        if grad_sync is not None:
+            grad_sync.broadcast_buffers()                         # DDP broadcast_buffers=True (main.py:367): per forward
         loss = train_step(model, criterion, optimizer, samples, targets, patch_targets, patch_output_type, epoch,
                           train_iter, arch_sample, grad_sync, loss_scaler, max_norm, teacher_output=teacher_output,
                           kd_criterion=kd_criterion, alpha=alpha)
@@ -376,6 +416,9 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
             print_out('Epoch: [{}] [{}] loss: {:.4f} time: {:.1f}s'.format(epoch, train_iter, meters['loss'].global_avg,
                                                                           time.time() - t0))
     for v in (torch.stack(pending).tolist() if pending else []):
+        if not math.isfinite(v):
+            print_out('Loss is {}, stopping training'.format(v))
+            sys.exit(1)
         meters['loss'].update(v)
     for m in meters.values():
         m.synchronize_between_processes()

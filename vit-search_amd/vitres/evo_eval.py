@@ -73,7 +73,8 @@ def score_candidate(model, sub_network_def, batches):
         if b not in plans:
             plans[b] = plan_for_subnet(model, sub_network_def, b)
         out = model(images, plan=plans[b])
-        out = out[0] if isinstance(out, tuple) else out
+        # two-token (distillation) models are ranked by the distillation head's accuracy (evo_search.py:280-284: dst_acc1)
+        out = (out[1] if getattr(model, "num_tokens", 1) == 2 else out[0]) if isinstance(out, tuple) else out
         hits = (out.argmax(dim=1) == target).sum()
         correct = hits if correct is None else correct + hits
         count += b

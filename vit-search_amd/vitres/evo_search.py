@@ -43,7 +43,7 @@ def _is_main():
 
 def search(model, batches, network_def, num_channels_to_keep, constraint_value, search_iter=20, init_popu_size=500,
            parent_size=75, mutate_size=75, mutate_prob=0.3, input_size=224, output_dir=None, seed=None, score_fn=None,
-           log=None):
+           log=None, distill=None):
     """Run the search; returns the best Individual of every iteration (the reference's `_best_result_history`).
 
     model: a vitres supernet (eval()); batches: list of (images, labels) on its device, the validation subset every candidate
@@ -53,7 +53,9 @@ def search(model, batches, network_def, num_channels_to_keep, constraint_value, 
     if seed is not None:
         torch.manual_seed(seed)
         np.random.seed(seed)
-    compute_mac = ComputationEstimator(distill=False, input_resolution=input_size, patch_size=14)
+    if distill is None:                                  # evo_search.py:201: distillation-token models count its MACs too
+        distill = getattr(model, "num_tokens", 1) == 2
+    compute_mac = ComputationEstimator(distill=bool(distill), input_resolution=input_size, patch_size=14)
     evolver = PopulationEvolver(largest_network_def=network_def, num_channels_to_keep=num_channels_to_keep,
                                 constraint=constraint_value, compute_resource=compute_mac)
     if score_fn is None:

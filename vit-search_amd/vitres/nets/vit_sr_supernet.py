@@ -95,11 +95,12 @@ class SpatialReductionPatchEmbedding(nn.Module):
 
 class _Plan:
     """Host-side description of one forward: which keep vector / drop-path scale each layer uses."""
-    __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch", "n_dp", "order")
+    __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch", "n_dp", "order", "dp_noise")
 
     def __init__(self):
         self.rows, self.layers, self.keep_dev, self.head, self.scales, self.batch, self.n_dp = [], [], None, None, None, 0, 0
         self.order = None
+        self.dp_noise = None     # test hook: the uniform draws of drop_path (nets/drop.py:23), [n_dp, B] in the CALLER's sample order
 
     def add(self, keep):
         if keep is None:
@@ -455,7 +456,14 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                         vals += [1.0 - blk.drop_path.drop_prob] * 2
                 kp = torch.tensor(vals, dtype=torch.float32).unsqueeze(1).to(device)
                 self._dp_keep_prob = kp
-            plan.scales = torch.floor(kp + torch.rand(plan.n_dp, B, device=device)) / kp
+            if plan.dp_noise is not None:                  # injected draws (caller order) -> the internal, arch-grouped row order
+                noise = torch.as_tensor(plan.dp_noise, dtype=torch.float32).reshape(plan.n_dp, B)
+                if plan.order is not None:
+                    noise = noise[:, torch.as_tensor(plan.order)]
+                noise = noise.to(device)
+            else:
+                noise = torch.rand(plan.n_dp, B, device=device)
+            plan.scales = torch.floor(kp + noise) / kp
         return plan
 
     # ---- forward -----------------------------------------------------------------------------------

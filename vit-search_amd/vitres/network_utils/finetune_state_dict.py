@@ -39,6 +39,6 @@ def state_dict_interpolate_pos_embed(model_state_dict, state_dict):
 
 def load_interpolated_state_dict(model_state_dict, ckpt_path):
     """Reference checkpoint layout (main.py:506-512): {'model': ..., 'model_ema': ...}; the EMA weights win when present."""
-    ckpt = torch.load(ckpt_path, map_location='cpu')
+    ckpt = torch.load(ckpt_path, map_location='cpu', weights_only=False)      # 'args' is an argparse.Namespace
     sd = ckpt['model_ema'] if 'model_ema' in ckpt else ckpt['model']
     return state_dict_interpolate_pos_embed(model_state_dict, sd)

@@ -230,3 +230,28 @@ class FlatAdamW(torch.optim.Optimizer):
         for k, v in self.model.state_dict(keep_vars=True).items():
             out[k] = byid[id(v)].clone() if id(v) in byid else v.detach().clone()
         return out
+
+    def load_ema_state_dict(self, sd):
+        """Inverse of ema_state_dict(): scatter a model-keyed state dict (the 'model_ema' entry of a checkpoint, reference
+        utils._load_checkpoint_for_ema / main.py:413-414) into the arena-shaped EMA.  Buffers in `sd` are ignored (the EMA tracks
+        parameters only; buffers come from the live model)."""
+        a = self._bind()
+        if self._flat_state["ema"] is None:
+            raise RuntimeError("constructed without ema_decay")
+        ema = self._flat_state["ema"]
+        where = {id(p): (off, n) for p, (off, n) in zip(a["params"], a["offsets"])}
+        missing = []
+        with torch.no_grad():
+            for k, v in self.model.state_dict(keep_vars=True).items():
+                if id(v) not in where:
+                    continue
+                if k not in sd:
+                    missing.append(k)
+                    continue
+                off, n = where[id(v)]
+                if tuple(sd[k].shape) != tuple(v.shape):
+                    raise ValueError("model_ema[%s] has shape %s, expected %s" % (k, tuple(sd[k].shape), tuple(v.shape)))
+                ema[off:off + n].copy_(sd[k].reshape(-1).to(ema.device, torch.float32))
+        if missing:
+            raise KeyError("model_ema lacks parameters: %s" % ", ".join(missing[:5]))
+
