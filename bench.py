@@ -68,12 +68,6 @@ def synthetic_batch(batch, device, seed):
     return x.to(device), t.to(device), pt.to(device)
 
 
-def effective_macs(model, nd, keeps):
-    """MACs per image actually kept by the sampled sub-networks (masked work is never counted)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    return None
-
-
 def cpu_baseline(name, seconds_budget=25.0):
     """The CPU oracle (oracle/vitres_oracle.py, pinned to the reference by golden vectors) on the host cores:
     full training step (fwd + bwd + AdamW), same network, bounded sample."""
@@ -81,9 +75,9 @@ def cpu_baseline(name, seconds_budget=25.0):
     import vitres_oracle as O
     from vitres import supernet_config
     w = WORKLOADS[name]
-    cores = min(os.cpu_count() or 1, 32)       # more threads than this only adds fork/join overhead at batch 8
+    cores = min(os.cpu_count() or 1, 32)       # more threads than this only adds fork/join overhead at batch 16
     torch.set_num_threads(cores)
-    B = 8
+    B = 16                                     # CPU baseline at B = 16 (train)
     if w["space"]:
         sp = getattr(supernet_config, w["space"])
         m = O.OracleViTSR(sp.network_def, num_classes=1000, drop_path_rate=w["drop_path"], supernet=True,
@@ -99,7 +93,7 @@ def cpu_baseline(name, seconds_budget=25.0):
         O.train_step(m, opt, x, t, pt, 31, n + 1, arch_sample=("multi" if w["space"] else None))
         n += 1
         dt = time.time() - t0
-        if dt + dt / n > seconds_budget or n >= 8:
+        if dt + dt / n > seconds_budget or n >= 6:
             break
     return {"value": round(B * n / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "%d train steps (fwd+bwd+AdamW) of the %s CPU oracle, batch %d, fp32, torch %d threads"
@@ -126,6 +120,22 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` (the form the driver uses at N = 1): become the launcher -- one rank per GPU through
+        # torch.distributed.run, rendezvous on 127.0.0.1; rank 0 of the children prints the JSON line
+        import socket
+        import subprocess
+        if torch.cuda.device_count() < args.gpus and os.environ.get("VITRES_DIST_BACKEND", "nccl") == "nccl":
+            sys.exit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -140,7 +150,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
 
     from vitres import engine, kernels as K
     from vitres.losses import SoftTargetCrossEntropy
@@ -196,6 +206,9 @@ def main():
         opt.step()
         return loss
 
+    if graphed is not None and world > 1:
+        graphed.exposed = []                                     # (event after the last backward graph, event after the exchange)
+
     for i in range(args.warmup):
         step(i)
     if world > 1:
@@ -203,6 +216,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     losses = []
+    if graphed is not None and world > 1:
+        graphed.exposed = []
     for i in range(args.steps):
         losses.append(step(args.warmup + i))
     host_enqueue = time.perf_counter() - t0              # host time to issue the K steps (the GPU may still be running)
@@ -216,6 +231,17 @@ def main():
     elapsed = float(tmax.item())
     lossv = torch.stack(losses).tolist()
     assert all(v == v and abs(v) != float("inf") for v in lossv), "non-finite loss"
+    exchange = None
+    if world > 1:
+        n_arena = model._arena["flat"].numel()
+        exposed = None
+        if graphed is not None and getattr(graphed, "exposed", None):
+            exposed = round(sum(a.elapsed_time(b) for a, b in graphed.exposed) / len(graphed.exposed), 3)
+        exchange = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "allreduce_bytes_per_step": 4 * n_arena,
+                    "dtype": "f32", "ranges": (len(graphed.ranges) if graphed is not None and graphed.ranges else 1),
+                    "exposed_ms_per_step": exposed,
+                    "note": "exposed = GPU time between the end of the last backward graph and the end of the last all-reduce "
+                            "(rank 0, HIP events on the compute stream)"}
 
     if rank != 0:
         if world > 1:
@@ -294,7 +320,11 @@ def main():
                     "tflops_kept": round(v[1] / v[0] / 1e12, 2), "tflops_dense_equiv": round(v[4] / v[0] / 1e12, 2),
                     "algorithmic_GBps": round(v[2] / v[0] / 1e9, 1), "ms_per_step": round(v[0] / args.profile_steps * 1e3, 3)}
                     for k, v in byname.items()}})
-    cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.workload)      # rank 0 at N = 1 only
+    if world > 1:                                                   # timed on rank 0 at N = 1 only
+        cpu = {"value": None, "unit": "images/sec", "cores": None, "kind": "port",
+               "sample": "not timed at N > 1: the CPU oracle runs beside the N = 1 line only (same workload, see that line)"}
+    else:
+        cpu = None if args.no_cpu_baseline else cpu_baseline(args.workload)
     from vitres.network_utils.compute_flop_mac import train_flops_per_image
     dense_flops = train_flops_per_image(nd)
     img_s = B * world * args.steps / elapsed
@@ -308,7 +338,8 @@ def main():
                    "optimizer": "AdamW (vitres.optim.FlatAdamW: vr_adamw_flat)" if args.optimizer == "flat" else "AdamW(torch fused)", "hipgraph": graphed is not None, "host_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
                    "grad_exchange": ("all-reduce of the flat fp32 gradient arena in %d ranges, each overlapped with the next backward graph" % split
                                      if (graphed is not None and graphed.graph_b is not None) else
-                                     "1 all-reduce of the flat fp32 arena" if world > 1 else "none (1 rank)"), "final_loss": round(lossv[-1], 4)},
+                                     "1 all-reduce of the flat fp32 arena" if world > 1 else "none (1 rank)"),
+                   "exchange": exchange, "final_loss": round(lossv[-1], 4)},
         "roofline": roof, "cpu_baseline": cpu,
         "dense_equiv": {"train_gflop_per_image": round(dense_flops / 1e9, 2),
                         "tflops_per_gpu": round(dense_flops * img_s / world / 1e12, 1),

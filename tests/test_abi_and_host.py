@@ -101,3 +101,31 @@ def test_channel_drop_tables_and_rng_protocol():
             tag = "c%d.e%d." % (ci, e)
             assert np.array_equal(draws, g[tag + "draws"])
             assert list(cd.table.numpy()) == list(g[tag + "table"]) and cd.num_layer_config == int(g[tag + "nlc"])
+
+
+def test_cosine_scheduler_known_answers():
+    """main.py:388 create_scheduler (--sched cosine, --epochs 120, lr 5e-4, --warmup-lr 1e-6, --min-lr 1e-5, 5 warm-up epochs,
+    10 cool-down epochs): five closed-form points, the two parameter groups of add_weight_decay, checkpoint round trip."""
+    import argparse
+    import math
+    import torch
+    from vitres.scheduler import create_scheduler
+    w = [torch.zeros(2, requires_grad=True), torch.zeros(2, requires_grad=True)]
+    opt = torch.optim.AdamW([{"params": [w[0]], "weight_decay": 0.0}, {"params": [w[1]], "weight_decay": 0.05}], lr=5e-4)
+    args = argparse.Namespace(epochs=120, sched="cosine", min_lr=1e-5, warmup_lr=1e-6, warmup_epochs=5, cooldown_epochs=10,
+                              decay_rate=0.1)
+    sched, n_epochs = create_scheduler(args, opt)
+    assert n_epochs == 130
+    assert [g["lr"] for g in opt.param_groups] == [1e-6, 1e-6]                 # starts at the warm-up rate
+    want = {0: 1e-6, 3: 1e-6 + 3 * (5e-4 - 1e-6) / 5, 5: 1e-5 + 0.5 * 4.9e-4 * (1 + math.cos(math.pi * 5 / 120)),
+            60: 1e-5 + 0.5 * 4.9e-4, 119: 1e-5 + 0.5 * 4.9e-4 * (1 + math.cos(math.pi * 119 / 120)), 120: 1e-5, 129: 1e-5}
+    for e, v in want.items():
+        sched.step(e)
+        assert all(abs(g["lr"] - v) < 1e-12 for g in opt.param_groups), (e, opt.param_groups[0]["lr"], v)
+    sd = sched.state_dict()
+    assert "optimizer" not in sd
+    opt2 = torch.optim.AdamW([{"params": [w[0]]}, {"params": [w[1]]}], lr=1.0)
+    s2, _ = create_scheduler(argparse.Namespace(epochs=7), opt2)
+    s2.load_state_dict(sd)
+    s2.step(60)
+    assert abs(opt2.param_groups[1]["lr"] - want[60]) < 1e-12

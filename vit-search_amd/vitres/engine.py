@@ -360,11 +360,19 @@ class GraphedTrainStep:
             loss = self(samples, targets, patch_targets, **kw)
         finally:
             self._sync = None
+        ev = None
+        if getattr(self, "exposed", None) is not None and grad_sync.world > 1:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()                                           # the backward is complete here (on the compute stream)
         if self.more_graphs:
             self._works.append(grad_sync.all_reduce_range(*self.ranges[-1]))
             grad_sync.finish(self._works, average=average)
         else:
             grad_sync.all_reduce_grads(average=average)
+        if ev is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()                                          # work.wait() made the compute stream wait for the exchange
+            self.exposed.append((ev, ev1))
         self._works = ()
         return loss
 

@@ -138,39 +138,51 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     if PROFILE is None:
         _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
         return out
-    # algorithmic FLOPs of this launch = those of the kept (un-masked) sub-problems only (skipped work is never counted)
+    flops, alg_bytes = _gemm_work(a, out, M, N, K, a_trans, rows_in, keep_k, keep_n, k_period, n_period, out2=out2, resid=resid,
+                                  dact_u=dact_u, pos=pos, bias=bias, atomic=atomic)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
+    e1.record()
+    PROFILE.append((("bf16" if args.in_dtype == VR_BF16 else "f32", int(a_trans), int(b_trans),
+                     int(a_map is not None or b_map is not None)), flops, 2.0 * M * N * K, alg_bytes, e0, e1))
+    return out
+
+
+def _gemm_work(a, out, M, N, K, a_trans, rows_in, keep_k, keep_n, k_period, n_period, out2=None, resid=None, dact_u=None,
+               pos=None, bias=None, atomic=False):
+    """(kept FLOPs, algorithmic HBM bytes) of one vr_gemm launch, both from the KEPT (un-masked) widths of the samples it
+    touches -- skipped work is never counted, and neither are operand bytes the masks let the kernel skip.
+      forward / dgrad (C[M,N] = A[M,K] B[N,K]^T): sample b reads rows_in x kk[b] of A and writes rows_in x N of C (masked columns
+        are written as zeros: downstream kernels read whole rows); the weights are read once for the widest sample:
+        max(kk) x max(kn); epilogue side tensors (fp32 residual, GELU pre-activation, second output) are counted in full;
+      wgrad (C[M,N] += A[T,M]^T B[T,N], a_trans): sample b reads rows_in x (kr[b] + kc[b]) channels; C (fp32) is read-modified-
+        written once over its widest kept block."""
+    esz, osz = a.element_size(), out.element_size()
+
     def kept(keep, dim, period):
         if keep is None:
             return None
         k = keep.detach().to("cpu", torch.float64)
         return torch.clamp(k, max=period) * (dim // period) if period else torch.clamp(k, max=dim)
-    if a_trans:                                   # wgrad: keep_k bounds output rows (M), keep_n output columns (N)
+    if a_trans:                                   # wgrad: keep_k bounds output rows (M), keep_n output columns (N); K = tokens
         kr, kc = kept(keep_k, M, k_period), kept(keep_n, N, n_period)
         if kr is None and kc is None:
-            flops = 2.0 * M * N * K
-        else:
-            nb = len(kr if kr is not None else kc)
-            kr = kr if kr is not None else torch.full((nb,), float(M), dtype=torch.float64)
-            kc = kc if kc is not None else torch.full((nb,), float(N), dtype=torch.float64)
-            flops = float((2.0 * rows_in * kr * kc).sum())
-    else:
-        kk, kn = kept(keep_k, K, k_period), kept(keep_n, N, n_period)
-        if kk is None and kn is None:
-            flops = 2.0 * M * N * K
-        else:
-            nb = len(kk if kk is not None else kn)
-            kk = kk if kk is not None else torch.full((nb,), float(K), dtype=torch.float64)
-            kn = kn if kn is not None else torch.full((nb,), float(N), dtype=torch.float64)
-            flops = float((2.0 * rows_in * kk * kn).sum())
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
-    e1.record()
-    esz = a.element_size()
-    PROFILE.append((("bf16" if args.in_dtype == VR_BF16 else "f32", int(a_trans), int(b_trans),
-                     int(a_map is not None or b_map is not None)), flops, 2.0 * M * N * K,
-                    float((M * K + N * K) * esz + M * N * out.element_size()), e0, e1))
-    return out
+            return 2.0 * M * N * K, float(K * (M + N) * esz + 2 * M * N * 4)
+        nb = len(kr if kr is not None else kc)
+        kr = kr if kr is not None else torch.full((nb,), float(M), dtype=torch.float64)
+        kc = kc if kc is not None else torch.full((nb,), float(N), dtype=torch.float64)
+        flops = float((2.0 * rows_in * kr * kc).sum())
+        return flops, float((rows_in * (kr + kc)).sum() * esz + 2 * float(kr.max()) * float(kc.max()) * 4)
+    kk, kn = kept(keep_k, K, k_period), kept(keep_n, N, n_period)
+    side = M * N * ((osz if out2 is not None else 0) + (4 if resid is not None else 0) + (esz if dact_u is not None else 0))
+    if kk is None and kn is None:
+        return 2.0 * M * N * K, float((M * K + N * K) * esz + M * N * osz + side)
+    nb = len(kk if kk is not None else kn)
+    kk = kk if kk is not None else torch.full((nb,), float(K), dtype=torch.float64)
+    kn = kn if kn is not None else torch.full((nb,), float(N), dtype=torch.float64)
+    flops = float((2.0 * rows_in * kk * kn).sum())
+    return flops, float((rows_in * kk).sum() * esz + float(kk.max()) * float(kn.max()) * esz + M * N * osz + side)
 
 
 def cast_bf16(src, dst):
