@@ -39,27 +39,35 @@ __device__ __forceinline__ f32x4 mfma16(bfv8 a, bfv8 b, f32x4 c) {
 // ---- staging ---------------------------------------------------------------------------------------------
 // rows [N][D] at src (row stride rs elements) -> chunk-major LDS, rows N..Np-1 zero.
 // Trip counts are compile-time (MAXNP = 32 * NKP >= Np) and the loop is fully unrolled with every global load issued
-// before the first LDS store: a run-time loop made each iteration a separate HBM round trip (load, wait, store), and a
-// workgroup that owns a CU alone (100+ KB of LDS) has nothing else to hide them behind.
+// before the first LDS store.  Lane -> element map: a group of 8 consecutive lanes covers 4 rows x 2 adjacent chunks, NCH / 2
+// consecutive groups cover the whole width of those 4 rows -- a wave-instruction reads whole 128-byte lines (the previous map,
+// consecutive lanes = consecutive rows of ONE chunk, touched 64 different lines per instruction and every line 8 times), and
+// the 8 lanes of a ds_write_b128 group fall on 8 different 16-byte bank slots: the chunk-plane stride is 128 (mod 256) bytes,
+// so the chunk parity picks the half of the bank row and the 4 consecutive rows fill 64 bytes of it.
 template <int D, int MAXNP, int NTHR>
 __device__ __forceinline__ void stage_chunked(char* dst, const bf16_t* __restrict__ src, int rs, int N, int Np, int tid) {
     const int NpS = Np + 8;                    // row stride of a chunk plane (see header)
-    constexpr int NCH = AC<D>::NCH;
+    constexpr int NCH = AC<D>::NCH, HP = NCH / 2;
     constexpr int IT = (MAXNP * NCH + NTHR - 1) / NTHR;
+    const int total = Np * NCH;
     uint4 v[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int idx = tid + it * NTHR;
-        const int n = idx % Np, ch = idx / Np;
-        const bool ok = n < N && ch < NCH;
+        const int q = idx >> 3, l8 = idx & 7;
+        const int rb = q / HP, cp = q - rb * HP;
+        const int n = 4 * rb + (l8 >> 1), ch = 2 * cp + (l8 & 1);
+        const bool ok = n < N && idx < total;
         v[it] = *reinterpret_cast<const uint4*>(src + (long long)(ok ? n : 0) * rs + (ok ? ch : 0) * 8);
         if (!ok) v[it] = make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int idx = tid + it * NTHR;
-        const int n = idx % Np, ch = idx / Np;
-        if (ch < NCH) *reinterpret_cast<uint4*>(dst + ((size_t)ch * NpS + n) * 16) = v[it];
+        const int q = idx >> 3, l8 = idx & 7;
+        const int rb = q / HP, cp = q - rb * HP;
+        const int n = 4 * rb + (l8 >> 1), ch = 2 * cp + (l8 & 1);
+        if (idx < total) *reinterpret_cast<uint4*>(dst + ((size_t)ch * NpS + n) * 16) = v[it];
     }
 }
 
@@ -108,12 +116,68 @@ __device__ __forceinline__ float gsum(float v) {
 }
 
 // ==========================================================================================================
+// Occupancy plan of the whole-head kernels (N <= 288).  A head of N = 257, D = 64 needs 76 KB of LDS: two workgroups per CU
+// at most.  The kernels are therefore written for <= 128 VGPRs with NW = 8 waves (a multiple of the 4 SIMDs: a 6-wave
+// workgroup occupies the SIMDs 2/2/1/1 and a second one was not co-scheduled -- measured: 1.2 resident waves per SIMD): two
+// co-resident workgroups give every SIMD four waves, and the staging of one head overlaps the MFMA / softmax work of the
+// other.  Register pressure is bounded by construction: the forward walks the keys in blocks of PB tile pairs with a
+// running (max, sum) and one accumulator rescale per block (the scores of a block, not of the whole row, live in registers);
+// the backward kernels hold one key / query tile per wave.  exp(x) is v_exp_f32 on x * log2(e) folded into the scale;
+// zero-padded LDS rows make every mask of the backward kernels redundant (an out-of-range key or query contributes exact
+// zeros), the forward masks the one partial key tile only.
+// The padded row count NP = 32 * NKP is a compile-time constant: every LDS fragment address is one per-lane base (computed
+// once per kernel) plus an immediate -- PMC counters of the previous form showed 935 VALU instructions per 16-query tile,
+// half of them address arithmetic, on a kernel whose VALU pipe was busy 3.6x longer than its matrix pipe.
+// ==========================================================================================================
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int D, int NP> struct Img {
+    static constexpr int S = (NP + 8) * 16;                   // bytes between chunk planes
+    static constexpr int BYTES = AC<D>::NCH * S;               // one staged operand
+    // per-lane byte offset of the ds_read_b128 fragment (row lane % 16, chunk 4 dk + lane / 16); + 16 * row0 selects the tile
+    __device__ static __forceinline__ int cbase(int dk, int lane) {
+        int ch = dk * 4 + (lane >> 4);
+        ch = ch < AC<D>::NCH ? ch : AC<D>::NCH - 1;            // partner operand is zero there (D = 48)
+        return (ch * (NP + 8) + (lane & 15)) * 16;
+    }
+    // per-lane byte offset of the transposing read (see tfrag); + (2 dt (NP + 8) + 32 kp) * 16 selects pair tile / d tile
+    __device__ static __forceinline__ int tbase(int lane) {
+        const int g = lane >> 4, i = lane & 15;
+        return ((((i & 3) >> 1)) * (NP + 8) + 4 * g + (i >> 2)) * 16 + (i & 1) * 8;
+    }
+    // the per-lane base as an opaque 32-bit LDS address: without the barrier the compiler folds the image's offset inside the
+    // workgroup's LDS into every fragment offset, the sum no longer fits the 16-bit immediate of ds_read and each read pays
+    // a v_or / v_add
+    __device__ static __forceinline__ const char* opaque(const char* p) {
+        typedef __attribute__((address_space(3))) const char lds_char;
+        unsigned a = (unsigned)(unsigned long long)(lds_char*)p;
+        asm volatile("" : "+v"(a));
+        return (const char*)(lds_char*)(unsigned long long)a;
+    }
+    __device__ static __forceinline__ bfv8 cread(const char* lane_base, int row0) {
+        return *reinterpret_cast<const bfv8*>(lane_base + row0 * 16);
+    }
+    __device__ static __forceinline__ bfv8 tread(const char* lane_base, int kp, int dt) {
+        typedef __attribute__((address_space(3))) s4v lds_s4v;
+        const char* p = lane_base + (2 * dt * (NP + 8) + 32 * kp) * 16;
+        const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(p));
+        const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(p + 16 * 16));
+        const s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bfv8, v);
+    }
+};
+
+// ==========================================================================================================
 // forward
 // ==========================================================================================================
-template <int D, int NKP, int NW>
-__global__ __launch_bounds__(NW * 64) void fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                      float* __restrict__ lse, const int* __restrict__ keep_hd, int B,
-                                                      int N, int H, float scale) {
+template <int D, int NKP, int NW, int PB, int OCC, bool FULL>
+__global__ __launch_bounds__(NW * 64, OCC) void fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                           float* __restrict__ lse, const int* __restrict__ keep_hd, int B,
+                                                           int N, int H, float scale) {
+    static_assert(NKP % PB == 0, "key-tile pairs must split into whole blocks");
+    constexpr int NP = 32 * NKP;
+    typedef Img<D, NP> I;
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -129,76 +193,118 @@ __global__ __launch_bounds__(NW * 64) void fwd_kernel(const bf16_t* __restrict__
         for (int n = tid; n < N; n += NW * 64) lb[n] = 0.f;
         return;
     }
-    const int Np = (N + 31) / 32 * 32, nkt = Np / 16, nkp = Np / 32;
     char* Kc = sm;
-    char* Vc = sm + (size_t)D * (Np + 8) * 2;
-    stage_chunked<D, 32 * NKP, NW * 64>(Kc, base + HD, RS, N, Np, tid);
-    stage_chunked<D, 32 * NKP, NW * 64>(Vc, base + 2 * HD, RS, N, Np, tid);
+    char* Vc = sm + I::BYTES;
+    int q0 = wave * 16;
+    bfv8 qf[AC<D>::DK];                                   // first query tile: in flight while K / V are staged
+#pragma unroll
+    for (int dk = 0; dk < AC<D>::DK; ++dk) qf[dk] = gfrag<D>(base, RS, q0, N, dk, lane);
+    stage_chunked<D, NP, NW * 64>(Kc, base + HD, RS, N, NP, tid);
+    stage_chunked<D, NP, NW * 64>(Vc, base + 2 * HD, RS, N, NP, tid);
     __syncthreads();
-    for (int q0 = wave * 16; q0 < N; q0 += NW * 16) {
-        bfv8 qf[AC<D>::DK];
+    const char* kb[AC<D>::DK];
 #pragma unroll
-        for (int dk = 0; dk < AC<D>::DK; ++dk) qf[dk] = gfrag<D>(base, RS, q0, N, dk, lane);
-        f32x4 st[2 * NKP];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 2 * NKP; ++kt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (kt < nkt) {
-#pragma unroll
-                for (int dk = 0; dk < AC<D>::DK; ++dk) acc = mfma16(cfrag<D>(Kc, Np, kt * 16, dk, lane), qf[dk], acc);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool kok = (kt * 16 + 4 * g + r) < N;
-                acc[r] = kok ? acc[r] * scale : -INFINITY;
-                mx = fmaxf(mx, acc[r]);
-            }
-            st[kt] = acc;
-        }
-        mx = gmax(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2 * NKP; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __expf(st[kt][r] - mx);
-                st[kt][r] = p;
-                sum += p;
-            }
-        sum = gsum(sum);
+    for (int dk = 0; dk < AC<D>::DK; ++dk) kb[dk] = I::opaque(Kc + I::cbase(dk, lane));
+    const char* vb = I::opaque(Vc + I::tbase(lane));
+    const float cs = scale * LOG2E;
+    while (q0 < N) {
+        float m = -INFINITY, sum = 0.f;                   // running raw max (same in the 4 lanes of a query) and per-lane sum
         f32x4 oacc[AC<D>::DT];
 #pragma unroll
         for (int dt = 0; dt < AC<D>::DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kp = 0; kp < NKP; ++kp) {
-            if (kp < nkp) {
-                const bfv8 pf = pack8(st[2 * kp], st[2 * kp + 1]);
+        for (int b0 = 0; b0 < NKP; b0 += PB) {
+            if (FULL || b0 * 32 < N) {
+                f32x4 st[2 * PB];
+                float bm = -INFINITY;
 #pragma unroll
-                for (int dt = 0; dt < AC<D>::DT; ++dt) oacc[dt] = mfma16(tfrag<D>(Vc, Np, kp, dt, lane), pf, oacc[dt]);
+                for (int j = 0; j < 2 * PB; ++j) {
+                    const int k0 = (2 * b0 + j) * 16;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    if (FULL || k0 < N) {
+#pragma unroll
+                        for (int dk = 0; dk < AC<D>::DK; ++dk) acc = mfma16(I::cread(kb[dk], k0), qf[dk], acc);
+                        // FULL: N > 32 (NKP - 1), only the last pair of tiles can hold rows >= N (compile-time choice of the
+                        // masked tiles, no per-tile scalar conditions: those cost more SGPRs than the kernel has)
+                        if (FULL ? (2 * b0 + j >= 2 * NKP - 2) : (k0 + 16 > N)) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[r] = (k0 + 4 * g + r) < N ? acc[r] : -INFINITY;
+                        }
+                    } else {
+                        acc = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    }
+                    st[j] = acc;
+                    bm = fmaxf(fmaxf(bm, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+                }
+                bm = gmax(bm);
+                const float mn = fmaxf(m, bm);
+                const float alpha = ex2((m - mn) * cs);   // 0 for the first block (m = -inf)
+                const float mc = mn * cs;
+                float ps = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2 * PB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = ex2(fmaf(st[j][r], cs, -mc));
+                        st[j][r] = pv;
+                        ps += pv;
+                    }
+                sum = sum * alpha + ps;
+                m = mn;
+                if (b0 > 0) {
+#pragma unroll
+                    for (int dt = 0; dt < AC<D>::DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+                }
+#pragma unroll
+                for (int jp = 0; jp < PB; ++jp) {
+                    if (FULL || (b0 + jp) * 32 < N) {
+                        const bfv8 pf = pack8(st[2 * jp], st[2 * jp + 1]);
+#pragma unroll
+                        for (int dt = 0; dt < AC<D>::DT; ++dt) oacc[dt] = mfma16(I::tread(vb, b0 + jp, dt), pf, oacc[dt]);
+                    }
+                }
+                // keep the blocks apart: in straight-line code the scheduler hoists every LDS read of the tile to the top and
+                // spills (87 VGPRs at the 128-register budget); the other three waves of the SIMD cover this wave's latencies
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        sum = gsum(sum);
         // O^T tiles (V^T as the first operand): the lane owns query q0 + c and 4 consecutive d per tile -> 8-byte stores
         const float inv = 1.0f / sum;
-        if (q0 + c < N) {
+        const int qs = q0;
+        q0 += NW * 16;
+        bfv8 qn[AC<D>::DK];                               // next tile's queries: issued before this tile's stores
+        if (q0 < N) {
+#pragma unroll
+            for (int dk = 0; dk < AC<D>::DK; ++dk) qn[dk] = gfrag<D>(base, RS, q0, N, dk, lane);
+        }
+        if (qs + c < N) {
 #pragma unroll
             for (int dt = 0; dt < AC<D>::DT; ++dt)
-                *reinterpret_cast<uint2*>(ob + (long long)(q0 + c) * HD + dt * 16 + 4 * g) =
+                *reinterpret_cast<uint2*>(ob + (long long)(qs + c) * HD + dt * 16 + 4 * g) =
                     make_uint2(pack_bf2(oacc[dt][0] * inv, oacc[dt][1] * inv), pack_bf2(oacc[dt][2] * inv, oacc[dt][3] * inv));
+            if (g == 0) lb[qs + c] = m * scale + __logf(sum);
         }
-        if (g == 0 && q0 + c < N) lb[q0 + c] = mx + __logf(sum);
+        if (q0 < N) {
+#pragma unroll
+            for (int dk = 0; dk < AC<D>::DK; ++dk) qf[dk] = qn[dk];
+        }
     }
 }
 
 // ==========================================================================================================
 // backward A: dQ (+ delta = rowsum(dO * O))
 // ==========================================================================================================
-template <int D, int NKP, int NW, int QT>
-__global__ __launch_bounds__(NW * 64) void bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
-                                                         const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
-                                                         float* __restrict__ delta, bf16_t* __restrict__ dqkv,
-                                                         const int* __restrict__ keep_hd, int B, int N, int H,
-                                                         float scale) {
+template <int D, int NKP, int NW, int OCC, bool FULL>
+__global__ __launch_bounds__(NW * 64, OCC) void bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                              const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, bf16_t* __restrict__ dqkv,
+                                                              const int* __restrict__ keep_hd, int B, int N, int H,
+                                                              float scale) {
+    constexpr int NP = 32 * NKP;
+    typedef Img<D, NP> I;
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -216,87 +322,83 @@ __global__ __launch_bounds__(NW * 64) void bwd_dq_kernel(const bf16_t* __restric
     const bf16_t* gb = d_o + (long long)b * N * HD + h * D;
     const float* lb = lse + ((long long)b * H + h) * N;
     float* db = delta + ((long long)b * H + h) * N;
-    const int Np = (N + 31) / 32 * 32, nkp = Np / 32;
     char* Kc = sm;
-    char* Vc = Kc + (size_t)D * (Np + 8) * 2;
-    stage_chunked<D, 32 * NKP, NW * 64>(Kc, base + HD, RS, N, Np, tid);
-    stage_chunked<D, 32 * NKP, NW * 64>(Vc, base + 2 * HD, RS, N, Np, tid);
+    char* Vc = Kc + I::BYTES;
+    int q0 = wave * 16;
+    bfv8 qf[AC<D>::DK], gf[AC<D>::DK], of[AC<D>::DK];     // first query tile: in flight while K / V are staged
+    float lq = 0.f;
+#pragma unroll
+    for (int dk = 0; dk < AC<D>::DK; ++dk) {
+        qf[dk] = gfrag<D>(base, RS, q0, N, dk, lane);
+        gf[dk] = gfrag<D>(gb, HD, q0, N, dk, lane);
+        of[dk] = gfrag<D>(ob, HD, q0, N, dk, lane);
+    }
+    if (q0 + c < N) lq = lb[q0 + c];
+    stage_chunked<D, NP, NW * 64>(Kc, base + HD, RS, N, NP, tid);
+    stage_chunked<D, NP, NW * 64>(Vc, base + 2 * HD, RS, N, NP, tid);
     __syncthreads();
-    // QT query tiles per wave at once: every LDS fragment (K, V, K^T of a key tile) is read once and feeds QT MFMAs --
-    // with one tile per wave the kernel was LDS-bandwidth bound (each wave re-read the whole head per 16 queries)
-    for (int u0 = wave * QT * 16; u0 < N; u0 += NW * QT * 16) {
-        bool qok[QT];
-        bfv8 qf[QT][AC<D>::DK], gf[QT][AC<D>::DK];
-        float dl[QT], l[QT];
-        f32x4 dq[QT][AC<D>::DT];
+    const char *kb[AC<D>::DK], *vb[AC<D>::DK];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const int q0 = u0 + 16 * t;
-            qok[t] = q0 + c < N;
-            float d = 0.f;
+    for (int dk = 0; dk < AC<D>::DK; ++dk) {
+        kb[dk] = I::opaque(Kc + I::cbase(dk, lane));
+        vb[dk] = I::opaque(Vc + I::cbase(dk, lane));
+    }
+    const char* kt_b = I::opaque(Kc + I::tbase(lane));
+    const float cs = scale * LOG2E;
+    while (q0 < N) {
+        float d = 0.f;
 #pragma unroll
-            for (int dk = 0; dk < AC<D>::DK; ++dk) {
-                qf[t][dk] = gfrag<D>(base, RS, q0, N, dk, lane);
-                gf[t][dk] = gfrag<D>(gb, HD, q0, N, dk, lane);
-                const bfv8 of = gfrag<D>(ob, HD, q0, N, dk, lane);
+        for (int dk = 0; dk < AC<D>::DK; ++dk)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) d += (float)gf[t][dk][e] * (float)of[e];
-            }
-            dl[t] = gsum(d);
-            l[t] = qok[t] ? lb[q0 + c] : 0.f;
-            if (g == 0 && qok[t]) db[q0 + c] = dl[t];
+            for (int e = 0; e < 8; ++e) d += (float)gf[dk][e] * (float)of[dk][e];
+        const float dl = gsum(d);
+        const float l2 = lq * LOG2E;
+        if (g == 0 && q0 + c < N) db[q0 + c] = dl;
+        f32x4 dq[AC<D>::DT];
 #pragma unroll
-            for (int dt = 0; dt < AC<D>::DT; ++dt) dq[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int dt = 0; dt < AC<D>::DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // keys beyond N are zero rows of K and V in LDS: their dS is finite and meets a zero K^T fragment -- no masks
 #pragma unroll
         for (int kp = 0; kp < NKP; ++kp) {
-            if (kp < nkp) {
-                f32x4 ds[QT][2];
+            if (FULL || kp * 32 < N) {
+                f32x4 ds[2];
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    const int kt = 2 * kp + tt;
-                    bfv8 ka[AC<D>::DK], va[AC<D>::DK];
-#pragma unroll
-                    for (int dk = 0; dk < AC<D>::DK; ++dk) {
-                        ka[dk] = cfrag<D>(Kc, Np, kt * 16, dk, lane);
-                        va[dk] = cfrag<D>(Vc, Np, kt * 16, dk, lane);
-                    }
-#pragma unroll
-                    for (int t = 0; t < QT; ++t) {
-                        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    const int k0 = (2 * kp + tt) * 16;
+                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    if (FULL || k0 < N) {
 #pragma unroll
                         for (int dk = 0; dk < AC<D>::DK; ++dk) {
-                            sc = mfma16(ka[dk], qf[t][dk], sc);
-                            dp = mfma16(va[dk], gf[t][dk], dp);
+                            sc = mfma16(I::cread(kb[dk], k0), qf[dk], sc);
+                            dp = mfma16(I::cread(vb[dk], k0), gf[dk], dp);
                         }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const bool ok = qok[t] && ((kt * 16 + 4 * g + r) < N);
-                            const float pr = ok ? __expf(sc[r] * scale - l[t]) : 0.f;
-                            sc[r] = pr * (dp[r] - dl[t]) * scale;
-                        }
-                        ds[t][tt] = sc;
+                        for (int r = 0; r < 4; ++r) sc[r] = ex2(fmaf(sc[r], cs, -l2)) * ((dp[r] - dl) * scale);
                     }
+                    ds[tt] = sc;
                 }
-                bfv8 sf[QT];
+                const bfv8 sf = pack8(ds[0], ds[1]);                                  // dS never leaves registers
 #pragma unroll
-                for (int t = 0; t < QT; ++t) sf[t] = pack8(ds[t][0], ds[t][1]);       // dS never leaves registers
-#pragma unroll
-                for (int dt = 0; dt < AC<D>::DT; ++dt) {
-                    const bfv8 kt_f = tfrag<D>(Kc, Np, kp, dt, lane);
-#pragma unroll
-                    for (int t = 0; t < QT; ++t) dq[t][dt] = mfma16(kt_f, sf[t], dq[t][dt]);
-                }
+                for (int dt = 0; dt < AC<D>::DT; ++dt) dq[dt] = mfma16(I::tread(kt_b, kp, dt), sf, dq[dt]);
+                if (kp % 3 == 2) __builtin_amdgcn_sched_barrier(0);      // see fwd_kernel: bounds the scheduler's hoisting
             }
         }
+        const int qs = q0;
+        q0 += NW * 16;
+        if (q0 < N) {                                       // next tile's operands: issued before this tile's stores
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            if (qok[t]) {      // dQ^T tiles: query q0 + c, 4 consecutive d per tile
-#pragma unroll
-                for (int dt = 0; dt < AC<D>::DT; ++dt)
-                    *reinterpret_cast<uint2*>(dbase + (long long)(u0 + 16 * t + c) * RS + dt * 16 + 4 * g) =
-                        make_uint2(pack_bf2(dq[t][dt][0], dq[t][dt][1]), pack_bf2(dq[t][dt][2], dq[t][dt][3]));
+            for (int dk = 0; dk < AC<D>::DK; ++dk) {
+                qf[dk] = gfrag<D>(base, RS, q0, N, dk, lane);
+                gf[dk] = gfrag<D>(gb, HD, q0, N, dk, lane);
+                of[dk] = gfrag<D>(ob, HD, q0, N, dk, lane);
             }
+            lq = q0 + c < N ? lb[q0 + c] : 0.f;
+        }
+        if (qs + c < N) {      // dQ^T tiles: query qs + c, 4 consecutive d per tile
+#pragma unroll
+            for (int dt = 0; dt < AC<D>::DT; ++dt)
+                *reinterpret_cast<uint2*>(dbase + (long long)(qs + c) * RS + dt * 16 + 4 * g) =
+                    make_uint2(pack_bf2(dq[dt][0], dq[dt][1]), pack_bf2(dq[dt][2], dq[dt][3]));
         }
     }
 }
@@ -304,11 +406,13 @@ __global__ __launch_bounds__(NW * 64) void bwd_dq_kernel(const bf16_t* __restric
 // ==========================================================================================================
 // backward B: dK, dV
 // ==========================================================================================================
-template <int D, int NKP, int NW, int QT>
-__global__ __launch_bounds__(NW * 64) void bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dqkv, const int* __restrict__ keep_hd,
-                                                          int B, int N, int H, float scale) {
+template <int D, int NKP, int NW, int OCC, bool FULL>
+__global__ __launch_bounds__(NW * 64, OCC) void bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               bf16_t* __restrict__ dqkv, const int* __restrict__ keep_hd,
+                                                               int B, int N, int H, float scale) {
+    constexpr int NP = 32 * NKP;
+    typedef Img<D, NP> I;
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -324,94 +428,91 @@ __global__ __launch_bounds__(NW * 64) void bwd_dkv_kernel(const bf16_t* __restri
         return;
     }
     const bf16_t* gb = d_o + (long long)b * N * HD + h * D;
-    const int Np = (N + 31) / 32 * 32, nqp = Np / 32;
+    const int nqp = FULL ? NKP : (N + 31) / 32;
     char* Qc = sm;
-    char* Gc = Qc + (size_t)D * (Np + 8) * 2;
-    float* Ls = reinterpret_cast<float*>(Gc + (size_t)D * (Np + 8) * 2);
-    float* Ds = Ls + Np;
-    stage_chunked<D, 32 * NKP, NW * 64>(Qc, base, RS, N, Np, tid);
-    stage_chunked<D, 32 * NKP, NW * 64>(Gc, gb, HD, N, Np, tid);
-    for (int n = tid; n < Np; n += NW * 64) {
-        Ls[n] = n < N ? lse[((long long)b * H + h) * N + n] : 0.f;
+    char* Gc = Qc + I::BYTES;
+    float* Ls = reinterpret_cast<float*>(Gc + I::BYTES);      // lse * log2(e) per query (0 beyond N)
+    float* Ds = Ls + NP;
+    int u0 = wave * 16;
+    bfv8 kf[AC<D>::DK], vf[AC<D>::DK];                    // first key tile: in flight while Q / dO are staged
+#pragma unroll
+    for (int dk = 0; dk < AC<D>::DK; ++dk) {
+        kf[dk] = gfrag<D>(base + HD, RS, u0, N, dk, lane);
+        vf[dk] = gfrag<D>(base + 2 * HD, RS, u0, N, dk, lane);
+    }
+    for (int n = tid; n < NP; n += NW * 64) {
+        Ls[n] = n < N ? lse[((long long)b * H + h) * N + n] * LOG2E : 0.f;
         Ds[n] = n < N ? delta[((long long)b * H + h) * N + n] : 0.f;
     }
+    stage_chunked<D, NP, NW * 64>(Qc, base, RS, N, NP, tid);
+    stage_chunked<D, NP, NW * 64>(Gc, gb, HD, N, NP, tid);
     __syncthreads();
-    for (int u0 = wave * QT * 16; u0 < N; u0 += NW * QT * 16) {       // QT key tiles per wave (see bwd_dq_kernel)
-        bfv8 kf[QT][AC<D>::DK], vf[QT][AC<D>::DK];
-        f32x4 dka[QT][AC<D>::DT], dva[QT][AC<D>::DT];
+    const char *qb[AC<D>::DK], *gcb[AC<D>::DK];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
+    for (int dk = 0; dk < AC<D>::DK; ++dk) {
+        qb[dk] = I::opaque(Qc + I::cbase(dk, lane));
+        gcb[dk] = I::opaque(Gc + I::cbase(dk, lane));
+    }
+    const char* qt_b = I::opaque(Qc + I::tbase(lane));
+    const char* gt_b = I::opaque(Gc + I::tbase(lane));
+    const float* lsg = Ls + 4 * g;
+    const float* dsg = Ds + 4 * g;
+    const float cs = scale * LOG2E;
+    while (u0 < N) {
+        f32x4 dka[AC<D>::DT], dva[AC<D>::DT];
 #pragma unroll
-            for (int dk = 0; dk < AC<D>::DK; ++dk) {
-                kf[t][dk] = gfrag<D>(base + HD, RS, u0 + 16 * t, N, dk, lane);
-                vf[t][dk] = gfrag<D>(base + 2 * HD, RS, u0 + 16 * t, N, dk, lane);
-            }
-#pragma unroll
-            for (int dt = 0; dt < AC<D>::DT; ++dt) {
-                dka[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dva[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int dt = 0; dt < AC<D>::DT; ++dt) {
+            dka[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dva[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-#pragma unroll 1
+        // queries beyond N are zero rows of Q and dO in LDS (and Ls = Ds = 0): P is finite, dS = 0 -- no masks
+#pragma unroll(NKP <= 3 ? NKP : 1)
         for (int qp = 0; qp < nqp; ++qp) {
-            f32x4 p[QT][2], ds[QT][2];
+            f32x4 p[2], ds[2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int q0 = qp * 32 + tt * 16;
-                bfv8 qa[AC<D>::DK], ga[AC<D>::DK];
+                const float4 l4 = *reinterpret_cast<const float4*>(lsg + q0);
+                const float4 d4 = *reinterpret_cast<const float4*>(dsg + q0);
+                const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int dk = 0; dk < AC<D>::DK; ++dk) {
-                    qa[dk] = cfrag<D>(Qc, Np, q0, dk, lane);
-                    ga[dk] = cfrag<D>(Gc, Np, q0, dk, lane);
+                    sc = mfma16(I::cread(qb[dk], q0), kf[dk], sc);
+                    dp = mfma16(I::cread(gcb[dk], q0), vf[dk], dp);
                 }
-                const float4 l4 = *reinterpret_cast<const float4*>(Ls + q0 + 4 * g);
-                const float4 d4 = *reinterpret_cast<const float4*>(Ds + q0 + 4 * g);
-                const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int dk = 0; dk < AC<D>::DK; ++dk) {
-                        sc = mfma16(qa[dk], kf[t][dk], sc);
-                        dp = mfma16(ga[dk], vf[t][dk], dp);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool ok = (q0 + 4 * g + r) < N;
-                        const float pv = ok ? __expf(sc[r] * scale - lr[r]) : 0.f;
-                        p[t][tt][r] = pv;
-                        ds[t][tt][r] = pv * (dp[r] - dr[r]) * scale;
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = ex2(fmaf(sc[r], cs, -lr[r]));
+                    p[tt][r] = pv;
+                    ds[tt][r] = pv * ((dp[r] - dr[r]) * scale);
                 }
             }
-            bfv8 pf[QT], sf[QT];
-#pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                pf[t] = pack8(p[t][0], p[t][1]);
-                sf[t] = pack8(ds[t][0], ds[t][1]);
-            }
+            const bfv8 pf = pack8(p[0], p[1]), sf = pack8(ds[0], ds[1]);
 #pragma unroll
             for (int dt = 0; dt < AC<D>::DT; ++dt) {
-                const bfv8 gt_f = tfrag<D>(Gc, Np, qp, dt, lane), qt_f = tfrag<D>(Qc, Np, qp, dt, lane);
+                dva[dt] = mfma16(I::tread(gt_b, qp, dt), pf, dva[dt]);
+                dka[dt] = mfma16(I::tread(qt_b, qp, dt), sf, dka[dt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);              // (unrolled short loops: see fwd_kernel)
+        }
+        const int k = u0 + c;
+        u0 += NW * 16;
+        if (u0 < N) {                                       // next key tile: issued before this tile's stores
 #pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    dva[t][dt] = mfma16(gt_f, pf[t], dva[t][dt]);
-                    dka[t][dt] = mfma16(qt_f, sf[t], dka[t][dt]);
-                }
+            for (int dk = 0; dk < AC<D>::DK; ++dk) {
+                kf[dk] = gfrag<D>(base + HD, RS, u0, N, dk, lane);
+                vf[dk] = gfrag<D>(base + 2 * HD, RS, u0, N, dk, lane);
             }
         }
+        if (k < N) {      // dK^T / dV^T tiles: key k, 4 consecutive d per tile
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const int k = u0 + 16 * t + c;
-            if (k < N) {      // dK^T / dV^T tiles: key k, 4 consecutive d per tile
-#pragma unroll
-                for (int dt = 0; dt < AC<D>::DT; ++dt) {
-                    bf16_t* dst = dbase + (long long)k * RS + dt * 16 + 4 * g;
-                    *reinterpret_cast<uint2*>(dst + HD) =
-                        make_uint2(pack_bf2(dka[t][dt][0], dka[t][dt][1]), pack_bf2(dka[t][dt][2], dka[t][dt][3]));
-                    *reinterpret_cast<uint2*>(dst + 2 * HD) =
-                        make_uint2(pack_bf2(dva[t][dt][0], dva[t][dt][1]), pack_bf2(dva[t][dt][2], dva[t][dt][3]));
-                }
+            for (int dt = 0; dt < AC<D>::DT; ++dt) {
+                bf16_t* dst = dbase + (long long)k * RS + dt * 16 + 4 * g;
+                *reinterpret_cast<uint2*>(dst + HD) =
+                    make_uint2(pack_bf2(dka[dt][0], dka[dt][1]), pack_bf2(dka[dt][2], dka[dt][3]));
+                *reinterpret_cast<uint2*>(dst + 2 * HD) =
+                    make_uint2(pack_bf2(dva[dt][0], dva[dt][1]), pack_bf2(dva[dt][2], dva[dt][3]));
             }
         }
     }
@@ -714,33 +815,56 @@ template <typename K> static int set_lds(K kernel, size_t bytes) {
     return 0;
 }
 
+// waves per (batch, head) and workgroups per CU the register budget is set for (a multiple of the 4 SIMDs, see above)
+template <int NKP> struct Plan {
+    static constexpr int NW = NKP >= 9 ? 8 : 4;
+    static constexpr int OCC = 4;                            // NW = 8: two workgroups per CU; NW = 4: four
+    static constexpr int PB = NKP >= 9 ? 3 : NKP;
+};
+
 template <int D, int NKP>
 static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, const int* keep, int B, int N, int H, float scale,
                       hipStream_t st) {
-    constexpr int NW = NKP >= 9 ? 8 : (NKP >= 3 ? 4 : 2);      // waves per (batch, head): one 16-query tile each per pass (measured)
-    const int Np = (N + 31) / 32 * 32;
-    const size_t lds = (size_t)2 * D * (Np + 8) * 2;
-    int rc = set_lds(fwd_kernel<D, NKP, NW>, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((fwd_kernel<D, NKP, NW>), dim3(B * H), dim3(NW * 64), lds, st, qkv, o, lse, keep, B, N, H, scale);
+    constexpr int NW = Plan<NKP>::NW, OCC = Plan<NKP>::OCC, PB = Plan<NKP>::PB;
+    const size_t lds = (size_t)2 * Img<D, 32 * NKP>::BYTES;
+    // FULL: the last pair of key tiles is in use (N = 257 / 65 / 17 and every N > 32 (NKP - 1)): no run-time tile guards
+    if (N > 32 * (NKP - 1)) {
+        int rc = set_lds(fwd_kernel<D, NKP, NW, PB, OCC, true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((fwd_kernel<D, NKP, NW, PB, OCC, true>), dim3(B * H), dim3(NW * 64), lds, st, qkv, o, lse, keep, B, N, H,
+                           scale);
+    } else {
+        int rc = set_lds(fwd_kernel<D, NKP, NW, PB, OCC, false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((fwd_kernel<D, NKP, NW, PB, OCC, false>), dim3(B * H), dim3(NW * 64), lds, st, qkv, o, lse, keep, B, N, H,
+                           scale);
+    }
     return 0;
 }
 template <int D, int NKP>
 static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, const float* lse, float* delta, bf16_t* dqkv,
                       const int* keep, int B, int N, int H, float scale, hipStream_t st) {
-    constexpr int NW = NKP >= 3 ? 8 : 2;
-    constexpr int QT = NKP >= 9 ? 3 : 1;      // key tiles per wave in dK/dV: 17 tiles of N = 257 = one pass of 6 waves
-    constexpr int QTQ = 1;                    // query tiles per wave in dQ: 1 measured best inside the step (3: -1 %)
-    const int Np = (N + 31) / 32 * 32;
-    const size_t l1 = (size_t)2 * D * (Np + 8) * 2, l2 = (size_t)2 * D * (Np + 8) * 2 + 2 * Np * sizeof(float);
-    int rc = set_lds(bwd_dq_kernel<D, NKP, NW, QTQ>, l1);
-    if (rc) return rc;
-    rc = set_lds(bwd_dkv_kernel<D, NKP, NW, QT>, l2);
-    if (rc) return rc;
-    hipLaunchKernelGGL((bwd_dq_kernel<D, NKP, NW, QTQ>), dim3(B * H), dim3(NW * 64), l1, st, qkv, o, d_o, lse, delta, dqkv, keep,
-                       B, N, H, scale);
-    hipLaunchKernelGGL((bwd_dkv_kernel<D, NKP, NW, QT>), dim3(B * H), dim3(NW * 64), l2, st, qkv, d_o, lse, delta, dqkv, keep, B,
-                       N, H, scale);
+    constexpr int NW = Plan<NKP>::NW, OCC = Plan<NKP>::OCC;
+    const size_t l1 = (size_t)2 * Img<D, 32 * NKP>::BYTES, l2 = l1 + 2 * 32 * NKP * sizeof(float);
+    if (N > 32 * (NKP - 1)) {
+        int rc = set_lds(bwd_dq_kernel<D, NKP, NW, OCC, true>, l1);
+        if (rc) return rc;
+        rc = set_lds(bwd_dkv_kernel<D, NKP, NW, OCC, true>, l2);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bwd_dq_kernel<D, NKP, NW, OCC, true>), dim3(B * H), dim3(NW * 64), l1, st, qkv, o, d_o, lse, delta, dqkv,
+                           keep, B, N, H, scale);
+        hipLaunchKernelGGL((bwd_dkv_kernel<D, NKP, NW, OCC, true>), dim3(B * H), dim3(NW * 64), l2, st, qkv, d_o, lse, delta, dqkv,
+                           keep, B, N, H, scale);
+    } else {
+        int rc = set_lds(bwd_dq_kernel<D, NKP, NW, OCC, false>, l1);
+        if (rc) return rc;
+        rc = set_lds(bwd_dkv_kernel<D, NKP, NW, OCC, false>, l2);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bwd_dq_kernel<D, NKP, NW, OCC, false>), dim3(B * H), dim3(NW * 64), l1, st, qkv, o, d_o, lse, delta, dqkv,
+                           keep, B, N, H, scale);
+        hipLaunchKernelGGL((bwd_dkv_kernel<D, NKP, NW, OCC, false>), dim3(B * H), dim3(NW * 64), l2, st, qkv, d_o, lse, delta, dqkv,
+                           keep, B, N, H, scale);
+    }
     return 0;
 }
 
