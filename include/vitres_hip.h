@@ -101,6 +101,14 @@ typedef struct vr_gemm_args {
 int vr_gemm(const vr_gemm_args* args, vr_stream_t stream);
 
 /*
+ * vr_gemm_group: exactly `for (i < count) vr_gemm(&args[i], stream)`, but 2..4 bf16 weight-gradient problems of the split-token
+ * form (a_trans && b_trans && atomic, split_k == 0, un-mapped rows) -- the four Linears of one transformer block, autograd of
+ * F.linear at nets/supernet_blocks.py:36,48,102,118 -- run as ONE launch whose workgroups share the CUs.  Any other mix is
+ * issued problem by problem.  Outputs must not alias between problems.
+ */
+int vr_gemm_group(const vr_gemm_args* args, int32_t count, vr_stream_t stream);
+
+/*
  * vr_gemm with the adjacent LayerNorm fused into its epilogue (workgroups own whole output rows; bf16 operands, fp32 output,
  * N % 8 == 0, N <= 512, no n_period / pos / act / row maps on the output; ldc is also the row stride of x, resid, gt_out).
  *   mode 0 -- forward of attention `proj` / Mlp `fc2` (nets/supernet_blocks.py:214-253) and the LayerNorm that consumes the

@@ -134,6 +134,11 @@ def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db, next_cast
     return dx, scale_mask_cast(dx, next_cast[0], next_cast[1], rows_per_sample, dy.dtype)
 
 
+def gemm_group(calls):
+    for a, b, out, kw in calls:
+        gemm(a, b, out, **kw)
+
+
 def gemm_ln_supported(a, N, ldc):
     return a.dtype == torch.bfloat16 and N == ldc and N % 8 == 0 and N <= 512
 
@@ -370,7 +375,7 @@ def patch_fold(col, B, gh, gw, P, C):
     return x.reshape(B * gh * P * gw * P, C).clone()
 
 
-ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "softce_train", "colsum", "scale_mask_cast",
+ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "gemm_group", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "softce_train", "colsum", "scale_mask_cast",
        "batchsum", "conv3x3", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
 
 

@@ -528,3 +528,46 @@ def test_softce_train(dtype, R, rps, K_, mapped):
     loss.backward()
     assert abs(acc.item() - 0.5 - loss.item()) < 1e-5 * abs(loss.item())
     assert relerr(real[:, :K_], x.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("T,C,F,HD", [(257 * 8, 64, 192, 64), (65 * 16, 128, 384, 96), (17 * 6, 256, 768, 192)])
+def test_gemm_group_equals_the_launches_one_by_one(T, C, F, HD):
+    """vr_gemm_group: the four weight gradients of a transformer block as one launch (masked tiles, bias gradients, per-head
+    periods included) against the same calls issued through vr_gemm -- and against the torch statement."""
+    import functools
+    dt = torch.bfloat16
+    rps = T // 8 if T % 8 == 0 else T // 2
+    nb = T // rps
+    keep_c = torch.tensor([C, C // 2] * (nb // 2), dtype=torch.int32)
+    keep_f = torch.tensor([F, F // 3] * (nb // 2), dtype=torch.int32)
+    keep_h = torch.tensor([HD, HD // 2] * (nb // 2), dtype=torch.int32)
+    shapes = [("fc2", C, F, keep_c, keep_f, 0), ("fc1", F, C, keep_f, keep_c, 0), ("proj", C, HD, keep_c, keep_h, 0),
+              ("qkv", 3 * HD, C, keep_h, keep_c, HD)]
+    calls_cpu, calls_gpu, outs_gpu, outs_one = [], [], [], []
+    for i, (name, out_f, in_f, kr, kc, period) in enumerate(shapes):
+        dy = rnd(T, out_f, seed=10 + i).to(dt)
+        x = rnd(T, in_f, seed=20 + i).to(dt)
+        for s_ in range(nb):                                         # masked channels are exact zeros by contract
+            lim = int(kr[s_])
+            if period:
+                dy[s_ * rps:(s_ + 1) * rps].view(rps, 3, period)[:, :, lim:] = 0
+            else:
+                dy[s_ * rps:(s_ + 1) * rps, lim:] = 0
+            x[s_ * rps:(s_ + 1) * rps, int(kc[s_]):] = 0
+        kw = dict(M=out_f, N=in_f, K=T, lda=out_f, ldb=in_f, ldc=in_f, a_trans=True, b_trans=True, atomic=True, split_k=0,
+                  k_period=period, rows_in=rps)
+        dw_ref, db_ref = torch.zeros(out_f, in_f), torch.zeros(out_f)
+        calls_cpu.append((dy, x, dw_ref, dict(kw, keep_k=kr, keep_n=kc, bias_grad=db_ref)))
+        dw_g, db_g = torch.zeros(out_f, in_f, device=DEV), torch.zeros(out_f, device=DEV)
+        dw_1, db_1 = torch.zeros(out_f, in_f, device=DEV), torch.zeros(out_f, device=DEV)
+        calls_gpu.append((dy.to(DEV), x.to(DEV), dw_g, dict(kw, keep_k=kr.to(DEV), keep_n=kc.to(DEV), bias_grad=db_g)))
+        outs_gpu.append((dw_g, db_g))
+        outs_one.append((dw_1, db_1, dict(kw, keep_k=kr.to(DEV), keep_n=kc.to(DEV), bias_grad=db_1)))
+    K.gemm_group(calls_gpu)
+    E.gemm_group(calls_cpu)
+    for (a, b, _, _), (dw_1, db_1, kw1) in zip(calls_gpu, outs_one):
+        K.gemm(a, b, dw_1, **kw1)
+    torch.cuda.synchronize()
+    for (dw_g, db_g), (dw_1, db_1, _), (_, _, dw_ref, kwr) in zip(outs_gpu, outs_one, calls_cpu):
+        assert relerr(dw_g, dw_1) < 1e-5 and relerr(db_g, db_1) < 1e-5          # same kernel body, same split rule apart
+        assert relerr(dw_g, dw_ref) < 1.2e-2 and relerr(db_g, kwr["bias_grad"]) < 1.2e-2

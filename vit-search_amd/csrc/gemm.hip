@@ -26,6 +26,7 @@
 
 bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);   // gemm_nt.hip
 bool vr_gemm_tn_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);   // gemm_tn.hip
+bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t stream, int n_cu);
 
 namespace {
 using namespace vr_gemm_shared;
@@ -745,9 +746,9 @@ int launch(const vr_gemm_args& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
-    if (!args || !args->A || !args->B || !args->C) return VR_EINVAL;
-    vr_gemm_args a = *args;
+// argument validation shared by vr_gemm and vr_gemm_group (normalises split_k in place)
+static int gemm_validate(vr_gemm_args& a) {
+    if (!a.A || !a.B || !a.C) return VR_EINVAL;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return VR_EINVAL;
     if (a.split_k < 0 || (!a.atomic && a.split_k == 0)) a.split_k = 1;   // 0 with atomic = choose automatically
     if (a.split_k > 1 && !a.atomic) return VR_EINVAL;
@@ -777,6 +778,14 @@ extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
         (a.dact_u && ((uintptr_t)a.dact_u & 15)))
         return VR_EALIGN;
     if (a.in_dtype == VR_F32 && a.out_dtype == VR_BF16) return VR_EUNSUPPORTED;
+    return VR_OK;
+}
+
+extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
+    if (!args) return VR_EINVAL;
+    vr_gemm_args a = *args;
+    const int vrc = gemm_validate(a);
+    if (vrc != VR_OK) return vrc;
     static const bool knob_nt = !(std::getenv("VITRES_GEMM_NT") && std::getenv("VITRES_GEMM_NT")[0] == '0');
     if (knob_nt && !(a.sched & 4) && vr_gemm_nt_launch(a, (hipStream_t)stream, cu_count())) {
         VR_CHECK_LAUNCH();
@@ -789,4 +798,28 @@ extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
     }
     if (a.in_dtype == VR_BF16) return launch<bf16_t>(a, (hipStream_t)stream);
     return launch<float>(a, (hipStream_t)stream);
+}
+
+extern "C" int vr_gemm_group(const vr_gemm_args* args, int count, vr_stream_t stream) {
+    if (!args || count <= 0) return VR_EINVAL;
+    static const bool knob = !(std::getenv("VITRES_GEMM_GROUP") && std::getenv("VITRES_GEMM_GROUP")[0] == '0');
+    if (knob && count >= 2 && count <= 4) {
+        vr_gemm_args v[4];
+        bool ok = true;
+        for (int i = 0; i < count && ok; ++i) {
+            v[i] = args[i];
+            const int want_auto = v[i].atomic && v[i].split_k == 0;
+            if (gemm_validate(v[i]) != VR_OK || (v[i].sched & 4)) ok = false;
+            if (want_auto) v[i].split_k = 0;            // (validation keeps 0 = automatic for atomic forms)
+        }
+        if (ok && vr_gemm_tn_group_launch(v, count, (hipStream_t)stream, cu_count())) {
+            VR_CHECK_LAUNCH();
+            return VR_OK;
+        }
+    }
+    for (int i = 0; i < count; ++i) {
+        const int rc = vr_gemm(args + i, stream);
+        if (rc != VR_OK) return rc;
+    }
+    return VR_OK;
 }

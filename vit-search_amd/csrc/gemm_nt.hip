@@ -56,7 +56,11 @@ struct RowMeta {
 // STAGES = 1: one slice buffer, the CU's other workgroups hide the load latency.  STAGES = 3: ring of three buffers with two
 // slices in flight (counted s_waitcnt vmcnt, raw s_barrier: __syncthreads would drain the LDS-DMA queue) for grids that leave a
 // CU one or two workgroups -- long-K GEMMs of the last stage, where a lone workgroup paid ~1 us per slice.
-template <typename TO, int EPI, bool FAST, int MI, int NJ, int STAGES>
+// FEAT (FAST kernels): which optional epilogue terms exist is a compile-time fact of the kernel -- 0: none, 1: bias, 2: bias +
+// residual, 3: bias + residual + DropPath scale, 4: decided per launch from the arguments (pos-embed, any other mix; the only
+// form of the non-FAST kernels).  As run-time uniform conditions the compiler if-converts them into a v_cndmask per element
+// and term (measured: 890 VALU instructions per tile and wave against 128 MFMAs at K = 256, VALU pipe busy 2x the matrix pipe).
+template <typename TO, int EPI, bool FAST, int MI, int NJ, int STAGES, int FEAT>
 __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm_args p) {
     constexpr int BM = 32 * MI, WROWS = 16 * MI;      // tile rows, rows per wave
     constexpr int BN = 32 * NJ, WCOLS = 16 * NJ;      // tile columns, columns per wave
@@ -102,27 +106,56 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     };
 
     // ---- LDS-DMA source addressing: piece h of this wave = tile rows wave*32 + 8h .. +8, lane -> (row, slot) ----
+    // Interior tiles of un-mapped operands (every block Linear) take the affine path: one row address per operand, pieces 8 rows
+    // apart -- the general path (row clamps at the matrix edge, vr_rowmap divisions) costs ~40 instructions per piece, 8 pieces,
+    // on a kernel whose K = 256 loop is 4 slices long (its instruction issue, not HBM or the matrix pipe, set the tile time).
     const char* gA[AP];
     const char* gB[BP];
     int chunkA[AP], chunkB[BP];    // element offset of this lane's k-chunk inside a slice
+    {
+        const int rb = wave * (8 * BP) + (lane >> 3);
+        if (bmap.rpi == 0 && n0 + BN <= p.N) {
+            const char* b0 = reinterpret_cast<const char*>(p.B) + (long long)(n0 + rb) * p.ldb * 2;
+            const long long step = (long long)p.ldb * 16;
 #pragma unroll
-    for (int h = 0; h < BP; ++h) {
-        const int r = wave * (8 * BP) + h * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const int nb = min(n0 + r, p.N - 1);
-        gB[h] = reinterpret_cast<const char*>(p.B) + (map_row(bmap, nb) * (long long)p.ldb + c * 8) * 2;
-        chunkB[h] = c * 8;
-    }
+            for (int h = 0; h < BP; ++h) {
+                const int c = (lane & 7) ^ (((rb + 8 * h) >> 1) & 7);
+                gB[h] = b0 + h * step + c * 16;
+                chunkB[h] = c * 8;
+            }
+        } else {
 #pragma unroll
-    for (int h = 0; h < AP; ++h) {
-        const int r = wave * (8 * AP) + h * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const int ma = min(m0 + r, p.M - 1);
-        gA[h] = reinterpret_cast<const char*>(p.A) + (map_row(amap, ma) * (long long)p.lda + c * 8) * 2;
-        chunkA[h] = c * 8;
+            for (int h = 0; h < BP; ++h) {
+                const int r = rb + h * 8;
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                const int nb = min(n0 + r, p.N - 1);
+                gB[h] = reinterpret_cast<const char*>(p.B) + (map_row(bmap, nb) * (long long)p.ldb + c * 8) * 2;
+                chunkB[h] = c * 8;
+            }
+        }
+        const int ra = wave * (8 * AP) + (lane >> 3);
+        if (amap.rpi == 0 && m0 + BM <= p.M) {
+            const char* a0 = reinterpret_cast<const char*>(p.A) + (long long)(m0 + ra) * p.lda * 2;
+            const long long step = (long long)p.lda * 16;
+#pragma unroll
+            for (int h = 0; h < AP; ++h) {
+                const int c = (lane & 7) ^ (((ra + 8 * h) >> 1) & 7);
+                gA[h] = a0 + h * step + c * 16;
+                chunkA[h] = c * 8;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < AP; ++h) {
+                const int r = ra + h * 8;
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                const int ma = min(m0 + r, p.M - 1);
+                gA[h] = reinterpret_cast<const char*>(p.A) + (map_row(amap, ma) * (long long)p.lda + c * 8) * 2;
+                chunkA[h] = c * 8;
+            }
+        }
     }
     const char* zero = reinterpret_cast<const char*>(zero_chunk);
-    const bool ktail = (p.K % BK) != 0;
+    const bool ktail = !FAST && (p.K % BK) != 0;      // FAST: K % 64 == 0 (host check)
 
     // ---- fragment read offsets: lane -> row (lane & 15) of a 16-row group, k-chunk 4 s + (lane >> 4) ----
     const int frow = lane & 15, fswz = (frow >> 1) & 7;
@@ -223,6 +256,9 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     }
 
     // ---- epilogue: lane owns C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) + 0..3] of the wave's 64 x 64 ----
+    // Optional terms (bias, pos-embed, prefix mask, DropPath scale, residual) are wave-uniform kernel arguments: each is one
+    // scalar branch around its code instead of arithmetic on neutral elements -- for the plain Linear forms the epilogue used
+    // to issue 5x the instructions of the K = 256 loop.  The prefix mask is applied only by waves that hold a boundary group.
     constexpr int CW = 8;
     float* park = reinterpret_cast<float*>(smem + wave * 4096);      // [16 rows][16 slots of 4 floats], slot ^= row
     const int n = n0 + wn * WCOLS + (lane % LPR) * 8;                 // this lane's 8 columns
@@ -236,12 +272,16 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     // group never wraps; other periods take the per-element test)
     const bool grp = FAST || p.n_period <= 0 || (p.n_period & 7) == 0;
     const int ncp = p.n_period > 0 ? nc % p.n_period : nc;
+    constexpr bool GEN = FEAT == 4;
+    const bool has_bias = (EPI == EPI_STORE || EPI == EPI_GELU) && (GEN ? p.bias != nullptr : FEAT >= 1);
+    const bool has_pos = (EPI == EPI_STORE) && GEN && p.pos;
+    const bool has_res = (EPI == EPI_STORE) && (GEN ? p.resid != nullptr : FEAT >= 2);
+    const bool has_mask = p.keep_n != nullptr;
+    const bool has_scale = GEN ? p.scale != nullptr : FEAT == 3;
     float bv[CW];
 #pragma unroll
     for (int e = 0; e < CW; ++e) bv[e] = 0.f;
-    if ((EPI == EPI_STORE || EPI == EPI_GELU) && p.bias) loadw<float, CW>(p.bias, nc, bv, vecb, nv);
-    const bool has_pos = (EPI == EPI_STORE) && p.pos;
-    const bool has_res = (EPI == EPI_STORE) && p.resid;
+    if (has_bias) loadw<float, CW>(p.bias, nc, bv, vecb, nv);
     const bool live = nvalid > 0;
     const RowMeta* meta = rowmeta + wm * WROWS + (lane / LPR);
     // one round per 16-row fragment: park [16 rows][WCOLS columns] (<= 4 KB per wave), read back as rows
@@ -255,17 +295,15 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         RowMeta rm[NQ];
-        long long orow[NQ];
+        long long oidx[NQ];
         float rv[NQ][CW], pv[NQ][CW];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             rm[q] = meta[i * 16 + q * RPP];
-            orow[q] = rm[q].orow < 0 ? 0 : rm[q].orow;
-#pragma unroll
-            for (int e = 0; e < CW; ++e) { rv[q][e] = 0.f; pv[q][e] = 0.f; }
-            if constexpr (EPI == EPI_DGELU) loadw<bf16_t, CW>(p.dact_u, orow[q] * p.ldu + nc, rv[q], vec, nv);
+            oidx[q] = (long long)(rm[q].orow < 0 ? 0 : rm[q].orow) * p.ldc + nc;
+            if constexpr (EPI == EPI_DGELU) loadw<bf16_t, CW>(p.dact_u, (long long)(rm[q].orow < 0 ? 0 : rm[q].orow) * p.ldu + nc, rv[q], vec, nv);
             if constexpr (EPI == EPI_STORE) {
-                if (has_res) loadw<float, CW>(p.resid, orow[q] * p.ldc + nc, rv[q], vec, nv);
+                if (has_res) loadw<float, CW>(p.resid, oidx[q], rv[q], vec, nv);
                 if (has_pos) loadw<float, CW>(p.pos, (long long)rm[q].mloc * p.N + nc, pv[q], vecb, nv);
             }
         }
@@ -273,8 +311,6 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         for (int q = 0; q < NQ; ++q) {
             const int rl = q * RPP + (lane / LPR);
             const bool mok = rm[q].orow >= 0;
-            const int kn = rm[q].keep - ncp;
-            const float sc = rm[q].scale;
             float v[CW];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -282,33 +318,54 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
                 const f32x4 a4 = *reinterpret_cast<const f32x4*>(park + rl * WCOLS + slot * 4);
                 v[4 * h] = a4[0]; v[4 * h + 1] = a4[1]; v[4 * h + 2] = a4[2]; v[4 * h + 3] = a4[3];
             }
-            bool kc[CW];
+            if (has_bias) {
 #pragma unroll
-            for (int e = 0; e < CW; ++e) {
-                v[e] += bv[e] + pv[q][e];
-                kc[e] = grp ? (e < kn) : kept_col(nc + e, p.n_period, rm[q].keep);
+                for (int e = 0; e < CW; ++e) v[e] += bv[e];
+            }
+            if (has_pos) {
+#pragma unroll
+                for (int e = 0; e < CW; ++e) v[e] += pv[q][e];
             }
             const bool any = mok && live;
-            const long long oidx = orow[q] * p.ldc + nc;
-            if constexpr (EPI == EPI_GELU) {
-                float hh[CW];
+            if constexpr (EPI == EPI_DGELU) {
 #pragma unroll
-                for (int e = 0; e < CW; ++e) {
-                    v[e] = kc[e] ? v[e] : 0.f;       // masked hidden units: u = 0, gelu(u) = 0 (their K loop may be skipped)
-                    hh[e] = kc[e] ? gelu_fast(v[e]) : 0.f;
+                for (int e = 0; e < CW; ++e) v[e] *= dgelu_fast(rv[q][e]);
+            }
+            float hh[CW];
+            if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < CW; ++e) hh[e] = gelu_fast(v[e]);
+            }
+            if (has_mask) {
+                const int kn = rm[q].keep - ncp;                       // kept columns of this lane's group (>= 8: all)
+                const bool edge = !grp || kn < CW;
+                if (__builtin_amdgcn_ballot_w64(edge) != 0) {          // some lane of the wave holds a mask boundary
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) {
+                        const bool kc = grp ? (e < kn) : kept_col(nc + e, p.n_period, rm[q].keep);
+                        v[e] = kc ? v[e] : 0.f;                         // (GELU: masked hidden units: u = 0, gelu(u) = 0)
+                        if constexpr (EPI == EPI_GELU) hh[e] = kc ? hh[e] : 0.f;
+                    }
                 }
+            }
+            if constexpr (EPI == EPI_GELU) {
                 if (any) {
-                    storew<TO, CW>(p.C, oidx, v, vec, mok, nvalid);
-                    storew<TO, CW>(p.C2, oidx, hh, vec, mok, nvalid);
+                    storew<TO, CW>(p.C, oidx[q], v, vec, mok, nvalid);
+                    storew<TO, CW>(p.C2, oidx[q], hh, vec, mok, nvalid);
                 }
             } else {
+                if (has_scale) {
+                    const float sc = rm[q].scale;
 #pragma unroll
-                for (int e = 0; e < CW; ++e) {
-                    if constexpr (EPI == EPI_DGELU) v[e] *= dgelu_fast(rv[q][e]);
-                    v[e] = kc[e] ? v[e] * sc : 0.f;
-                    if constexpr (EPI == EPI_STORE) v[e] += rv[q][e];
+                    for (int e = 0; e < CW; ++e) v[e] *= sc;
                 }
-                if (any) storew<TO, CW>(p.C, oidx, v, vec, mok, nvalid);
+                if constexpr (EPI == EPI_STORE) {
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < CW; ++e) v[e] += rv[q][e];
+                    }
+                }
+                if (any) storew<TO, CW>(p.C, oidx[q], v, vec, mok, nvalid);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -316,16 +373,44 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     }
 }
 
-template <typename TO, int EPI, int MI, int NJ, int STAGES = 1> void launch2(const vr_gemm_args& a, hipStream_t stream, bool fast) {
+template <typename TO, int EPI, int MI, int NJ, int STAGES, int FEAT> void launch3(const vr_gemm_args& a, hipStream_t stream, bool fast) {
     const long long total = (long long)((a.M + 32 * MI - 1) / (32 * MI)) * ((a.N + 32 * NJ - 1) / (32 * NJ));
-    if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true, MI, NJ, STAGES>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
-    else hipLaunchKernelGGL((nt_kernel<TO, EPI, false, MI, NJ, STAGES>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true, MI, NJ, STAGES, FEAT>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    else hipLaunchKernelGGL((nt_kernel<TO, EPI, false, MI, NJ, STAGES, 4>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+}
+
+template <typename TO, int EPI, int MI, int NJ, int STAGES = 1> void launch2(const vr_gemm_args& a, hipStream_t stream, bool fast) {
+    // epilogue form (see nt_kernel): the forms of the transformer-block Linears get their own kernels
+    int feat = 4;
+    if (fast && !a.pos) {
+        if (!a.bias && !a.resid && !a.scale) feat = 0;
+        else if (a.bias && !a.resid && !a.scale) feat = 1;
+        else if (a.bias && a.resid && !a.scale) feat = 2;
+        else if (a.bias && a.resid && a.scale) feat = 3;
+    }
+    if constexpr (EPI == EPI_STORE) {
+        switch (feat) {
+            case 0: return launch3<TO, EPI, MI, NJ, STAGES, 0>(a, stream, fast);
+            case 1: return launch3<TO, EPI, MI, NJ, STAGES, 1>(a, stream, fast);
+            case 2: return launch3<TO, EPI, MI, NJ, STAGES, 2>(a, stream, fast);
+            case 3: return launch3<TO, EPI, MI, NJ, STAGES, 3>(a, stream, fast);
+            default: return launch3<TO, EPI, MI, NJ, STAGES, 4>(a, stream, fast);
+        }
+    } else if constexpr (EPI == EPI_GELU) {
+        if (feat == 1) return launch3<TO, EPI, MI, NJ, STAGES, 1>(a, stream, fast);
+        if (feat == 0) return launch3<TO, EPI, MI, NJ, STAGES, 0>(a, stream, fast);
+        return launch3<TO, EPI, MI, NJ, STAGES, 4>(a, stream, fast);
+    } else {
+        if (feat == 0) return launch3<TO, EPI, MI, NJ, STAGES, 0>(a, stream, fast);
+        return launch3<TO, EPI, MI, NJ, STAGES, 4>(a, stream, fast);
+    }
 }
 
 template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     const long long tn = (a.N + 127) / 128;
     const long long t128 = (long long)((a.M + 127) / 128) * tn, t64 = (long long)((a.M + 63) / 64) * tn;
-    const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);
+    const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0) &&
+                      a.K % BK == 0;
     static const int knob = std::getenv("VITRES_NT_TILE") ? std::atoi(std::getenv("VITRES_NT_TILE")) : 0;   // 1/2/3: force
     // tile by grid size (measured crossovers, tools/gemm_bench.py): 128x128 while it gives a CU two workgroups, 64x128
     // below that, 64x64 when even that leaves CUs with a single workgroup (long-K GEMMs of the last stage)

@@ -71,7 +71,7 @@ template <int ROWB> __device__ __forceinline__ bfv8 tr_frag(const char* p) {
 // gemm_nt.hip).  Faster alone; inside the training step its 96 KB of LDS displace the data-gradient workgroups it runs beside
 // (measured -5 %), so the default stays the single buffer.
 template <bool BIAS, bool MAPPED, int TW, int STAGES>
-__global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
+__device__ __forceinline__ void tn_body(const vr_gemm_args& p, const int bid) {
     typedef Geo<TW> G;
     constexpr int ROWB = G::ROWB, SLOTS = G::SLOTS, TPP = G::TPP, PPW = G::PPW, TILE_BYTES = G::TILE_BYTES, F = G::F;
     constexpr int STAGE_BYTES = 2 * TILE_BYTES;
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + TW - 1) / TW, tiles_m = (p.M + TW - 1) / TW;
     const int total = tiles_n * tiles_m * p.split_k;
-    int tile = blockIdx.x;
+    int tile = bid;
+    if (tile >= total) return;      // (grouped launches pad every problem to a multiple of 8 workgroups)
     if (total >= 16) {   // XCD-aware order (see gemm_nt.hip)
         const int xq = total >> 3, xr = total & 7, x = tile & 7;
         tile = x * xq + min(x, xr) + (tile >> 3);
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
 #pragma unroll
         for (int j = 0; j < F; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    const bool want_bg = BIAS && tn == 0 && wn == 0;
+    const bool want_bg = BIAS && p.bias_grad != nullptr && tn == 0 && wn == 0;
     const s8 ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
     const bfv8 ones = __builtin_bit_cast(bfv8, ones_bits);
 
@@ -231,6 +232,31 @@ __global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
         }
 }
 
+template <bool BIAS, bool MAPPED, int TW, int STAGES>
+__global__ __launch_bounds__(NTHR, 4) void tn_kernel(const vr_gemm_args p) {
+    tn_body<BIAS, MAPPED, TW, STAGES>(p, blockIdx.x);
+}
+
+// Several weight gradients in ONE launch (vr_gemm_group): the four Linears of a transformer block have 12 + 4 + 12 + 12 tiles
+// at 256 x 768 -- alone, at the coarse token split their fp32 atomics call for, each runs ~200 workgroups, one per CU, every
+// 64-token slice at the full load latency.  Together they put ~4 workgroups on every CU, which overlap one another's slices
+// exactly like the forward kernel's workgroups do, in a quarter of the launches.  Problem k owns workgroups
+// [first[k], first[k + 1]) (multiples of 8, so that the XCD-aware tile order of tn_body still sees its own XCD).
+constexpr int MAXG = 4;
+struct TnGroup {
+    vr_gemm_args a[MAXG];
+    int first[MAXG + 1];
+    int count;
+};
+template <bool MAPPED, int TW>
+__global__ __launch_bounds__(NTHR, 4) void tn_group_kernel(const TnGroup g) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < MAXG; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.first[i]) k = i;
+    tn_body<true, MAPPED, TW, 1>(g.a[k], (int)blockIdx.x - g.first[k]);
+}
+
 template <int TW, int STAGES> void launch_tw(const vr_gemm_args& a, hipStream_t stream, long long total) {
     const bool mapped = a.a_map.rpi != 0 || a.b_map.rpi != 0;
     if (mapped) {
@@ -244,13 +270,54 @@ template <int TW, int STAGES> void launch_tw(const vr_gemm_args& a, hipStream_t 
 
 }  // namespace vr_gemm_tn
 
+static bool tn_covers(const vr_gemm_args& a0) {
+    if (a0.in_dtype != VR_BF16 || !a0.a_trans || !a0.b_trans || !a0.atomic || a0.out_dtype != VR_F32) return false;
+    if (a0.lda % 8 || a0.ldb % 8 || ((uintptr_t)a0.A & 15) || ((uintptr_t)a0.B & 15)) return false;
+    if (a0.lda < (a0.M + 7) / 8 * 8 || a0.ldb < (a0.N + 7) / 8 * 8) return false;
+    return true;
+}
+
+// vr_gemm_group: `count` validated weight-gradient problems as one launch.  Returns false when any of them is not a plain
+// (un-mapped, automatic split) tn_kernel form -- the caller then issues them one by one.
+bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t stream, int n_cu) {
+    using namespace vr_gemm_tn;
+    if (count < 2 || count > MAXG) return false;
+    for (int i = 0; i < count; ++i) {
+        const vr_gemm_args& a = args[i];
+        if (!tn_covers(a) || a.a_map.rpi != 0 || a.b_map.rpi != 0 || a.split_k > 0) return false;
+    }
+    static const int knob_s = std::getenv("VITRES_TN_S") ? std::atoi(std::getenv("VITRES_TN_S")) : 32;
+    static const int knob_fill = std::getenv("VITRES_TN_GROUP_FILL") ? std::atoi(std::getenv("VITRES_TN_GROUP_FILL")) : 2;
+    // one slice count per workgroup for the whole group: ~knob_fill workgroups per CU in total (2 measured best inside the
+    // step: 8.52 ms against 8.61 at 4 and 8.76 at 6 -- fewer workgroups, fewer fp32 atomics), never finer than 8 slices
+    // (each workgroup pays |tile| x 4 B of atomics) nor coarser than the single-launch rule (VITRES_TN_S)
+    long long work = 0;
+    for (int i = 0; i < count; ++i)
+        work += (long long)((args[i].M + 127) / 128) * ((args[i].N + 127) / 128) * ((args[i].K + BT - 1) / BT);
+    long long spw = work / ((long long)knob_fill * n_cu);
+    spw = spw < 8 ? 8 : (spw > knob_s ? knob_s : spw);
+    TnGroup g;
+    g.count = count;
+    int next = 0;
+    for (int i = 0; i < count; ++i) {
+        g.a[i] = args[i];
+        const long long slices = (args[i].K + BT - 1) / BT;
+        const long long tiles = (long long)((args[i].M + 127) / 128) * ((args[i].N + 127) / 128);
+        long long split = (slices + spw - 1) / spw;
+        g.a[i].split_k = (int)(split < 1 ? 1 : split);
+        g.first[i] = next;
+        next += (int)((tiles * g.a[i].split_k + 7) / 8 * 8);
+    }
+    for (int i = count; i <= MAXG; ++i) g.first[i] = next;
+    hipLaunchKernelGGL((tn_group_kernel<false, 128>), dim3((unsigned)next), dim3(NTHR), 0, stream, g);
+    return true;
+}
+
 // Called by vr_gemm after validation.  Returns false when the form is not covered here (odd leading dimensions): the
 // general kernel takes those.
 bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_tn;
-    if (a0.in_dtype != VR_BF16 || !a0.a_trans || !a0.b_trans || !a0.atomic || a0.out_dtype != VR_F32) return false;
-    if (a0.lda % 8 || a0.ldb % 8 || ((uintptr_t)a0.A & 15) || ((uintptr_t)a0.B & 15)) return false;
-    if (a0.lda < (a0.M + 7) / 8 * 8 || a0.ldb < (a0.N + 7) / 8 * 8) return false;
+    if (!tn_covers(a0)) return false;
     vr_gemm_args a = a0;
     static const int knob_s = std::getenv("VITRES_TN_S") ? std::atoi(std::getenv("VITRES_TN_S")) : 32;
     static const int knob_tw = std::getenv("VITRES_TN_TW") ? std::atoi(std::getenv("VITRES_TN_TW")) : 0;

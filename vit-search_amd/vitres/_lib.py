@@ -42,6 +42,7 @@ class LnEpilogue(ctypes.Structure):
 SYMBOLS = {
     "vr_version": [],
     "vr_gemm": [ctypes.POINTER(GemmArgs), c_void_p],
+    "vr_gemm_group": [ctypes.POINTER(GemmArgs), ctypes.c_int32, c_void_p],
     "vr_gemm_ln": [ctypes.POINTER(GemmArgs), ctypes.POINTER(LnEpilogue), c_void_p],
     "vr_gemm_ln_supported": [c_int32],
     "vr_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],

@@ -144,12 +144,23 @@ def linear_dgrad(dy, W, dx, M, N_in, K_out, lddy, lddx, **kw):
 
 
 def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None, db=None, keep_rows=None,
-                 keep_cols=None, row_period=0, tokens_per_sample=0, sched=0):
+                 keep_cols=None, row_period=0, tokens_per_sample=0, sched=0, collect=None):
     """dw[N_out, K_in] += dy[M, N_out]^T @ x[M, K_in]  (fp32 atomics, split over tokens; db[N_out] += colsum(dy)).
-    keep_rows / keep_cols: per-sample kept prefix of dy's / x's channels -> fully masked tiles are skipped."""
-    K.gemm(dy, x, dw, M=N_out, N=K_in, K=M, lda=lddy, ldb=ldx, ldc=ldw or K_in, a_trans=True, b_trans=True,
-           atomic=True, split_k=0, a_map=a_map, b_map=b_map, bias_grad=db,
-           keep_k=keep_rows, keep_n=keep_cols, k_period=row_period, rows_in=tokens_per_sample, sched=sched)
+    keep_rows / keep_cols: per-sample kept prefix of dy's / x's channels -> fully masked tiles are skipped.
+    collect: a list -> the call is appended to it instead of being launched (K.gemm_group launches the list as one kernel)."""
+    kw = dict(M=N_out, N=K_in, K=M, lda=lddy, ldb=ldx, ldc=ldw or K_in, a_trans=True, b_trans=True,
+              atomic=True, split_k=0, a_map=a_map, b_map=b_map, bias_grad=db,
+              keep_k=keep_rows, keep_n=keep_cols, k_period=row_period, rows_in=tokens_per_sample, sched=sched)
+    if collect is not None:
+        collect.append((dy, x, dw, kw))
+    else:
+        K.gemm(dy, x, dw, **kw)
+
+
+# VITRES_WGRAD_GROUP=1: the four weight gradients of a transformer block (fc2, fc1, proj, qkv) are issued as ONE vr_gemm_group
+# launch on the side stream once the last of their operands (dqkv) exists, instead of four launches of ~200 workgroups each.
+WGRAD_GROUP = _os.environ.get('VITRES_WGRAD_GROUP', '1') != '0'
+_block_wgrads = []       # collected (dy, x, dw, kwargs) of the block being walked backwards
 
 
 # --------------------------------------------------------------------------------------------------
@@ -199,23 +210,32 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     if gt is None:
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                   # d(branch output), compute dtype
 
+    grp = _block_wgrads if (ov and WGRAD_GROUP) else None
+
     def wgrad_proj():
         linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"], keep_rows=out_keep, keep_cols=attn_keep,
-                     tokens_per_sample=N, sched=sch)
-    if ov and not PROJ_LATE:
+                     tokens_per_sample=N, sched=sch, collect=grp)
+    if grp is not None:
+        wgrad_proj()
+    elif ov and not PROJ_LATE:
         on_side(wgrad_proj, gt)
     elif not ov:
         wgrad_proj()
     d_o = torch.empty((B, N, HD), dtype=dt, device=x.device)
     linear_dgrad(gt, p["proj"], d_o, M, HD, C, C, HD, keep_n=attn_keep, rows_in=N, keep_k=out_keep, sched=sch)
     dqkv = K.attn_bwd(qkv, o, d_o, lse, attn_keep, B, N, H, D, cfg["scale"])
-    if ov and PROJ_LATE:
+    if ov and PROJ_LATE and grp is None:
         on_side(wgrad_proj, gt)
 
     def wgrad_qkv():
         linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C, db=grads["qkv.b"], keep_rows=attn_keep,
-                     keep_cols=embed_keep, row_period=HD, tokens_per_sample=N, sched=sch)
-    if ov:
+                     keep_cols=embed_keep, row_period=HD, tokens_per_sample=N, sched=sch, collect=grp)
+    if grp is not None:
+        wgrad_qkv()
+        calls = list(grp)                                   # fc2, fc1 (MLP branch), proj, qkv: every operand exists now
+        del grp[:]
+        on_side(lambda: K.gemm_group(calls), *[t_ for c_ in calls for t_ in c_[:2]])
+    elif ov:
         on_side(wgrad_qkv, dqkv)
     else:
         wgrad_qkv()
@@ -267,10 +287,12 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     if gt is None:
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
 
+    grp = _block_wgrads if (ov and WGRAD_GROUP) else None
+
     def wgrad_fc2():
         linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"], keep_rows=out_keep, keep_cols=mlp_keep,
-                     tokens_per_sample=N, sched=sch)
-    if ov:
+                     tokens_per_sample=N, sched=sch, collect=grp)
+    if ov and grp is None:
         on_side(wgrad_fc2, gt)
     else:
         wgrad_fc2()
@@ -279,8 +301,8 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
 
     def wgrad_fc1():
         linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"], keep_rows=mlp_keep, keep_cols=embed_keep,
-                     tokens_per_sample=N, sched=sch)
-    if ov:
+                     tokens_per_sample=N, sched=sch, collect=grp)
+    if ov and grp is None:
         on_side(wgrad_fc1, du)
     else:
         wgrad_fc1()

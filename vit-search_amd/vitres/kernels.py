@@ -149,6 +149,32 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     return out
 
 
+def gemm_group(calls):
+    """calls: [(a, b, out, kwargs)] -- the arguments of gemm() for each problem.  One vr_gemm_group launch (weight gradients of
+    a transformer block share the CUs); semantics are exactly those of issuing the calls one after the other."""
+    if len(calls) == 1:
+        a, b, out, kw = calls[0]
+        return gemm(a, b, out, **kw)
+    arr = (GemmArgs * len(calls))()
+    for i, (a, b, out, kw) in enumerate(calls):
+        arr[i] = _gemm_args(a, b, out, **kw)
+    if PROFILE is None:
+        _lib.check(_lib.lib().vr_gemm_group(arr, len(calls), _stream()), "vr_gemm_group")
+        return
+    flops = dense = alg = 0.0
+    for a, b, out, kw in calls:
+        f, by = _gemm_work(a, out, kw["M"], kw["N"], kw["K"], kw.get("a_trans", False), kw.get("rows_in", 0), kw.get("keep_k"),
+                           kw.get("keep_n"), kw.get("k_period", 0), kw.get("n_period", 0), atomic=kw.get("atomic", False))
+        flops, dense, alg = flops + f, dense + 2.0 * kw["M"] * kw["N"] * kw["K"], alg + by
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(_lib.lib().vr_gemm_group(arr, len(calls), _stream()), "vr_gemm_group")
+    e1.record()
+    a0, kw0 = calls[0][0], calls[0][3]
+    PROFILE.append((("bf16" if a0.dtype == torch.bfloat16 else "f32", int(kw0.get("a_trans", False)),
+                     int(kw0.get("b_trans", False)), 0), flops, dense, alg, e0, e1))
+
+
 def _gemm_work(a, out, M, N, K, a_trans, rows_in, keep_k, keep_n, k_period, n_period, out2=None, resid=None, dact_u=None,
                pos=None, bias=None, atomic=False):
     """(kept FLOPs, algorithmic HBM bytes) of one vr_gemm launch, both from the KEPT (un-masked) widths of the samples it
