@@ -196,6 +196,11 @@ def main():
                                           optimizer=opt if opt_in_graph else None)
 
     def step(i):
+        # the reference draws SwitchTokenMix's two sample permutations from the CPU generator every iteration
+        # (token_mixup.py:104-106,126-127) BEFORE the forward saves / restores its state (engine.py:119-165): without them every
+        # step of a synthetic-data run would re-draw the same architectures
+        torch.randperm(B // 2)
+        torch.randperm(B - B // 2)
         if graphed is None:
             return eager_step(i)
         if graphed.optimizer is not None:

@@ -281,6 +281,10 @@ int vr_batchsum(const float* in, float* out, int32_t B, int64_t inner, vr_stream
  */
 int vr_im2col_patch(const float* img, void* col, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t P,
                     int32_t ldk, int32_t dtype, vr_stream_t stream);
+/* The same with output sample b read from image sample_map[b] (NULL: identity): the batch re-ordering of the arch-grouped
+ * execution order folded into the gather (one pass over the images instead of index_select + im2col). */
+int vr_im2col_patch_map(const float* img, void* col, const int64_t* sample_map, int32_t B, int32_t Cin, int32_t H, int32_t W,
+                        int32_t P, int32_t ldk, int32_t dtype, vr_stream_t stream);
 
 /* token rows of the embedding: x[b,t,c] = (tokens[t,c] + pos[t,c]) masked by keep, t < num_tokens (1: class token; 2: class +
  * distillation token of the *_distill_* factories) (vit_sr_supernet.py:399-407) */

@@ -260,12 +260,14 @@ def batchsum(x, out):
     return out
 
 
-def im2col_patch(img, P, ldk, out_dtype):
+def im2col_patch(img, P, ldk, out_dtype, sample_map=None, out=None):
+    if sample_map is not None:
+        img = img.index_select(0, sample_map)
     B, Cin, H, W = img.shape
     col = F.unfold(img, kernel_size=P, stride=P).transpose(1, 2).reshape(B * (H // P) * (W // P), Cin * P * P)
-    out = torch.zeros(col.shape[0], ldk, dtype=out_dtype)
-    out[:, :col.shape[1]] = col.to(out_dtype)
-    return out
+    res = torch.zeros(col.shape[0], ldk, dtype=out_dtype) if out is None else out.zero_()
+    res[:, :col.shape[1]] = col.to(out_dtype)
+    return res
 
 
 def embed_cls(tokens, pos, x, keep, num_tokens=1):

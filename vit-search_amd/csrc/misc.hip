@@ -194,10 +194,12 @@ __global__ __launch_bounds__(256) void token_mean_bwd_kernel(const T* __restrict
 // so a gather per patch ran at 0.9 TB/s.
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img, T* __restrict__ col, int B,
-                                                           int Cin, int H, int W, int P, int ldk) {
+                                                           int Cin, int H, int W, int P, int ldk,
+                                                           const long long* __restrict__ sample_map) {
     extern __shared__ __attribute__((aligned(16))) float band[];      // [Cin][P][W]
     const int gw = W / P, gh = H / P;
-    const int py = blockIdx.x % gh, b = blockIdx.x / gh;
+    const int py = blockIdx.x % gh, bo = blockIdx.x / gh;             // output sample bo reads image sample_map[bo]
+    const int b = sample_map ? (int)sample_map[bo] : bo;
     const int rows = Cin * P;
     const bool v4 = (W % 4) == 0;
     if (v4) {
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restri
     }
     __syncthreads();
     const int K = Cin * P * P;
-    T* out = col + ((long long)b * gh + py) * gw * ldk;
+    T* out = col + ((long long)bo * gh + py) * gw * ldk;
     for (int idx = threadIdx.x; idx < gw * ldk; idx += blockDim.x) {
         const int px = idx / ldk, k = idx % ldk;
         float v = 0.f;
@@ -506,14 +508,20 @@ extern "C" int vr_batchsum(const float* in, float* out, int32_t B, int64_t inner
 
 extern "C" int vr_im2col_patch(const float* img, void* col, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t P,
                                int32_t ldk, int32_t dtype, vr_stream_t stream) {
+    return vr_im2col_patch_map(img, col, nullptr, B, Cin, H, W, P, ldk, dtype, stream);
+}
+
+extern "C" int vr_im2col_patch_map(const float* img, void* col, const int64_t* sample_map, int32_t B, int32_t Cin, int32_t H,
+                                   int32_t W, int32_t P, int32_t ldk, int32_t dtype, vr_stream_t stream) {
     if (!img || !col || B <= 0 || P <= 0 || H % P || W % P || ldk < Cin * P * P) return VR_EINVAL;
+    const long long* smap = reinterpret_cast<const long long*>(sample_map);
     dim3 grid(B * (H / P));
     const size_t lds = (size_t)Cin * P * W * sizeof(float);
     if (lds > 64 * 1024) return VR_EUNSUPPORTED;
     if (dtype == VR_F32)
-        hipLaunchKernelGGL((im2col_patch_kernel<float>), grid, dim3(256), lds, (hipStream_t)stream, img, (float*)col, B, Cin, H, W, P, ldk);
+        hipLaunchKernelGGL((im2col_patch_kernel<float>), grid, dim3(256), lds, (hipStream_t)stream, img, (float*)col, B, Cin, H, W, P, ldk, smap);
     else if (dtype == VR_BF16)
-        hipLaunchKernelGGL((im2col_patch_kernel<bf16_t>), grid, dim3(256), lds, (hipStream_t)stream, img, (bf16_t*)col, B, Cin, H, W, P, ldk);
+        hipLaunchKernelGGL((im2col_patch_kernel<bf16_t>), grid, dim3(256), lds, (hipStream_t)stream, img, (bf16_t*)col, B, Cin, H, W, P, ldk, smap);
     else
         return VR_EUNSUPPORTED;
     VR_CHECK_LAUNCH();

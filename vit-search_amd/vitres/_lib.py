@@ -64,6 +64,7 @@ SYMBOLS = {
     "vr_token_mean_bwd": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "vr_batchsum": [c_void_p, c_void_p, c_int32, c_int64, c_void_p],
     "vr_im2col_patch": [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p],
+    "vr_im2col_patch_map": [c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p],
     "vr_embed_cls": [c_void_p] * 4 + [c_int32] * 4 + [c_void_p],
     "vr_sr_im2col": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
     "vr_sr_col2im": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],

@@ -248,9 +248,22 @@ class GraphedTrainStep:
                 self._step_body(None)
         torch.cuda.current_stream().wait_stream(side)
         plan = model.sample_plan(B)
-        self.keep_static = None
-        if plan.rows:
-            self.keep_static = torch.stack(plan.rows).to(torch.int32).to(samples.device)
+        # what changes per replay reaches the graph through ONE static int32 buffer: the keep rows of every ChannelDrop and the
+        # DropPath scale vectors (bit-cast floats), both made on the host (model.plan_host_buffer) and uploaded from a ring of
+        # pinned staging blocks; for the type-0 patch embedding the patch gather runs in front of the graph, straight from the
+        # caller's batch (no copy of the images into a static buffer, no re-ordering pass)
+        self.keep_static = None                                   # (name kept: tests / tools look at it)
+        self._plan_nk, self._stage, self._stage_i = 0, [], 0
+        flat, nk = model.plan_host_buffer(plan)
+        if flat.size:
+            self.keep_static = torch.from_numpy(flat).to(samples.device)
+            self._plan_nk = nk
+            self._stage = [[torch.empty(flat.size, dtype=torch.int32).pin_memory(), None] for _ in range(64)]
+        self.col_static = None
+        if getattr(model, "embed_type", None) == 0 and model.compute_dtype == torch.bfloat16:
+            ldk = (model.in_chans * model.patch_size ** 2 + 7) // 8 * 8
+            self.col_static = torch.empty((B * model.patch_embed.num_patches, ldk), dtype=torch.bfloat16, device=samples.device)
+            self._gather(samples, plan)
         model.zero_grad(set_to_none=True)
         # split_for_sync = number of backward parts (True = 2): part k's graph is followed by the all-reduce of the arena range
         # it completed, overlapping part k+1 (a cut in front of every spatial reduction, counted from the end)
@@ -276,7 +289,9 @@ class GraphedTrainStep:
                     model._bwd_split = opt_cut[0]
                     model._bwd_join_parts = False                  # the second part follows in the same capture
             with torch.cuda.graph(self.graph):
-                plan.keep_dev = self.keep_static
+                if self.keep_static is not None:
+                    model.attach_plan_buffer(plan, self.keep_static, self._plan_nk)
+                plan.embed_col = self.col_static
                 self.loss = self._step_body(plan)
                 if self.optimizer is not None:
                     from . import functional as Fn
@@ -309,6 +324,15 @@ class GraphedTrainStep:
         self.loss = self.loss.detach()
         torch.random.set_rng_state(rng)
 
+    def _gather(self, samples, plan):
+        """Patch gather of the caller's batch into the graph's static patchify operand (internal, arch-grouped sample order)."""
+        from . import kernels as K
+        smap = None
+        if plan.order is not None:
+            smap, _ = self.model._order_tensors(plan.order, samples.device)
+        K.im2col_patch(samples.contiguous().float(), self.model.patch_size, self.col_static.shape[1], torch.bfloat16,
+                       sample_map=smap, out=self.col_static)
+
     def _step_body(self, plan):
         """forward + loss + (first part of the) backward of one step; returns the loss tensor."""
         if self.fused_loss:
@@ -336,9 +360,20 @@ class GraphedTrainStep:
         if rng is not None:
             torch.random.set_rng_state(rng)
         if self.keep_static is not None:
-            self.keep_static.copy_(torch.stack(plan.rows).to(torch.int32).pin_memory(), non_blocking=True)
-        if samples.data_ptr() != self.x.data_ptr():
+            flat, _ = self.model.plan_host_buffer(plan)
+            slot = self._stage[self._stage_i % len(self._stage)]
+            self._stage_i += 1
+            if slot[1] is not None:
+                slot[1].synchronize()                             # the host runs ahead of the device: the block's last copy is done?
+            slot[0].numpy()[:] = flat
+            self.keep_static.copy_(slot[0], non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+        if self.col_static is not None:
+            self._gather(samples, plan)                           # reads the caller's tensor directly
+        elif samples.data_ptr() != self.x.data_ptr():
             self.x.copy_(samples, non_blocking=True)
+        if targets.data_ptr() != self.t.data_ptr():
             self.t.copy_(targets, non_blocking=True)
             if self.pt is not None:
                 self.pt.copy_(patch_targets, non_blocking=True)

@@ -383,13 +383,16 @@ def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep, gt=None, next_cast=
 # --------------------------------------------------------------------------------------------------
 # patch embedding (type 0: timm PatchEmbed == one patchify GEMM)
 # --------------------------------------------------------------------------------------------------
-def embed0_fwd(img, p, cfg, keep, save):
+def embed0_fwd(img, p, cfg, keep, save, sample_map=None, col=None):
+    """sample_map: internal sample b is the caller's image sample_map[b] (arch-grouped execution order);
+    col: the gathered patch matrix when the caller already made it (engine.GraphedTrainStep gathers outside the graph)."""
     B = img.shape[0]
     T = cfg.get("tokens", 1)
     P, C, N = cfg["patches"], cfg["dim"], cfg["patches"] + T
     dt = cfg["dtype"]
     ldk = p["proj"].ld
-    col = K.im2col_patch(img, cfg["patch"], ldk, dt)
+    if col is None:
+        col = K.im2col_patch(img, cfg["patch"], ldk, dt, sample_map=sample_map)
     x = torch.empty((B, N, C), dtype=torch.float32, device=img.device)
     K.gemm(col, p["proj"].w_c, x, M=B * P, N=C, K=ldk, lda=ldk, ldb=ldk, ldc=C, bias=p["proj"].b, pos=p["pos"][0, T:],
            keep_n=keep, rows_in=P, c_map=(P, N, T))

@@ -329,11 +329,12 @@ def batchsum(x, out):
     return out
 
 
-def im2col_patch(img, P, ldk, out_dtype):
+def im2col_patch(img, P, ldk, out_dtype, sample_map=None, out=None):
+    """sample_map (int64 [B], device): output sample b is image sample_map[b]; out: a preallocated col matrix."""
     B, Cin, H, W = img.shape
-    col = torch.empty((B * (H // P) * (W // P), ldk), dtype=out_dtype, device=img.device)
-    _lib.check(_lib.lib().vr_im2col_patch(_p(img), _p(col), B, Cin, H, W, P, ldk, _dtcode(out_dtype), _stream()),
-               "vr_im2col_patch")
+    col = out if out is not None else torch.empty((B * (H // P) * (W // P), ldk), dtype=out_dtype, device=img.device)
+    _lib.check(_lib.lib().vr_im2col_patch_map(_p(img), _p(col), _p(sample_map), B, Cin, H, W, P, ldk, _dtcode(out_dtype),
+                                              _stream()), "vr_im2col_patch_map")
     return col
 
 

@@ -67,6 +67,27 @@ class ChannelDrop(nn.Module):
             'In forward(), batch size is not divisible by sub-batch size (examples per arch).'
         return rows[:batch // self.example_per_arch].repeat(self.example_per_arch)
 
+    def sample_groups(self, batch, channels, training=None):
+        """The same draw as sample_keep (one torch.randperm on the CPU generator, reference forward_mask :93-111) returned as
+        the short numpy vector g with keep[b] = g[b % len(g)]: the first batch / example_per_arch permuted table rows (one per
+        architecture group; `rows[:G].repeat(epa)`), or a single entry (single_arch, eval, fixed mask)."""
+        import numpy as np
+        if training is None:
+            training = self.training
+        if self.fixed_keep is not None:
+            return np.array([int(self.fixed_keep)], dtype=np.int64)
+        if not training:
+            return np.array([channels], dtype=np.int64)
+        if self.table is None:
+            self._build_table(batch, channels)
+            self._table_np = self.table.numpy()
+        perm = torch.randperm(self.table.shape[0]).numpy()
+        if self.single_arch:
+            return self._table_np[perm[0:1]]
+        assert batch % self.example_per_arch == 0, \
+            'In forward(), batch size is not divisible by sub-batch size (examples per arch).'
+        return self._table_np[perm[:batch // self.example_per_arch]]
+
     def forward(self, x):
         raise RuntimeError('ChannelDrop has no standalone device op in the HIP path: its multiply is fused into the '
                            'neighbouring kernels; use sample_keep() (host) and the parent model forward.')

@@ -95,12 +95,17 @@ class SpatialReductionPatchEmbedding(nn.Module):
 
 class _Plan:
     """Host-side description of one forward: which keep vector / drop-path scale each layer uses."""
-    __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch", "n_dp", "order", "dp_noise")
+    __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch", "n_dp", "order", "dp_noise", "host", "embed_col",
+                 "keeps_host", "scales_host", "embed_map")
 
     def __init__(self):
         self.rows, self.layers, self.keep_dev, self.head, self.scales, self.batch, self.n_dp = [], [], None, None, None, 0, 0
         self.order = None
         self.dp_noise = None     # test hook: the uniform draws of drop_path (nets/drop.py:23), [n_dp, B] in the CALLER's sample order
+        self.host = None         # (int32 [n_rows, B] keeps, float32 [n_dp, B] DropPath scales) on the host, internal row order
+        self.keeps_host = self.scales_host = None
+        self.embed_map = None    # int64 device map: internal sample -> caller's sample, consumed by the type-0 patch gather
+        self.embed_col = None    # type-0 patch embedding: the patchify operand already gathered (engine.GraphedTrainStep)
 
     def add(self, keep):
         if keep is None:
@@ -370,43 +375,69 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
     # ---- host-side mask plan -----------------------------------------------------------------------
     def sample_plan(self, B):
         """Host side of one forward: sample every ChannelDrop (reference RNG protocol, call order) and lay out which
-        keep row / drop-path scale each layer uses.  No device work -- see _upload_plan."""
+        keep row / drop-path scale each layer uses.  No device work -- see _upload_plan.
+        Every keep vector of a forward is `g.repeat(.)` of a short group vector g (one entry per architecture group,
+        channel_drop.py:101-109): the plan is assembled on the group vectors and expanded to [rows, B] once (numpy)."""
         plan = _Plan()
         plan.batch = B
         tr = self.training
-        log = []
+        groups = []                      # group vectors in ChannelDrop call order (last_keeps)
 
         def samp(cd, ch):
             if cd is None:
                 return None
-            k = cd.sample_keep(B, ch, tr)
-            log.append(k)
-            return k
+            g = cd.sample_groups(B, ch, tr)
+            groups.append(g)
+            return g
+        rows = []                        # group vectors of the plan's keep rows
+
+        def add(g):
+            if g is None:
+                return None
+            rows.append(g)
+            return len(rows) - 1
+
+        def gmin(a_, b_):                # AND of two prefix masks; group vectors have 1 or G entries
+            return np.minimum(a_, b_)
+        recipe = self.__dict__.get("_plan_recipe")
+        if recipe is None:               # the module walk, once: (kind, ChannelDrops, widths, has DropPath) per entry of self.blocks
+            recipe = []
+            for blk in self.blocks:
+                if isinstance(blk, Block):
+                    dpm = blk.drop_path
+                    recipe.append((1, blk.attn.channel_drop_layer, blk.attn.num_heads * blk.attn.head_dim, blk.layer_drop,
+                                   blk.norm1.num_channels, blk.mlp.channel_drop_layer, blk.mlp.fc1.out_features,
+                                   (not isinstance(dpm, nn.Identity)) and dpm.drop_prob > 0))
+                elif isinstance(blk, SpatialReductionPatchEmbedding):
+                    recipe.append((2, blk.channel_drop, blk.token_transform.out_features))
+                else:
+                    recipe.append((0,))
+            self.__dict__["_plan_recipe"] = recipe
         embed_keep = samp(self.embed_channel_drop, self.embed_dim)
         layer_keep = None
-        e_idx = plan.add(embed_keep)
+        e_idx = add(embed_keep)
         plan.layers.append({"embed": e_idx})
         n_dp = 0
-        for blk in self.blocks:
-            if isinstance(blk, Block):
-                hd = blk.attn.num_heads * blk.attn.head_dim
-                ka = samp(blk.attn.channel_drop_layer, hd)
+        for ent in recipe:
+            if ent[0] == 1:
+                _, cd_a, hd, cd_l, cn, cd_m, fo, has_dp = ent
+                ka = samp(cd_a, hd)
                 cur = None
-                if blk.layer_drop is not None:
-                    cur = samp(blk.layer_drop, blk.norm1.num_channels)
+                if cd_l is not None:
+                    cur = samp(cd_l, cn)
                     if layer_keep is not None:
-                        cur = torch.minimum(cur, layer_keep)
+                        cur = gmin(cur, layer_keep)
                 if embed_keep is not None:
-                    cur = embed_keep if cur is None else torch.minimum(cur, embed_keep)
-                km = samp(blk.mlp.channel_drop_layer, blk.mlp.fc1.out_features)
-                dp = tr and not isinstance(blk.drop_path, nn.Identity) and blk.drop_path.drop_prob > 0
-                plan.layers.append({"embed": e_idx, "attn": plan.add(ka), "mlp": plan.add(km), "out": plan.add(cur),
+                    cur = embed_keep if cur is None else gmin(cur, embed_keep)
+                km = samp(cd_m, fo)
+                dp = tr and has_dp
+                plan.layers.append({"embed": e_idx, "attn": add(ka), "mlp": add(km), "out": add(cur),
                                     "dp": (n_dp if dp else None)})
                 n_dp += 2 if dp else 0
                 layer_keep = cur
-            elif isinstance(blk, SpatialReductionPatchEmbedding):
-                nk = samp(blk.channel_drop, blk.token_transform.out_features)
-                n_idx = plan.add(nk)
+            elif ent[0] == 2:
+                nk = samp(ent[1], ent[2])
+                n_idx = add(nk)
                 plan.layers.append({"embed": e_idx, "new": n_idx})
                 embed_keep, e_idx, layer_keep = nk, n_idx, None
             else:
@@ -414,20 +445,55 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 layer_keep = None
         plan.head = e_idx
         plan.n_dp = n_dp
-        self.last_keeps = log
         # Arch-grouped execution order: sample b runs architecture (b mod G), G = B / example_per_arch
         # (channel_drop.py:101-105 tiles the G sampled rows).  Running the batch as G contiguous groups makes every
         # GEMM tile / wgrad split see ONE architecture, so masked K slices and output tiles can be skipped.  Results
         # are returned in the caller's order; nothing but the internal row order changes.
         cd = self.embed_channel_drop
-        if tr and cd is not None and plan.rows and cd.example_per_arch and B % cd.example_per_arch == 0:
+        if tr and cd is not None and rows and cd.example_per_arch and B % cd.example_per_arch == 0:
             epa = cd.example_per_arch
             G = B // epa
             if 1 < G < B:
                 plan.order = [j * G + g for g in range(G) for j in range(epa)]
-                idx = torch.tensor(plan.order)
-                plan.rows = [r[idx] for r in plan.rows]
+
+        def expand(gs, who):             # [len(gs), B]: entry b of a group vector g is g[b % len(g)]
+            if not gs:
+                return None
+            out = np.empty((len(gs), B), dtype=np.int64)
+            for i, g in enumerate(gs):
+                out[i] = g[who % len(g)]
+            return out
+        caller = np.arange(B)
+        plan.keeps_host = expand(rows, np.asarray(plan.order) if plan.order is not None else caller)
+        plan.rows = list(torch.from_numpy(plan.keeps_host)) if rows else []
+        log = expand(groups, caller)
+        self.last_keeps = list(torch.from_numpy(log)) if groups else []
         return plan
+
+    def _dp_scales_host(self, plan):
+        """DropPath scales floor(keep_prob + u) / keep_prob (nets/drop.py:21-26) of one forward, [n_dp, B] float32 on the host in
+        the internal row order.  u comes from plan.dp_noise (tests) or from a private CPU generator: the reference draws on the
+        device, so the draws never touch the CPU generator the ChannelDrops consume -- neither do these."""
+        B = plan.batch
+        kp = getattr(self, "_dp_keep_prob_host", None)
+        if kp is None or kp.shape[0] != plan.n_dp:
+            vals = []
+            for blk in self.blocks:
+                if isinstance(blk, Block) and not isinstance(blk.drop_path, nn.Identity) and blk.drop_path.drop_prob > 0:
+                    vals += [1.0 - blk.drop_path.drop_prob] * 2
+            kp = np.asarray(vals, dtype=np.float32).reshape(-1, 1)
+            self._dp_keep_prob_host = kp
+        if plan.dp_noise is not None:                      # injected draws (caller order) -> the internal, arch-grouped row order
+            noise = torch.as_tensor(plan.dp_noise, dtype=torch.float32).reshape(plan.n_dp, B).numpy()
+            if plan.order is not None:
+                noise = noise[:, np.asarray(plan.order)]
+        else:
+            gen = getattr(self, "_dp_gen", None)
+            if gen is None:
+                gen = self._dp_gen = torch.Generator(device="cpu")
+                gen.manual_seed((torch.initial_seed() * 2654435761 + 97) % (2 ** 63))
+            noise = torch.rand(plan.n_dp, B, generator=gen).numpy()
+        return (np.floor(kp + noise.astype(np.float32)) / kp).astype(np.float32)
 
     def _order_tensors(self, order, device):
         cache = getattr(self, "_order_cache", None)
@@ -438,32 +504,47 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             self._order_cache = cache
         return cache[1], cache[2]
 
-    def _upload_plan(self, plan, device):
-        """Device side of a plan: one H2D copy of all keep rows (unless a static buffer was attached, e.g. by a
-        captured hipGraph) and the drop-path scale vectors."""
+    def plan_host_buffer(self, plan):
+        """(keeps int32 [n_rows, B], scales float32 [n_dp, B]) of a plan as ONE flat int32 host array (scales bit-cast), the unit
+        a training step uploads -- see engine.GraphedTrainStep."""
+        if plan.keeps_host is None and plan.rows:          # a plan assembled row by row (evo_eval.plan_for_subnet)
+            plan.keeps_host = torch.stack([torch.as_tensor(r) for r in plan.rows]).numpy()
+        nk = 0 if plan.keeps_host is None else plan.keeps_host.size
+        ns = plan.n_dp * plan.batch
+        flat = np.empty(nk + ns, dtype=np.int32)
+        if nk:
+            flat[:nk] = plan.keeps_host.reshape(-1)
+        if ns:
+            if plan.scales_host is None:
+                plan.scales_host = self._dp_scales_host(plan)
+            flat[nk:] = plan.scales_host.reshape(-1).view(np.int32)
+        return flat, nk
+
+    def attach_plan_buffer(self, plan, dev_flat, nk):
+        """Point a plan at a device copy of plan_host_buffer()'s array."""
         B = plan.batch
-        if plan.rows and plan.keep_dev is None:
-            host = torch.stack(plan.rows).to(torch.int32)
+        if nk:
+            plan.keep_dev = dev_flat[:nk].view(-1, B)
+        if plan.n_dp:
+            plan.scales = dev_flat[nk:nk + plan.n_dp * B].view(torch.float32).view(plan.n_dp, B)
+
+    def _upload_plan(self, plan, device):
+        """Device side of a plan: one H2D copy of all keep rows and DropPath scale vectors (unless a static buffer was
+        attached, e.g. by a captured hipGraph)."""
+        need_k = (plan.keeps_host is not None or bool(plan.rows)) and plan.keep_dev is None
+        need_s = plan.n_dp and plan.scales is None
+        if need_k or need_s:
+            flat, nk = self.plan_host_buffer(plan)
+            host = torch.from_numpy(flat)
             if device.type == 'cuda':
                 host = host.pin_memory()
-            plan.keep_dev = host.to(device, non_blocking=True)
-        if plan.n_dp and plan.scales is None:
-            kp = getattr(self, "_dp_keep_prob", None)
-            if kp is None or kp.device != device or kp.shape[0] != plan.n_dp:      # built once (not under graph capture)
-                vals = []
-                for blk in self.blocks:
-                    if isinstance(blk, Block) and not isinstance(blk.drop_path, nn.Identity) and blk.drop_path.drop_prob > 0:
-                        vals += [1.0 - blk.drop_path.drop_prob] * 2
-                kp = torch.tensor(vals, dtype=torch.float32).unsqueeze(1).to(device)
-                self._dp_keep_prob = kp
-            if plan.dp_noise is not None:                  # injected draws (caller order) -> the internal, arch-grouped row order
-                noise = torch.as_tensor(plan.dp_noise, dtype=torch.float32).reshape(plan.n_dp, B)
-                if plan.order is not None:
-                    noise = noise[:, torch.as_tensor(plan.order)]
-                noise = noise.to(device)
-            else:
-                noise = torch.rand(plan.n_dp, B, device=device)
-            plan.scales = torch.floor(kp + noise) / kp
+            dev = host.to(device, non_blocking=True)
+            keep_dev, scales = plan.keep_dev, plan.scales
+            self.attach_plan_buffer(plan, dev, nk)
+            if not need_k:
+                plan.keep_dev = keep_dev
+            if not need_s:
+                plan.scales = scales
         return plan
 
     # ---- forward -----------------------------------------------------------------------------------
@@ -486,7 +567,10 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         x = x.contiguous().float()
         if plan.order is not None:
             fwd_idx, inv_idx = self._order_tensors(plan.order, x.device)
-            x = x.index_select(0, fwd_idx)
+            if self.embed_type == _TYPE_IS_EMBED:
+                plan.embed_map = fwd_idx             # the patch gather reads the images in the internal order (vr_im2col_patch_map)
+            else:
+                x = x.index_select(0, fwd_idx)
         out = _ViTResFn.apply(self, x, plan, with_patch, *params)
         if plan.order is not None:
             out = tuple(o.index_select(0, inv_idx) for o in out) if isinstance(out, tuple) else out.index_select(0, inv_idx)
@@ -520,7 +604,10 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         smap = None
         if plan.order is not None:
             smap, _ = self._order_tensors(plan.order, x.device)
-            x = x.index_select(0, smap)
+            if self.embed_type == _TYPE_IS_EMBED:
+                plan.embed_map = smap                # the patch gather reads the images in the internal order (vr_im2col_patch_map)
+            elif plan.embed_col is None:
+                x = x.index_select(0, smap)
         with torch.no_grad():
             cls, pat, tape = self._run_forward(x, plan, with_patch, True)
             loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=x.device)
@@ -594,7 +681,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         ep = self._embed_params()
         ekeep = plan.k(plan.layers[0]["embed"])
         if self.embed_type == _TYPE_IS_EMBED:
-            h, sv = Fn.embed0_fwd(x, ep, ecfg, ekeep, save)
+            h, sv = Fn.embed0_fwd(x, ep, ecfg, ekeep, save, sample_map=plan.embed_map, col=plan.embed_col)
         else:
             from .. import stem
             h, sv = stem.embed_conv_fwd(self, x, ep, ecfg, ekeep, save)
