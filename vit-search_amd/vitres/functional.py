@@ -91,6 +91,8 @@ def on_side(fn, *keepalive, defer=True):
 
 def join_side():
     """Current stream waits for ALL side-stream work issued so far (and releases every tensor kept for it)."""
+    if _block_wgrads:
+        flush_wgrads()
     flush_side()
     if _pending or _side_streams:
         main = torch.cuda.current_stream()
@@ -161,6 +163,20 @@ def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_m
 # launch on the side stream once the last of their operands (dqkv) exists, instead of four launches of ~200 workgroups each.
 WGRAD_GROUP = _os.environ.get('VITRES_WGRAD_GROUP', '1') != '0'
 _block_wgrads = []       # collected (dy, x, dw, kwargs) of the block being walked backwards
+# VITRES_WGRAD_EARLY=1 (measured slower, 8.73-8.91 against 8.47 ms: the attention kernels lose more to the contention than the
+# LayerNorm backward gains): the group is launched in front of the attention core (fc2, fc1, proj of this block + qkv of the
+# block before), so that it runs beside the attention kernels and the qkv data gradient instead of beside the HBM-bound
+# LayerNorm backward that closes the block
+WGRAD_EARLY = _os.environ.get('VITRES_WGRAD_EARLY', '0') != '0'
+
+
+def flush_wgrads():
+    """Launch the collected weight gradients as one group on the side stream (no-op when nothing is pending)."""
+    if not _block_wgrads:
+        return
+    calls = list(_block_wgrads)
+    del _block_wgrads[:]
+    on_side(lambda: K.gemm_group(calls), *[t_ for c_ in calls for t_ in c_[:2]])
 
 
 # --------------------------------------------------------------------------------------------------
@@ -217,6 +233,8 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
                      tokens_per_sample=N, sched=sch, collect=grp)
     if grp is not None:
         wgrad_proj()
+        if WGRAD_EARLY:
+            flush_wgrads()                                  # [qkv of the previous block,] fc2, fc1, proj: beside the attention core
     elif ov and not PROJ_LATE:
         on_side(wgrad_proj, gt)
     elif not ov:
@@ -232,9 +250,8 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
                      keep_cols=embed_keep, row_period=HD, tokens_per_sample=N, sched=sch, collect=grp)
     if grp is not None:
         wgrad_qkv()
-        calls = list(grp)                                   # fc2, fc1 (MLP branch), proj, qkv: every operand exists now
-        del grp[:]
-        on_side(lambda: K.gemm_group(calls), *[t_ for c_ in calls for t_ in c_[:2]])
+        if not WGRAD_EARLY:
+            flush_wgrads()                                  # fc2, fc1 (MLP branch), proj, qkv: every operand exists now
     elif ov:
         on_side(wgrad_qkv, dqkv)
     else:
@@ -344,6 +361,7 @@ def sr_fwd(x, p, cfg, embed_keep, new_keep, save, pre=None):
 
 
 def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep, gt=None, next_cast=None):
+    flush_wgrads()                                          # the last block's qkv weight gradient (VITRES_WGRAD_EARLY)
     x, mean, rstd, y, col = saved
     B, Ni, C = x.shape
     g = cfg["grid"]
@@ -401,6 +419,7 @@ def embed0_fwd(img, p, cfg, keep, save, sample_map=None, col=None):
 
 
 def embed0_bwd(g, saved, p, grads, cfg, keep, gt=None):
+    flush_wgrads()
     (col,) = saved
     B, N, C = g.shape
     T = cfg.get("tokens", 1)
