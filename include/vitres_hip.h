@@ -68,7 +68,8 @@ typedef struct vr_gemm_args {
     const void* A;
     const void* B;
     void* C;
-    void* C2;            /* second output for act==1 (same dtype/ld as C) or NULL */
+    void* C2;            /* act==1: second output gelu(u) (same dtype/ld as C) while C gets u; NULL with act==1: C gets
+                            gelu(u) alone (forward-only evaluation: the pre-activation is not kept) */
     const float* bias;   /* [N] or NULL */
     const float* pos;    /* [rows_in, N] or NULL */
     const float* scale;  /* [batch] or NULL */
@@ -83,7 +84,7 @@ typedef struct vr_gemm_args {
     int32_t a_trans, b_trans;
     int32_t in_dtype;    /* dtype of A and B (and dact_u) */
     int32_t out_dtype;   /* dtype of C/C2 */
-    int32_t act;         /* 0 none, 1 gelu dual store */
+    int32_t act;         /* 0 none, 1 gelu (dual store with C2, single store without) */
     int32_t atomic;      /* 1: atomicAdd fp32 */
     int32_t split_k;     /* >= 1 */
     int32_t rows_in;     /* rows per sample of the M index (0: single sample); wgrad: tokens per sample of the K index */

@@ -54,8 +54,11 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     C2d = _flat2d(out, ldc)
     if act == 1:
         v = torch.where(nmask, v, torch.zeros_like(v))
-        C2d[orow, :N] = v.to(out.dtype)
         h = torch.where(nmask, F.gelu(v), torch.zeros_like(v))
+        if out2 is None:                                   # forward-only: gelu(u) alone
+            C2d[orow, :N] = h.to(out.dtype)
+            return out
+        C2d[orow, :N] = v.to(out.dtype)
         _flat2d(out2, ldc)[orow, :N] = h.to(out.dtype)
         return out
     if dact_u is not None:

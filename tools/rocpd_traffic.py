@@ -24,7 +24,7 @@ def per_kernel(path):
 
 def family(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    for fam in ("vr_gemm_nt::nt_kernel", "vr_gemm_tn::tn_kernel", "gemm_kernel", "ln_bwd_kernel", "ln_fwd_kernel",
+    for fam in ("vr_gemm_nt::nt_kernel", "vr_gemm_tn::tn_group_kernel", "vr_gemm_tn::tn_kernel", "gemm_kernel", "ln_bwd_kernel", "ln_fwd_kernel",
                 "vr_attn_mfma::fwd_kernel", "vr_attn_mfma::bwd_dq_kernel", "vr_attn_mfma::bwd_dkv_kernel"):
         if name.startswith(fam):
             return fam
@@ -42,7 +42,9 @@ rows = sorted(fam.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))
 print("%-44s %7s %14s %14s %14s" % ("kernel family", "launch", "read MB/launch", "write MB/launch", "total MB/step"))
 out = {}
 steps = 2
-for k, (n, rd, wr) in rows[:24]:
+tot = sum(v[1] + v[2] for v in fam.values()) / steps
+print('# all kernels: %.1f MB per step' % (tot / 1e6))
+for k, (n, rd, wr) in rows[:28]:
     if n == 0:
         continue
     print("%-44s %7d %14.2f %14.2f %14.1f" % (k, n, rd / n / 1e6, wr / n / 1e6, (rd + wr) / steps / 1e6))

@@ -397,8 +397,12 @@ __device__ __forceinline__ void epilogue_all(const vr_gemm_args& p, f32x16 (&acc
                         h[e] = kc[e] ? (sizeof(T) == 2 ? gelu_fast(v[e]) : gelu_f(v[e])) : 0.f;
                     }
                     if (any) {
-                        store4<TO>(p.C, oidx, v, vq[j][g], ok);
-                        store4<TO>(p.C2, oidx, h, vq[j][g], ok);
+                        if (p.C2) {
+                            store4<TO>(p.C, oidx, v, vq[j][g], ok);
+                            store4<TO>(p.C2, oidx, h, vq[j][g], ok);
+                        } else {
+                            store4<TO>(p.C, oidx, h, vq[j][g], ok);      // forward-only: the activation alone
+                        }
                     }
                 } else {
 #pragma unroll
@@ -504,8 +508,12 @@ __device__ __forceinline__ void epilogue_lds(const vr_gemm_args& p, f32x16 (&acc
                     h[e] = kc[e] ? (sizeof(T) == 2 ? gelu_fast(v[e]) : gelu_f(v[e])) : 0.f;
                 }
                 if (any) {
-                    storew<TO, CW>(p.C, oidx, v, vec, mok[q], nvalid);
-                    storew<TO, CW>(p.C2, oidx, h, vec, mok[q], nvalid);
+                    if (p.C2) {
+                        storew<TO, CW>(p.C, oidx, v, vec, mok[q], nvalid);
+                        storew<TO, CW>(p.C2, oidx, h, vec, mok[q], nvalid);
+                    } else {
+                        storew<TO, CW>(p.C, oidx, h, vec, mok[q], nvalid);      // forward-only: the activation alone
+                    }
                 }
             } else {
 #pragma unroll
@@ -753,7 +761,6 @@ static int gemm_validate(vr_gemm_args& a) {
     if (a.split_k < 0 || (!a.atomic && a.split_k == 0)) a.split_k = 1;   // 0 with atomic = choose automatically
     if (a.split_k > 1 && !a.atomic) return VR_EINVAL;
     if (a.atomic && a.out_dtype != VR_F32) return VR_EINVAL;
-    if (a.act == 1 && !a.C2) return VR_EINVAL;
     if (a.bias_grad && !(a.a_trans && a.atomic)) return VR_EINVAL;
     if (a.in_dtype != VR_F32 && a.in_dtype != VR_BF16) return VR_EUNSUPPORTED;
     if (a.out_dtype != VR_F32 && a.out_dtype != VR_BF16) return VR_EUNSUPPORTED;

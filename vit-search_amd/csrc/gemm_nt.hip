@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         }
     }
     const char* zero = reinterpret_cast<const char*>(zero_chunk);
-    const bool ktail = !FAST && (p.K % BK) != 0;      // FAST: K % 64 == 0 (host check)
+    const bool ktail = (FEAT == 4) && (p.K % BK) != 0;   // FEAT 0..3: K % 64 == 0 (host check)
 
     // ---- fragment read offsets: lane -> row (lane & 15) of a 16-row group, k-chunk 4 s + (lane >> 4) ----
     const int frow = lane & 15, fswz = (frow >> 1) & 7;
@@ -350,8 +350,12 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
             }
             if constexpr (EPI == EPI_GELU) {
                 if (any) {
-                    storew<TO, CW>(p.C, oidx[q], v, vec, mok, nvalid);
-                    storew<TO, CW>(p.C2, oidx[q], hh, vec, mok, nvalid);
+                    if (p.C2) {
+                        storew<TO, CW>(p.C, oidx[q], v, vec, mok, nvalid);
+                        storew<TO, CW>(p.C2, oidx[q], hh, vec, mok, nvalid);
+                    } else {
+                        storew<TO, CW>(p.C, oidx[q], hh, vec, mok, nvalid);      // forward-only (evaluation): gelu(u) alone
+                    }
                 }
             } else {
                 if (has_scale) {
@@ -382,7 +386,7 @@ template <typename TO, int EPI, int MI, int NJ, int STAGES, int FEAT> void launc
 template <typename TO, int EPI, int MI, int NJ, int STAGES = 1> void launch2(const vr_gemm_args& a, hipStream_t stream, bool fast) {
     // epilogue form (see nt_kernel): the forms of the transformer-block Linears get their own kernels
     int feat = 4;
-    if (fast && !a.pos) {
+    if (fast && !a.pos && a.K % BK == 0) {
         if (!a.bias && !a.resid && !a.scale) feat = 0;
         else if (a.bias && !a.resid && !a.scale) feat = 1;
         else if (a.bias && a.resid && !a.scale) feat = 2;
@@ -409,8 +413,7 @@ template <typename TO, int EPI, int MI, int NJ, int STAGES = 1> void launch2(con
 template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     const long long tn = (a.N + 127) / 128;
     const long long t128 = (long long)((a.M + 127) / 128) * tn, t64 = (long long)((a.M + 63) / 64) * tn;
-    const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0) &&
-                      a.K % BK == 0;
+    const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);
     static const int knob = std::getenv("VITRES_NT_TILE") ? std::atoi(std::getenv("VITRES_NT_TILE")) : 0;   // 1/2/3: force
     // tile by grid size (measured crossovers, tools/gemm_bench.py): 128x128 while it gives a CU two workgroups, 64x128
     // below that, 64x64 when even that leaves CUs with a single workgroup (long-K GEMMs of the last stage)

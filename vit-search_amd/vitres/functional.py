@@ -276,10 +276,15 @@ def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save, pre=N
     F = cfg["hidden"]
     dt = cfg["dtype"]
     y, mean, rstd = pre if pre is not None else K.ln_fwd(x, p["n2w"], p["n2b"], embed_keep, N, cfg["eps"], dt)
-    u = torch.empty((B, N, F), dtype=dt, device=x.device)
     h = torch.empty((B, N, F), dtype=dt, device=x.device)
-    K.gemm(y, p["fc1"].w_c, u, out2=h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b, act=1,
-           keep_n=mlp_keep, rows_in=N, keep_k=embed_keep)
+    if save:
+        u = torch.empty((B, N, F), dtype=dt, device=x.device)
+        K.gemm(y, p["fc1"].w_c, u, out2=h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b, act=1,
+               keep_n=mlp_keep, rows_in=N, keep_k=embed_keep)
+    else:                                       # forward-only: the pre-activation is not kept, fc1 writes gelu(u) alone
+        u = None
+        K.gemm(y, p["fc1"].w_c, h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b, act=1,
+               keep_n=mlp_keep, rows_in=N, keep_k=embed_keep)
     x2 = torch.empty_like(x)
     post = None
     if _ln_fusable(h, C, next_ln):

@@ -96,7 +96,7 @@ class SpatialReductionPatchEmbedding(nn.Module):
 class _Plan:
     """Host-side description of one forward: which keep vector / drop-path scale each layer uses."""
     __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch", "n_dp", "order", "dp_noise", "host", "embed_col",
-                 "keeps_host", "scales_host", "embed_map")
+                 "keeps_host", "scales_host", "embed_map", "want_tape")
 
     def __init__(self):
         self.rows, self.layers, self.keep_dev, self.head, self.scales, self.batch, self.n_dp = [], [], None, None, None, 0, 0
@@ -104,6 +104,7 @@ class _Plan:
         self.dp_noise = None     # test hook: the uniform draws of drop_path (nets/drop.py:23), [n_dp, B] in the CALLER's sample order
         self.host = None         # (int32 [n_rows, B] keeps, float32 [n_dp, B] DropPath scales) on the host, internal row order
         self.keeps_host = self.scales_host = None
+        self.want_tape = True    # False under torch.no_grad(): the forward keeps nothing for a backward
         self.embed_map = None    # int64 device map: internal sample -> caller's sample, consumed by the type-0 patch gather
         self.embed_col = None    # type-0 patch embedding: the patchify operand already gathered (engine.GraphedTrainStep)
 
@@ -120,7 +121,7 @@ class _Plan:
 class _ViTResFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, plan, with_patch, *params):
-        save = any(ctx.needs_input_grad[4:])
+        save = plan.want_tape and any(ctx.needs_input_grad[4:])      # (needs_input_grad ignores torch.no_grad())
         cls, pat, tape = model._run_forward(x, plan, with_patch, save)
         ctx.model, ctx.plan, ctx.tape, ctx.with_patch = model, plan, tape, with_patch
         ctx.set_materialize_grads(False)
@@ -290,6 +291,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         vitres.optim.FlatAdamW maintains the bf16 weight shadow: re-casts it right away (forwards then skip their own cast,
         also inside a captured hipGraph)."""
         a = self._arena
+        if a is not None:
+            a["shadow_ver"] = None
         if a is not None and a.get("shadow_ok") and a["flat"].is_cuda:
             K.cast_bf16(a["flat"], a["shadow"])
 
@@ -571,6 +574,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 plan.embed_map = fwd_idx             # the patch gather reads the images in the internal order (vr_im2col_patch_map)
             else:
                 x = x.index_select(0, fwd_idx)
+        plan.want_tape = torch.is_grad_enabled()
         out = _ViTResFn.apply(self, x, plan, with_patch, *params)
         if plan.order is not None:
             out = tuple(o.index_select(0, inv_idx) for o in out) if isinstance(out, tuple) else out.index_select(0, inv_idx)
@@ -671,8 +675,15 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         if self.compute_dtype == torch.bfloat16:
             if Fn.OVERLAP and a["flat"].is_cuda:
                 Fn.join_side()             # a previous forward's side work (if its backward never ran)
-            if not a.get("shadow_ok"):                 # vitres.optim.FlatAdamW writes the shadow with every update
-                K.cast_bf16(a["flat"], a["shadow"])
+            # the bf16 weight shadow: vitres.optim.FlatAdamW writes it with every update (shadow_ok).  Otherwise it is re-cast per
+            # forward in training mode; in eval mode (frozen weights: evaluation, candidate scoring) only when a parameter changed --
+            # tracked by the parameters' version counters, which every in-place update under autograd's eyes bumps (optimizers,
+            # load_state_dict, EMA copies; raw `.data` arithmetic is not seen: call invalidate_shadow() after such edits)
+            if not a.get("shadow_ok"):
+                ver = None if self.training else sum(p_._version for p_ in a["params"])
+                if ver is None or a.get("shadow_ver") != ver:
+                    K.cast_bf16(a["flat"], a["shadow"])
+                a["shadow_ver"] = ver
         B = x.shape[0]
         tape = [] if save else None
         side_params = {}
