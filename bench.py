@@ -377,7 +377,7 @@ def main():
             if dt_ == "bf16" and not at and not bt:
                 return "vr_gemm_nt::nt_kernel (forward+dgrad)"
             if dt_ == "bf16" and at and bt:
-                return "vr_gemm_tn::tn_kernel (wgrad)"
+                return "vr_gemm_tn::tn_group_kernel / tn_kernel (wgrad)"
             if at:
                 return "gemm_kernel<%s,true,true,float,EPI_ATOMIC> (row-mapped wgrad)" % dt_
             return "gemm_kernel<%s,false,%s> (%s)" % (dt_, "true" if bt else "false", "dgrad, contraction-major W" if bt
@@ -392,13 +392,13 @@ def main():
         ach = fl / sec / 1e12
         gemm_sec = sum(v[0] for v in agg.values()) / args.profile_steps
         traffic, traffic_note = None, None
-        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_hbm_traffic.json")
         if os.path.exists(tfile) and args.workload == "sr_tiny_supernet":
             tj = json.load(open(tfile))
             for fam, tv in tj["kernels"].items():
                 if dom.startswith(fam):
                     traffic = round(tv["read_bytes_per_launch"] + tv["write_bytes_per_launch"], 1)
-                    traffic_note = "HBM bytes per launch (read + write) of %s from profiles/r01_hbm_traffic.json: %s" % (
+                    traffic_note = "HBM-side bytes per launch (read + write) of %s from profiles/r02_hbm_traffic.json: %s" % (
                         fam, tj["source"])
         # which roof binds the dominant kernel: its arithmetic intensity (dense-equivalent FLOPs per algorithmic byte of a launch)
         # against the machine balance peak_flops / peak_bandwidth; the other roof is reported beside it

@@ -176,6 +176,8 @@ def flush_wgrads():
         return
     calls = list(_block_wgrads)
     del _block_wgrads[:]
+    if not OVERLAP:                                         # single-stream runs (profiling passes): same kernel, in line
+        return K.gemm_group(calls)
     on_side(lambda: K.gemm_group(calls), *[t_ for c_ in calls for t_ in c_[:2]])
 
 
@@ -226,7 +228,7 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     if gt is None:
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                   # d(branch output), compute dtype
 
-    grp = _block_wgrads if (ov and WGRAD_GROUP) else None
+    grp = _block_wgrads if (WGRAD_GROUP and g.is_cuda) else None
 
     def wgrad_proj():
         linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"], keep_rows=out_keep, keep_cols=attn_keep,
@@ -309,7 +311,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     if gt is None:
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
 
-    grp = _block_wgrads if (ov and WGRAD_GROUP) else None
+    grp = _block_wgrads if (WGRAD_GROUP and g.is_cuda) else None
 
     def wgrad_fc2():
         linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"], keep_rows=out_keep, keep_cols=mlp_keep,
