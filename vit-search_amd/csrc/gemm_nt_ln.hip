@@ -1,5 +1,5 @@
 // bf16 GEMM whose workgroups own WHOLE output rows, with the LayerNorm that follows (forward) or precedes (backward) the
-// Linear fused into the epilogue:
+// Linear fused behind it:
 //
 //   mode 0 (forward; attention `proj` and Mlp `fc2`, reference nets/supernet_blocks.py:214-253):
 //       x1 = resid + scale[s] * mask_keep_n(A W^T + bias)          -> C       (fp32 residual stream, as vr_gemm)
@@ -11,11 +11,14 @@
 //       dy = dU W            (fp32, never written)
 //       C = resid + dLN/dx(dy; x, w, mean, rstd, keep);  dw/db += column sums;  gt_out = cast(mask(C) * gt_scale)   (as vr_ln_bwd)
 //
-// Tile: BM rows x BN >= N columns (64 x 256 for N <= 256, 32 x 512 for N <= 512), four waves side by side along N, each
-// BM x BN/4 = MI x NJ v_mfma_f32_16x16x32_bf16 tiles (64 accumulators).  K loop, LDS image and LDS-DMA addressing are those of
-// gemm_nt.hip (single slice buffer; the CU's other workgroups hide the load latency).  Row statistics are combined across the
-// four waves through LDS with one workgroup barrier: forward merges per-wave (sum, M2 about the wave's own mean) pairs (Chan),
-// so the variance is as robust as a two-pass one.
+// Structure (round 2 rewrite): the K loop of gemm_nt.hip on a BM x BN tile (64 x 256 for N <= 256, 32 x 512 for N <= 512; four
+// waves side by side along N, 64 accumulator registers each), then the LayerNorm kernels' own row loop on the tile: the
+// accumulators are parked in the (idle) slice buffer as fp32 rows, half a tile at a time, and every wave walks whole rows -- a
+// lane owns 4 (8) consecutive columns of a row, row statistics are two wave reductions, all loads of several rows are in flight
+// before the first reduction.  The first version kept the row values in dead accumulator registers across a workgroup barrier
+// and merged per-wave partial statistics through LDS: its backward form needed 168 registers, spilled and ran 3x slower than
+// the two separate kernels.  This form is the two kernels it replaces glued together through LDS: nothing is live across the
+// glue but the accumulators.
 #include <cstdlib>
 
 #include "common.h"
@@ -41,29 +44,19 @@ struct RowMeta {
     float mu, rs;  // backward: saved statistics of the row
 };
 
-template <int LPR> __device__ __forceinline__ float row_sum(float v) {     // over the LPR consecutive lanes of a row
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o);
-    return v;
-}
-template <int LPR> __device__ __forceinline__ float col_sum(float v) {     // over the 64 / LPR lanes sharing a column group
-#pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int MI, int NJ, int MODE>
+template <int MI, int NJ, int MODE, bool KTAIL>
 __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, const vr_ln_epilogue f) {
     constexpr int BM = 16 * MI, BN = 64 * NJ, WCOLS = 16 * NJ;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int AP = BM / 32, BP = BN / 32;                      // LDS-DMA pieces (8 rows x 128 B) per wave
-    constexpr int LPR = 2 * NJ, RPP = 64 / LPR, NQ = 16 / RPP;     // epilogue: lanes per row, rows per pass, passes per 16 rows
-    constexpr int PARK = 16 * WCOLS * 4;                           // bytes a wave parks per 16-row round
-    constexpr int CW = 8;
-    static_assert(AP >= 1 && 4 * PARK <= A_BYTES + B_BYTES, "tile shape");
+    constexpr int NV = BN / 256;                                   // float4 column groups per lane in the row loop
+    constexpr int HM = MI / 2, PR = 16 * HM;                       // 16-row fragments / rows parked per half tile
+    constexpr int SLOTS = BN / 4;                                  // 16-byte slots per parked row
+    static_assert(AP >= 1 && PR * BN * 4 <= A_BYTES + B_BYTES, "tile shape");
     __shared__ __attribute__((aligned(1024))) char smem[A_BYTES + B_BYTES];
     __shared__ RowMeta rowmeta[BM];
-    __shared__ float2 stats[BM][4];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -97,24 +90,49 @@ __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, con
     const char* gA[AP];
     const char* gB[BP];
     int chunkA[AP], chunkB[BP];
+    {
+        const int rb = wave * (8 * BP) + (lane >> 3);
+        if (BN <= p.N) {                                        // every weight row of the tile exists: affine addresses
+            const char* b0 = reinterpret_cast<const char*>(p.B) + (long long)rb * p.ldb * 2;
+            const long long step = (long long)p.ldb * 16;
 #pragma unroll
-    for (int h = 0; h < BP; ++h) {
-        const int r = (wave * BP + h) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const int nb = min(r, p.N - 1);
-        gB[h] = reinterpret_cast<const char*>(p.B) + ((long long)nb * p.ldb + c * 8) * 2;
-        chunkB[h] = c * 8;
-    }
+            for (int h = 0; h < BP; ++h) {
+                const int c = (lane & 7) ^ (((rb + 8 * h) >> 1) & 7);
+                gB[h] = b0 + h * step + c * 16;
+                chunkB[h] = c * 8;
+            }
+        } else {
 #pragma unroll
-    for (int h = 0; h < AP; ++h) {
-        const int r = (wave * AP + h) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const int ma = min(m0 + r, p.M - 1);
-        gA[h] = reinterpret_cast<const char*>(p.A) + (map_row(amap, ma) * (long long)p.lda + c * 8) * 2;
-        chunkA[h] = c * 8;
+            for (int h = 0; h < BP; ++h) {
+                const int r = rb + h * 8;
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                const int nb = min(r, p.N - 1);
+                gB[h] = reinterpret_cast<const char*>(p.B) + ((long long)nb * p.ldb + c * 8) * 2;
+                chunkB[h] = c * 8;
+            }
+        }
+        const int ra = wave * (8 * AP) + (lane >> 3);
+        if (amap.rpi == 0 && m0 + BM <= p.M) {
+            const char* a0 = reinterpret_cast<const char*>(p.A) + (long long)(m0 + ra) * p.lda * 2;
+            const long long step = (long long)p.lda * 16;
+#pragma unroll
+            for (int h = 0; h < AP; ++h) {
+                const int c = (lane & 7) ^ (((ra + 8 * h) >> 1) & 7);
+                gA[h] = a0 + h * step + c * 16;
+                chunkA[h] = c * 8;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < AP; ++h) {
+                const int r = ra + h * 8;
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                const int ma = min(m0 + r, p.M - 1);
+                gA[h] = reinterpret_cast<const char*>(p.A) + (map_row(amap, ma) * (long long)p.lda + c * 8) * 2;
+                chunkA[h] = c * 8;
+            }
+        }
     }
     const char* zero = reinterpret_cast<const char*>(zero_chunk);
-    const bool ktail = (p.K % BK) != 0;
 
     const int frow = lane & 15, fswz = (frow >> 1) & 7;
     const int slot0 = (((lane >> 4)) ^ fswz) << 4, slot1 = ((4 + (lane >> 4)) ^ fswz) << 4;
@@ -132,12 +150,14 @@ __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, con
         const long long kb = (long long)k0 * 2;
 #pragma unroll
         for (int h = 0; h < AP; ++h) {
-            const char* sa = (!ktail || (k0 + chunkA[h] < p.K)) ? gA[h] + kb : zero;
+            const char* sa = gA[h] + kb;
+            if constexpr (KTAIL) sa = (k0 + chunkA[h] < p.K) ? sa : zero;
             __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(smem + (wave * AP + h) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int h = 0; h < BP; ++h) {
-            const char* sb = (!ktail || (k0 + chunkB[h] < p.K)) ? gB[h] + kb : zero;
+            const char* sb = gB[h] + kb;
+            if constexpr (KTAIL) sb = (k0 + chunkB[h] < p.K) ? sb : zero;
             __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(smem + A_BYTES + (wave * BP + h) * 1024), 16, 0, 0);
         }
     };
@@ -160,7 +180,7 @@ __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, con
 
     int kt = next_live(0);
     if (kt < ntiles) issue(kt);
-    if (t < BM) {                          // per-row epilogue metadata; its loads overlap the first slice
+    if (t < BM) {                          // per-row metadata of the row loop; its loads overlap the first slice
         const int m = m0 + t;
         RowMeta rm;
         rm.keep = 1 << 30; rm.scale = 1.0f; rm.orow = -1; rm.lnkeep = p.N; rm.mu = 0.f; rm.rs = 0.f;
@@ -190,225 +210,197 @@ __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, con
         if (kt < ntiles) issue(kt);
     }
 
-    // ---- epilogue: lane owns C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) + 0..3] of the wave's BM x WCOLS; a round
-    //      parks 16 rows in the wave's own piece of the slice buffer and reads them back as rows: lane -> row lane / LPR
-    //      (+ RPP q), columns 8 (lane % LPR) .. +8 ----
-    float* park = reinterpret_cast<float*>(smem + wave * PARK);
-    const int cg = lane % LPR, rsub = lane / LPR;
-    const int n = wave * WCOLS + cg * CW;
-    const bool live = n < p.N;                               // N % 8 == 0: the group is whole or outside
-    const int nc = live ? n : 0;
-    const RowMeta* meta = rowmeta + rsub;
-    float lw[CW];
-    loadw<float, CW>(f.w, nc, lw, true, CW);
-    // row-layout values kept across the workgroup barrier (forward: x1, LayerNorm-masked; backward: dy, masked) live in the
-    // accumulator registers of their round, which are dead once the round is parked: value (i, q, e) -> acc[i][(8 q + e) / 4][(8 q + e) % 4]
-#define XV(i, q, e) acc[i][((q) * CW + (e)) >> 2][((q) * CW + (e)) & 3]
-    const int wlo = wave * WCOLS;
+    // ---- row loop: the tile is parked half by half ([PR rows][BN columns] fp32 in the slice buffer; 16-byte slot s of row r
+    //      sits at slot s ^ (r & 7): the 8 rows a ds_write_b128 lane group writes at one column fall on 8 different bank
+    //      groups, a row read back by the 64 lanes of a wave is a permutation of its 64 slots) and walked as whole rows ----
+    float* park = reinterpret_cast<float*>(smem);
+    const int g4 = lane >> 4, c16 = lane & 15;
+    // this lane's columns in the row loop: float4 group v covers columns 4 (lane + 64 v) .. +3
+    float4 lw[NV], lb[NV], bv[NV];
+    bool cin[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = 4 * (lane + 64 * v);
+        cin[v] = c < p.N;                                      // N % 8 == 0 -> a group is whole or outside
+        const int cc = cin[v] ? c : 0;
+        lw[v] = ld4(f.w + cc);
+        lb[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (MODE == 0) {
+            lb[v] = ld4(f.b + cc);
+            if (p.bias) bv[v] = ld4(p.bias + cc);
+        }
+    }
+    float4 gw[NV], gb[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { gw[v] = make_float4(0.f, 0.f, 0.f, 0.f); gb[v] = gw[v]; }
+    const bool has_res = p.resid != nullptr;
+    constexpr int RPW = PR / 4;                                // rows per wave and half tile
+    constexpr int RU = (NV == 1 && RPW >= 4) ? 4 : 2;         // rows in flight per wave (register budget: 168)
 
-    auto park_round = [&](int i) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int slot = (4 * j + (lane >> 4)) ^ ((lane & 15) & (4 * NJ - 1));
-            *reinterpret_cast<f32x4*>(park + (lane & 15) * WCOLS + slot * 4) = acc[i][j];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto unpark = [&](int q, float (&v)[CW]) {
-        const int rl = q * RPP + rsub;
+    for (int half = 0; half < 2; ++half) {
+        // park rows [half * PR, half * PR + PR): lane holds C[16 i + c16][wave * WCOLS + 16 j + 4 g4 + 0..3]
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int slot = (2 * cg + h) ^ (rl & (4 * NJ - 1));
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(park + rl * WCOLS + slot * 4);
-            v[4 * h] = a4[0]; v[4 * h + 1] = a4[1]; v[4 * h + 2] = a4[2]; v[4 * h + 3] = a4[3];
-        }
-    };
-
-    if constexpr (MODE == 0) {
-        float bv[CW], lb[CW];
+        for (int ih = 0; ih < HM; ++ih) {
+            const int i = half * HM + ih;
+            const int r = 16 * ih + c16;
 #pragma unroll
-        for (int e = 0; e < CW; ++e) bv[e] = 0.f;
-        if (p.bias) loadw<float, CW>(p.bias, nc, bv, true, CW);
-        loadw<float, CW>(f.b, nc, lb, true, CW);
-        const bool has_res = p.resid != nullptr;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            park_round(i);
-            RowMeta rm[NQ];
-            float rv[NQ][CW];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                rm[q] = meta[i * 16 + q * RPP];
-                const long long orow = rm[q].orow < 0 ? 0 : rm[q].orow;
-#pragma unroll
-                for (int e = 0; e < CW; ++e) rv[q][e] = 0.f;
-                if (has_res) loadw<float, CW>(p.resid, orow * p.ldc + nc, rv[q], true, CW);
+            for (int j = 0; j < NJ; ++j) {
+                const int slot = (wave * WCOLS + 16 * j + 4 * g4) >> 2;
+                *reinterpret_cast<f32x4*>(park + ((size_t)r * SLOTS + (slot ^ (r & 7))) * 4) = acc[i][j];
             }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                float v[CW];
-                unpark(q, v);
-                const int kn = live ? rm[q].keep - n : 0, kl = live ? rm[q].lnkeep - n : 0;
-                const float sc = rm[q].scale;
-#pragma unroll
-                for (int e = 0; e < CW; ++e) {
-                    v[e] += bv[e];
-                    v[e] = (e < kn) ? v[e] * sc : 0.f;
-                    v[e] += rv[q][e];
-                    XV(i, q, e) = (e < kl) ? v[e] : 0.f;
-                }
-                if (rm[q].orow >= 0 && live) storew<float, CW>(p.C, (long long)rm[q].orow * p.ldc + nc, v, true, true, CW);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
-        // per-wave partial statistics of every row: (sum, M2 about the wave's own mean) over its kept columns
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int row = i * 16 + q * RPP + rsub;
-                const int lk = rowmeta[row].lnkeep;
-                const int nw = min(max(lk - wlo, 0), WCOLS);
-                float s = 0.f;
-#pragma unroll
-                for (int e = 0; e < CW; ++e) s += XV(i, q, e);
-                s = row_sum<LPR>(s);
-                const float mw = nw > 0 ? s / (float)nw : 0.f;
-                float d = 0.f;
-#pragma unroll
-                for (int e = 0; e < CW; ++e) {
-                    const float u = XV(i, q, e) - mw;
-                    d += (n + e < lk) ? u * u : 0.f;
-                }
-                d = row_sum<LPR>(d);
-                if (cg == 0) stats[row][wave] = make_float2(s, d);
-            }
         __syncthreads();
+#pragma unroll 1
+        for (int r0 = 0; r0 < RPW; r0 += RU) {
+            RowMeta rm[RU];
+            float4 dv[RU][NV], xv[RU][NV], rv[RU][NV];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int u = 0; u < RU; ++u) {
+                const int r = 4 * (r0 + u) + wave;                 // row inside the parked half
+                rm[u] = rowmeta[half * PR + r];
+                const long long orow = rm[u].orow < 0 ? 0 : rm[u].orow;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int row = i * 16 + q * RPP + rsub;
-                const RowMeta rm = rowmeta[row];
-                const int lk = rm.lnkeep;
-                const float inv_n = lk > 0 ? 1.0f / (float)lk : 0.f;
-                float2 st[4];
-                float tot = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) { st[w] = stats[row][w]; tot += st[w].x; }
-                const float mu = tot * inv_n;
-                float m2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const int nw = min(max(lk - w * WCOLS, 0), WCOLS);
-                    const float dm = nw > 0 ? st[w].x / (float)nw - mu : 0.f;
-                    m2 += st[w].y + (float)nw * dm * dm;
+                for (int v = 0; v < NV; ++v) {
+                    const int slot = lane + 64 * v;
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(park + ((size_t)r * SLOTS + (slot ^ (r & 7))) * 4);
+                    dv[u][v] = make_float4(a4[0], a4[1], a4[2], a4[3]);
+                    const int cc = cin[v] ? 4 * slot : 0;
+                    rv[u][v] = has_res ? ld4(p.resid + orow * p.ldc + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (MODE == 1) xv[u][v] = ld4(f.x + orow * p.ldc + cc);
                 }
-                const float rs = 1.0f / sqrtf(m2 * inv_n + f.eps);
-                if (rm.orow >= 0) {
-                    if (wave == 0 && cg == 0) { f.mean[rm.orow] = mu; f.rstd[rm.orow] = rs; }
-                    if (live) {
-                        float o[CW];
+            }
 #pragma unroll
-                        for (int e = 0; e < CW; ++e) o[e] = (n + e < lk) ? lw[e] * ((XV(i, q, e) - mu) * rs) + lb[e] : 0.f;
-                        storew<bf16_t, CW>(f.y, (long long)rm.orow * p.N + nc, o, true, true, CW);
+            for (int u = 0; u < RU; ++u) {
+                const bool rok = rm[u].orow >= 0;
+                const int lk = rm[u].lnkeep;
+                const float inv_n = lk > 0 ? 1.0f / (float)lk : 0.f;
+                if constexpr (MODE == 0) {
+                    // x1 = resid + scale * mask(acc + bias); LayerNorm over the first lk channels (vr_ln_fwd)
+                    float4 x1[NV];
+                    float s = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const int c = 4 * (lane + 64 * v);
+                        const int kn = rm[u].keep - c;
+                        const float sc = rm[u].scale;
+                        float4 a = dv[u][v];
+                        a.x = (0 < kn) ? (a.x + bv[v].x) * sc : 0.f;
+                        a.y = (1 < kn) ? (a.y + bv[v].y) * sc : 0.f;
+                        a.z = (2 < kn) ? (a.z + bv[v].z) * sc : 0.f;
+                        a.w = (3 < kn) ? (a.w + bv[v].w) * sc : 0.f;
+                        a.x += rv[u][v].x; a.y += rv[u][v].y; a.z += rv[u][v].z; a.w += rv[u][v].w;
+                        if (rok && cin[v]) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long long)rm[u].orow * p.ldc + c) = a;
+                        const int kl = cin[v] ? lk - c : 0;
+                        a.x = (0 < kl) ? a.x : 0.f; a.y = (1 < kl) ? a.y : 0.f; a.z = (2 < kl) ? a.z : 0.f; a.w = (3 < kl) ? a.w : 0.f;
+                        x1[v] = a;
+                        s += a.x + a.y + a.z + a.w;
+                        s2 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+                    }
+                    s = wave_sum(s);
+                    const float mu = s * inv_n;
+                    float var;
+                    if (f.keep) {                                  // masked path: var = E[x^2] / p - mu^2 (masked_layer_norm.py:38-40)
+                        var = wave_sum(s2) * inv_n - mu * mu;
+                    } else {                                       // F.layer_norm: two-pass variance
+                        float d2 = 0.f;
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) {
+                            if (cin[v]) {
+                                const float a = x1[v].x - mu, b2 = x1[v].y - mu, c2 = x1[v].z - mu, d = x1[v].w - mu;
+                                d2 += a * a + b2 * b2 + c2 * c2 + d * d;
+                            }
+                        }
+                        var = wave_sum(d2) * inv_n;
+                    }
+                    const float rs = 1.0f / sqrtf(var + f.eps);
+                    if (rok) {
+                        if (lane == 0) { f.mean[rm[u].orow] = mu; f.rstd[rm[u].orow] = rs; }
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) {
+                            const int c = 4 * (lane + 64 * v);
+                            if (cin[v]) {
+                                const int kl = lk - c;
+                                const float o0 = (0 < kl) ? lw[v].x * ((x1[v].x - mu) * rs) + lb[v].x : 0.f;
+                                const float o1 = (1 < kl) ? lw[v].y * ((x1[v].y - mu) * rs) + lb[v].y : 0.f;
+                                const float o2 = (2 < kl) ? lw[v].z * ((x1[v].z - mu) * rs) + lb[v].z : 0.f;
+                                const float o3 = (3 < kl) ? lw[v].w * ((x1[v].w - mu) * rs) + lb[v].w : 0.f;
+                                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(f.y) + (long long)rm[u].orow * p.N + c) =
+                                    make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
+                            }
+                        }
+                    }
+                } else {
+                    // dLN/dx of dy (vr_ln_bwd): dz = dy * w; dx = (dz - (mean(dz) + z mean(z dz))) * rstd + resid
+                    float4 gz[NV], zz[NV];
+                    float s1 = 0.f, s2 = 0.f;
+                    const float mu = rm[u].mu, rs = rm[u].rs;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const int c = 4 * (lane + 64 * v);
+                        const int kl = (rok && cin[v]) ? lk - c : 0;
+                        float4 a = dv[u][v], xx = xv[u][v];
+                        if (!(0 < kl)) { a.x = 0.f; xx.x = mu; }
+                        if (!(1 < kl)) { a.y = 0.f; xx.y = mu; }
+                        if (!(2 < kl)) { a.z = 0.f; xx.z = mu; }
+                        if (!(3 < kl)) { a.w = 0.f; xx.w = mu; }
+                        const float4 z = make_float4((xx.x - mu) * rs, (xx.y - mu) * rs, (xx.z - mu) * rs, (xx.w - mu) * rs);
+                        gw[v].x += a.x * z.x; gw[v].y += a.y * z.y; gw[v].z += a.z * z.z; gw[v].w += a.w * z.w;
+                        gb[v].x += a.x; gb[v].y += a.y; gb[v].z += a.z; gb[v].w += a.w;
+                        const float4 g = make_float4(a.x * lw[v].x, a.y * lw[v].y, a.z * lw[v].z, a.w * lw[v].w);
+                        s1 += g.x + g.y + g.z + g.w;
+                        s2 += g.x * z.x + g.y * z.y + g.z * z.z + g.w * z.w;
+                        gz[v] = g;
+                        zz[v] = z;
+                    }
+                    s1 = wave_sum(s1) * inv_n;
+                    s2 = wave_sum(s2) * inv_n;
+                    if (rok) {
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) {
+                            const int c = 4 * (lane + 64 * v);
+                            if (cin[v]) {
+                                const int kl = lk - c, kg = rm[u].keep - c;
+                                const float4 r = rv[u][v];
+                                float4 o;
+                                o.x = (0 < kl) ? (gz[v].x - (s1 + zz[v].x * s2)) * rs + r.x : 0.f;
+                                o.y = (1 < kl) ? (gz[v].y - (s1 + zz[v].y * s2)) * rs + r.y : 0.f;
+                                o.z = (2 < kl) ? (gz[v].z - (s1 + zz[v].z * s2)) * rs + r.z : 0.f;
+                                o.w = (3 < kl) ? (gz[v].w - (s1 + zz[v].w * s2)) * rs + r.w : 0.f;
+                                const long long oidx = (long long)rm[u].orow * p.ldc + c;
+                                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + oidx) = o;
+                                if (f.gt_out) {
+                                    const float sc = rm[u].scale;
+                                    const float t0 = (0 < kg) ? o.x * sc : 0.f, t1 = (1 < kg) ? o.y * sc : 0.f;
+                                    const float t2 = (2 < kg) ? o.z * sc : 0.f, t3 = (3 < kg) ? o.w * sc : 0.f;
+                                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(f.gt_out) + oidx) =
+                                        make_uint2(pack_bf2(t0, t1), pack_bf2(t2, t3));
+                                }
+                            }
+                        }
                     }
                 }
             }
-    } else {
-        float gwp[CW], gbp[CW];
+        }
+        __syncthreads();                                       // the park area is rewritten by the second half / reused below
+    }
+
+    if constexpr (MODE == 1) {
+        // LayerNorm weight / bias gradients: every wave holds partial column sums over its rows -> cross-wave sum through LDS
+        float* red = reinterpret_cast<float*>(smem);               // [2][4 waves][BN]
 #pragma unroll
-        for (int e = 0; e < CW; ++e) { gwp[e] = 0.f; gbp[e] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            park_round(i);
-            RowMeta rm[NQ];
-            float xx[NQ][CW];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                rm[q] = meta[i * 16 + q * RPP];
-                const long long orow = rm[q].orow < 0 ? 0 : rm[q].orow;
-                loadw<float, CW>(f.x, orow * p.ldc + nc, xx[q], true, CW);
-            }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                float v[CW];
-                unpark(q, v);
-                const int kl = (rm[q].orow >= 0 && live) ? rm[q].lnkeep - nc : 0;
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int e = 0; e < CW; ++e) {
-                    const bool in = e < kl;
-                    const float a = in ? v[e] : 0.f;
-                    const float z = in ? (xx[q][e] - rm[q].mu) * rm[q].rs : 0.f;
-                    XV(i, q, e) = a;
-                    gwp[e] += a * z;
-                    gbp[e] += a;
-                    const float g = a * lw[e];
-                    s1 += g;
-                    s2 += g * z;
-                }
-                s1 = row_sum<LPR>(s1);
-                s2 = row_sum<LPR>(s2);
-                if (cg == 0) stats[i * 16 + q * RPP + rsub][wave] = make_float2(s1, s2);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        for (int v = 0; v < NV; ++v) {
+            *reinterpret_cast<float4*>(red + (0 * 4 + wave) * BN + 4 * (lane + 64 * v)) = gw[v];
+            *reinterpret_cast<float4*>(red + (1 * 4 + wave) * BN + 4 * (lane + 64 * v)) = gb[v];
         }
         __syncthreads();
-        const bool has_res = p.resid != nullptr;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            RowMeta rm[NQ];
-            float xx[NQ][CW], rv[NQ][CW];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                rm[q] = meta[i * 16 + q * RPP];
-                const long long orow = rm[q].orow < 0 ? 0 : rm[q].orow;
-                loadw<float, CW>(f.x, orow * p.ldc + nc, xx[q], true, CW);       // second read: L2 hit
-#pragma unroll
-                for (int e = 0; e < CW; ++e) rv[q][e] = 0.f;
-                if (has_res) loadw<float, CW>(p.resid, orow * p.ldc + nc, rv[q], true, CW);
-            }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int row = i * 16 + q * RPP + rsub;
-                const int lk = rm[q].lnkeep;
-                const float inv_n = lk > 0 ? 1.0f / (float)lk : 0.f;
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) { const float2 st = stats[row][w]; s1 += st.x; s2 += st.y; }
-                s1 *= inv_n;
-                s2 *= inv_n;
-                const int kl = lk - nc, kg = rm[q].keep - nc;
-                float o[CW], tg[CW];
-#pragma unroll
-                for (int e = 0; e < CW; ++e) {
-                    const float z = (xx[q][e] - rm[q].mu) * rm[q].rs;
-                    const float g = XV(i, q, e) * lw[e];
-                    o[e] = (e < kl) ? (g - (s1 + z * s2)) * rm[q].rs + rv[q][e] : 0.f;
-                    tg[e] = (e < kg) ? o[e] * rm[q].scale : 0.f;
-                }
-                if (rm[q].orow >= 0 && live) {
-                    const long long oidx = (long long)rm[q].orow * p.ldc + nc;
-                    storew<float, CW>(p.C, oidx, o, true, true, CW);
-                    if (f.gt_out) storew<bf16_t, CW>(f.gt_out, oidx, tg, true, true, CW);
-                }
-            }
-        }
-        // LayerNorm weight / bias gradients: column sums over the tile's rows (this wave owns its columns alone)
-#pragma unroll
-        for (int e = 0; e < CW; ++e) {
-            gwp[e] = col_sum<LPR>(gwp[e]);
-            gbp[e] = col_sum<LPR>(gbp[e]);
-        }
-        if (rsub == 0 && live) {
-#pragma unroll
-            for (int e = 0; e < CW; ++e) {
-                atomicAdd(f.dw + n + e, gwp[e]);
-                atomicAdd(f.db + n + e, gbp[e]);
+        for (int c = t; c < BN; c += NTHR) {
+            if (c < p.N) {
+                const float a = red[0 * BN + c] + red[1 * BN + c] + red[2 * BN + c] + red[3 * BN + c];
+                const float b2 = red[4 * BN + c] + red[5 * BN + c] + red[6 * BN + c] + red[7 * BN + c];
+                atomicAdd(f.dw + c, a);
+                atomicAdd(f.db + c, b2);
             }
         }
     }
@@ -416,13 +408,17 @@ __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, con
 
 template <int MI, int NJ> int launch(const vr_gemm_args& a, const vr_ln_epilogue& f, hipStream_t stream) {
     const unsigned tiles = (unsigned)((a.M + 16 * MI - 1) / (16 * MI));
-    if (f.mode == 0) hipLaunchKernelGGL((ntln_kernel<MI, NJ, 0>), dim3(tiles), dim3(NTHR), 0, stream, a, f);
-    else hipLaunchKernelGGL((ntln_kernel<MI, NJ, 1>), dim3(tiles), dim3(NTHR), 0, stream, a, f);
+    const bool ktail = (a.K % BK) != 0;
+    if (f.mode == 0) {
+        if (ktail) hipLaunchKernelGGL((ntln_kernel<MI, NJ, 0, true>), dim3(tiles), dim3(NTHR), 0, stream, a, f);
+        else hipLaunchKernelGGL((ntln_kernel<MI, NJ, 0, false>), dim3(tiles), dim3(NTHR), 0, stream, a, f);
+    } else {
+        if (ktail) hipLaunchKernelGGL((ntln_kernel<MI, NJ, 1, true>), dim3(tiles), dim3(NTHR), 0, stream, a, f);
+        else hipLaunchKernelGGL((ntln_kernel<MI, NJ, 1, false>), dim3(tiles), dim3(NTHR), 0, stream, a, f);
+    }
     VR_CHECK_LAUNCH();
     return VR_OK;
 }
-
-#undef XV
 
 }  // namespace vr_gemm_ntln
 

@@ -28,12 +28,16 @@ DEFER_JOIN = _os.environ.get('VITRES_OVERLAP', '3') == '2'
 JOIN_PER_BLOCK = _os.environ.get('VITRES_OVERLAP', '3') == '3'
 FUSE_CAST = _os.environ.get('VITRES_FUSE_CAST', '1') != '0'      # LayerNorm backward also emits the next branch's gradient
 PROJ_LATE = _os.environ.get('VITRES_PROJ_LATE', '0') != '0'      # issue proj's weight gradient after the attention core
-# vr_gemm_ln (gemm_nt_ln.hip), opt-in: bit 0 = LayerNorm forward in the epilogue of the Linear that produces its input, bit 1 =
-# LayerNorm backward in the epilogue of the data-gradient GEMM that produces its gradient.  Measured on the sr_tiny step: the
-# separate kernels already stream at ~4 TB/s, whole-row tiles (64 x 256 / 32 x 512) re-stream the weights per 64 / 32 rows and
-# leave a CU 2-3 workgroups: forward fusion +0.5 % at width 256, -3 % with width 512 included; backward fusion -25 % (spills).
-FUSE_LN = int(_os.environ.get('VITRES_FUSE_LN', '0'))
-FUSE_LN_MAXN = int(_os.environ.get('VITRES_FUSE_LN_MAXN', '512'))
+# vr_gemm_ln (gemm_nt_ln.hip): bit 0 = LayerNorm forward behind the Linear that produces its input, bit 1 = LayerNorm backward
+# behind the data-gradient GEMM that produces its gradient; whole-row tiles, so only widths <= VITRES_FUSE_LN_MAXN.  Round 2
+# (kernel rewritten as GEMM K loop + the LayerNorm kernels' row loop glued through LDS) measured inside the sr_tiny step:
+# backward fusion at width 256: 51 us against 28 + 36..50 us for the two kernels (8.34 -> 8.20 ms); forward fusion: proj (K <= 256)
+# 28 against 19.5 + 13.6 us, fc2 (K = 768: twelve single-buffered 64 x 256 slices) 45..49 against 32 + 13.6 us (a wash per kernel;
+# the step still prefers it, 8.12 against 8.17 ms, one launch less per block; VITRES_FUSE_LN_FWD_MAXK bounds the K it applies to);
+# width 512 (32 x 512 tiles, 260 of them at M = 8320) loses in both directions.
+FUSE_LN = int(_os.environ.get('VITRES_FUSE_LN', '3'))
+FUSE_LN_MAXN = int(_os.environ.get('VITRES_FUSE_LN_MAXN', '256'))
+FUSE_LN_FWD_MAXK = int(_os.environ.get('VITRES_FUSE_LN_FWD_MAXK', '4096'))
 STEM_SIDE = _os.environ.get('VITRES_STEM_SIDE', '1') != '0'      # conv-stem weight gradients on the side stream (+2 % since SIDE_DEFER)
 _side_streams = {}
 
@@ -185,7 +189,8 @@ def flush_wgrads():
 # transformer block halves
 # --------------------------------------------------------------------------------------------------
 def _ln_fusable(a, C, next_ln):
-    return next_ln is not None and (FUSE_LN & 1) and C <= FUSE_LN_MAXN and K.gemm_ln_supported(a, C, C)
+    return next_ln is not None and (FUSE_LN & 1) and C <= FUSE_LN_MAXN and a.shape[-1] <= FUSE_LN_FWD_MAXK and \
+        K.gemm_ln_supported(a, C, C)
 
 
 def attn_branch_fwd(x, p, cfg, embed_keep, attn_keep, out_keep, scale, save, pre=None, next_ln=None):
