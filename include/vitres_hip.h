@@ -84,7 +84,9 @@ typedef struct vr_gemm_args {
     int32_t a_trans, b_trans;
     int32_t in_dtype;    /* dtype of A and B (and dact_u) */
     int32_t out_dtype;   /* dtype of C/C2 */
-    int32_t act;         /* 0 none, 1 gelu (dual store with C2, single store without) */
+    int32_t act;         /* 0 none; 1 gelu (dual store with C2: C = u, C2 = gelu(u); single store without: C = gelu(u)); 2 the
+                            saved-derivative form of the same pair: forward (no dact_u) C = gelu'(u), C2 = gelu(u); data gradient
+                            (dact_u given) multiplies by dact_u as it is -- no transcendental in the backward epilogue */
     int32_t atomic;      /* 1: atomicAdd fp32 */
     int32_t split_k;     /* >= 1 */
     int32_t rows_in;     /* rows per sample of the M index (0: single sample); wgrad: tokens per sample of the K index */

@@ -52,20 +52,27 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     nmask = ncol[None, :] < keep[:, None]
     orow = _rows(M, c_map)
     C2d = _flat2d(out, ldc)
-    if act == 1:
+    if act in (1, 2) and dact_u is None:
         v = torch.where(nmask, v, torch.zeros_like(v))
         h = torch.where(nmask, F.gelu(v), torch.zeros_like(v))
         if out2 is None:                                   # forward-only: gelu(u) alone
             C2d[orow, :N] = h.to(out.dtype)
             return out
+        if act == 2:                                       # C = gelu'(u) instead of u
+            cdf = 0.5 * (1 + torch.erf(v / math.sqrt(2.0)))
+            pdf = torch.exp(-0.5 * v * v) / math.sqrt(2 * math.pi)
+            v = torch.where(nmask, cdf + v * pdf, torch.zeros_like(v))
         C2d[orow, :N] = v.to(out.dtype)
         _flat2d(out2, ldc)[orow, :N] = h.to(out.dtype)
         return out
     if dact_u is not None:
         u = _flat2d(dact_u, ldu)[orow, :N].float()
-        cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2.0)))
-        pdf = torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
-        v = v * (cdf + u * pdf)
+        if act == 2:                                       # dact_u is the derivative itself
+            v = v * u
+        else:
+            cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2.0)))
+            pdf = torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+            v = v * (cdf + u * pdf)
     v = torch.where(nmask, v, torch.zeros_like(v))
     if scale is not None:
         v = v * scale[sample].view(M, 1)

@@ -571,3 +571,36 @@ def test_gemm_group_equals_the_launches_one_by_one(T, C, F, HD):
     for (dw_g, db_g), (dw_1, db_1, _), (_, _, dw_ref, kwr) in zip(outs_gpu, outs_one, calls_cpu):
         assert relerr(dw_g, dw_1) < 1e-5 and relerr(db_g, db_1) < 1e-5          # same kernel body, same split rule apart
         assert relerr(dw_g, dw_ref) < 1.2e-2 and relerr(db_g, kwr["bias_grad"]) < 1.2e-2
+
+
+@pytest.mark.parametrize("M,C,F", [(257 * 4, 256, 768), (65 * 3, 128, 392)])
+def test_gemm_saved_gelu_derivative_pair(M, C, F):
+    """act = 2: fc1 stores (gelu'(u), gelu(u)); fc2's data gradient multiplies by the saved derivative -- the same du as the
+    (u, gelu(u)) / gelu'(u)-in-the-epilogue pair of act = 1, and the torch statement."""
+    dt = torch.bfloat16
+    B = M // (257 if M % 257 == 0 else 65)
+    rps = M // B
+    y, w1 = _bf(rnd(M, C, seed=1)), _bf(rnd(F, C, seed=2, scale=C ** -0.5))
+    b1 = rnd(F, seed=3)
+    keep = torch.tensor([F - 64 * (i % 2) for i in range(B)], dtype=torch.int32)
+    kw = dict(M=M, N=F, K=C, lda=C, ldb=C, ldc=F, bias=b1, keep_n=keep, rows_in=rps)
+    u_ref, h_ref = torch.empty(M, F, dtype=dt), torch.empty(M, F, dtype=dt)
+    d_ref, h2_ref = torch.empty(M, F, dtype=dt), torch.empty(M, F, dtype=dt)
+    E.gemm(y, w1, u_ref, out2=h_ref, act=1, **kw)
+    E.gemm(y, w1, d_ref, out2=h2_ref, act=2, **kw)
+    cu = lambda t_: t_.to(DEV) if isinstance(t_, torch.Tensor) else t_
+    kwd = {k: cu(v) for k, v in kw.items()}
+    d, h = torch.empty(M, F, dtype=dt, device=DEV), torch.empty(M, F, dtype=dt, device=DEV)
+    K.gemm(cu(y), cu(w1), d, out2=h, act=2, **kwd)
+    assert relerr(h, h_ref) < 1.2e-2 and relerr(d, d_ref) < 1.2e-2
+    for i in range(B):                                                 # masked hidden units: derivative stored as 0
+        tail = d.view(B, rps, F)[i, :, int(keep[i]):]
+        assert tail.numel() == 0 or float(tail.abs().max()) == 0.0
+    # data gradient of fc2: du = (gt @ W2) * gelu'(u)
+    gt, w2t = _bf(rnd(M, C, seed=5)), _bf(rnd(F, C, seed=6, scale=C ** -0.5))      # W2^T rows: [F, C] K-contiguous
+    kw2 = dict(M=M, N=F, K=C, lda=C, ldb=C, ldc=F, ldu=F, keep_n=keep, rows_in=rps)
+    du_ref = torch.empty(M, F, dtype=dt)
+    E.gemm(gt, w2t, du_ref, dact_u=u_ref, **kw2)
+    du = torch.empty(M, F, dtype=dt, device=DEV)
+    K.gemm(cu(gt), cu(w2t), du, dact_u=d, act=2, **{k: cu(v) for k, v in kw2.items()})
+    assert relerr(du, du_ref) < 2e-2, relerr(du, du_ref)

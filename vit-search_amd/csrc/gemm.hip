@@ -395,6 +395,7 @@ __device__ __forceinline__ void epilogue_all(const vr_gemm_args& p, f32x16 (&acc
                     for (int e = 0; e < 4; ++e) {
                         v[e] = kc[e] ? v[e] : 0.f;       // masked hidden units: u = 0, gelu(u) = 0 (their K loop may be skipped)
                         h[e] = kc[e] ? (sizeof(T) == 2 ? gelu_fast(v[e]) : gelu_f(v[e])) : 0.f;
+                        if (p.act == 2) v[e] = kc[e] ? (sizeof(T) == 2 ? dgelu_fast(v[e]) : dgelu_f(v[e])) : 0.f;   // C = gelu'(u)
                     }
                     if (any) {
                         if (p.C2) {
@@ -407,7 +408,7 @@ __device__ __forceinline__ void epilogue_all(const vr_gemm_args& p, f32x16 (&acc
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if constexpr (EPI == EPI_DGELU) v[e] *= (sizeof(T) == 2 ? dgelu_fast(rv[j][g][e]) : dgelu_f(rv[j][g][e]));
+                        if constexpr (EPI == EPI_DGELU) v[e] *= p.act == 2 ? rv[j][g][e] : (sizeof(T) == 2 ? dgelu_fast(rv[j][g][e]) : dgelu_f(rv[j][g][e]));
                         v[e] = kc[e] ? v[e] * sc[i] : 0.f;
                         if constexpr (EPI == EPI_STORE) v[e] += rv[j][g][e];
                     }
@@ -506,6 +507,7 @@ __device__ __forceinline__ void epilogue_lds(const vr_gemm_args& p, f32x16 (&acc
                 for (int e = 0; e < CW; ++e) {
                     v[e] = kc[e] ? v[e] : 0.f;       // masked hidden units: u = 0, gelu(u) = 0 (their K loop may be skipped)
                     h[e] = kc[e] ? (sizeof(T) == 2 ? gelu_fast(v[e]) : gelu_f(v[e])) : 0.f;
+                    if (p.act == 2) v[e] = kc[e] ? (sizeof(T) == 2 ? dgelu_fast(v[e]) : dgelu_f(v[e])) : 0.f;   // C = gelu'(u)
                 }
                 if (any) {
                     if (p.C2) {
@@ -518,7 +520,7 @@ __device__ __forceinline__ void epilogue_lds(const vr_gemm_args& p, f32x16 (&acc
             } else {
 #pragma unroll
                 for (int e = 0; e < CW; ++e) {
-                    if constexpr (EPI == EPI_DGELU) v[e] *= (sizeof(T) == 2 ? dgelu_fast(rv[q][e]) : dgelu_f(rv[q][e]));
+                    if constexpr (EPI == EPI_DGELU) v[e] *= p.act == 2 ? rv[q][e] : (sizeof(T) == 2 ? dgelu_fast(rv[q][e]) : dgelu_f(rv[q][e]));
                     v[e] = kc[e] ? v[e] * sc[q] : 0.f;
                     if constexpr (EPI == EPI_STORE) v[e] += rv[q][e];
                 }
@@ -734,7 +736,7 @@ int launch(const vr_gemm_args& a, hipStream_t stream) {
         else return VR_EUNSUPPORTED;
     } else if (a.a_trans) {
         return VR_EUNSUPPORTED;
-    } else if (a.act == 1) {
+    } else if (a.act == 1 || (a.act == 2 && !a.dact_u)) {
         if (a.b_trans || of32 != (sizeof(T) == 4)) return VR_EUNSUPPORTED;
         launch1<T, false, false, T, EPI_GELU>(a, stream);
     } else if (a.dact_u) {

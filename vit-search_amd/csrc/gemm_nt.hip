@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     const int nc = nvalid > 0 ? n : 0;
     const int nv = nvalid > 0 ? nvalid : 1;
     constexpr int OALIGN = sizeof(TO) == 2 ? 8 : 4;
-    const bool vec = FAST || (nvalid == CW && (p.ldc % OALIGN == 0) && (EPI != EPI_DGELU || p.ldu % 8 == 0));
+    const bool vec = FAST || (nvalid == CW && (p.ldc % OALIGN == 0) && ((EPI != EPI_DGELU && EPI != EPI_DMUL) || p.ldu % 8 == 0));
     const bool vecb = FAST || (nvalid == CW && (p.N % 4 == 0));
     // prefix masks: the lane's 8 columns sit at ncp.. inside their period (periods are multiples of 8 on this path, so a
     // group never wraps; other periods take the per-element test)
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         for (int q = 0; q < NQ; ++q) {
             rm[q] = meta[i * 16 + q * RPP];
             oidx[q] = (long long)(rm[q].orow < 0 ? 0 : rm[q].orow) * p.ldc + nc;
-            if constexpr (EPI == EPI_DGELU) loadw<bf16_t, CW>(p.dact_u, (long long)(rm[q].orow < 0 ? 0 : rm[q].orow) * p.ldu + nc, rv[q], vec, nv);
+            if constexpr (EPI == EPI_DGELU || EPI == EPI_DMUL) loadw<bf16_t, CW>(p.dact_u, (long long)(rm[q].orow < 0 ? 0 : rm[q].orow) * p.ldu + nc, rv[q], vec, nv);
             if constexpr (EPI == EPI_STORE) {
                 if (has_res) loadw<float, CW>(p.resid, oidx[q], rv[q], vec, nv);
                 if (has_pos) loadw<float, CW>(p.pos, (long long)rm[q].mloc * p.N + nc, pv[q], vecb, nv);
@@ -331,10 +331,24 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
 #pragma unroll
                 for (int e = 0; e < CW; ++e) v[e] *= dgelu_fast(rv[q][e]);
             }
+            if constexpr (EPI == EPI_DMUL) {                       // the forward saved gelu'(u) itself (act == 2)
+#pragma unroll
+                for (int e = 0; e < CW; ++e) v[e] *= rv[q][e];
+            }
             float hh[CW];
             if constexpr (EPI == EPI_GELU) {
+                if (p.act == 2) {                                  // C = gelu'(u) instead of u: the backward multiplies by it
 #pragma unroll
-                for (int e = 0; e < CW; ++e) hh[e] = gelu_fast(v[e]);
+                    for (int e = 0; e < CW; ++e) {
+                        float cdf, pdf;
+                        gelu_terms_fast(v[e], cdf, pdf);
+                        hh[e] = v[e] * cdf;
+                        v[e] = fmaf(v[e], pdf, cdf);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) hh[e] = gelu_fast(v[e]);
+                }
             }
             if (has_mask) {
                 const int kn = rm[q].keep - ncp;                       // kept columns of this lane's group (>= 8: all)
@@ -437,12 +451,13 @@ bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_nt;
     if (a.in_dtype != VR_BF16 || a.a_trans || a.b_trans || a.atomic || a.split_k > 1 || a.bias_grad) return false;
     const bool of32 = a.out_dtype == VR_F32;
-    if (a.act == 1) {
+    if (a.act == 1 || (a.act == 2 && !a.dact_u)) {
         if (of32) return false;
         launch1<bf16_t, EPI_GELU>(a, stream, n_cu);
     } else if (a.dact_u) {
         if (of32) return false;
-        launch1<bf16_t, EPI_DGELU>(a, stream, n_cu);
+        if (a.act == 2) launch1<bf16_t, EPI_DMUL>(a, stream, n_cu);
+        else launch1<bf16_t, EPI_DGELU>(a, stream, n_cu);
     } else if (of32) {
         launch1<float, EPI_STORE>(a, stream, n_cu);
     } else {

@@ -24,7 +24,8 @@ __device__ __forceinline__ int max_keep(const int* keep, int s_lo, int s_hi, int
 //   EPI_GELU  : (+bias) -> C = u, C2 = gelu(u) masked by keep            (Mlp.fc1)
 //   EPI_DGELU : * gelu'(u) -> keep mask -> store TO                        (fc2 dgrad)
 //   EPI_ATOMIC: keep mask/scale -> atomicAdd fp32                          (split-K wgrad)
-enum { EPI_STORE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_ATOMIC = 3 };
+//   EPI_DMUL  : * saved gelu'(u) (dact_u holds the derivative itself, act == 2) -> keep mask -> store TO
+enum { EPI_STORE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_ATOMIC = 3, EPI_DMUL = 4 };
 
 // CW consecutive elements (CW = 4 or 8): 16-byte accesses whenever the group is whole and aligned
 template <typename TI, int CW> __device__ __forceinline__ void loadw(const void* base, long long idx, float (&v)[CW], bool vec,

@@ -285,9 +285,11 @@ def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save, pre=N
     y, mean, rstd = pre if pre is not None else K.ln_fwd(x, p["n2w"], p["n2b"], embed_keep, N, cfg["eps"], dt)
     h = torch.empty((B, N, F), dtype=dt, device=x.device)
     if save:
+        # bf16: the tensor kept for the backward is gelu'(u), not u (act = 2): fc1's epilogue has the erf terms at hand, and fc2's
+        # data gradient becomes a plain multiply (its erf / exp per element made that kernel VALU-bound); fp32 parity mode keeps u
         u = torch.empty((B, N, F), dtype=dt, device=x.device)
-        K.gemm(y, p["fc1"].w_c, u, out2=h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b, act=1,
-               keep_n=mlp_keep, rows_in=N, keep_k=embed_keep)
+        K.gemm(y, p["fc1"].w_c, u, out2=h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b,
+               act=(2 if dt == torch.bfloat16 else 1), keep_n=mlp_keep, rows_in=N, keep_k=embed_keep)
     else:                                       # forward-only: the pre-activation is not kept, fc1 writes gelu(u) alone
         u = None
         K.gemm(y, p["fc1"].w_c, h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b, act=1,
@@ -326,7 +328,8 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     else:
         wgrad_fc2()
     du = torch.empty((B, N, F), dtype=dt, device=x.device)
-    linear_dgrad(gt, p["fc2"], du, M, F, C, C, F, dact_u=u, ldu=F, keep_n=mlp_keep, rows_in=N, keep_k=out_keep, sched=sch)
+    linear_dgrad(gt, p["fc2"], du, M, F, C, C, F, dact_u=u, ldu=F, keep_n=mlp_keep, rows_in=N, keep_k=out_keep, sched=sch,
+                 act=(2 if dt == torch.bfloat16 else 0))
 
     def wgrad_fc1():
         linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"], keep_rows=mlp_keep, keep_cols=embed_keep,
