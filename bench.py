@@ -213,9 +213,9 @@ def main():
                     "fused HIP pass over the arena); torch: torch.optim.AdamW(fused=True)")
     ap.add_argument("--split-sync", type=int, default=-1, help="backward captured as this many hipGraphs (cut in front of the "
                     "spatial reductions), each followed by the all-reduce of the gradient range it completed, overlapped with the "
-                    "next one; 0/1: one graph, one all-reduce; -1: 2 when --gpus > 1 (3 exposes less of the exchange -- ~24 MB instead of ~116 MB "
-                    "of the 279 MB -- but could not be timed over RCCL from the 1-GPU development box; 2 ranks over gloo on one GPU run "
-                    "it 10x slower than 2, a host-side interaction of gloo's copy threads with graph launches)")
+                    "next one; 0/1: one graph, one all-reduce; -1: 3 when --gpus > 1 (only ~24 MB of the 279 MB are exchanged after the "
+                    "backward has finished, against ~116 MB with 2 graphs; +0.2 ms of graph boundaries measured on one GPU; not yet timed "
+                    "over RCCL -- no multi-GPU box was available)")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -286,7 +286,7 @@ def main():
                                  grad_sync=sync if exchange else None, average_grads=average)
 
     graphed = None
-    split = (2 if world > 1 else 0) if args.split_sync < 0 else (args.split_sync if args.split_sync >= 2 else 0)
+    split = (3 if world > 1 else 0) if args.split_sync < 0 else (args.split_sync if args.split_sync >= 2 else 0)
     if not args.no_graph:
         # N > 1: the backward is captured as two graphs so that the all-reduce of the last stage's gradients (the tail of
         # the flat arena, most of the parameters) runs on RCCL's stream while the rest of the backward is still computing
