@@ -134,11 +134,12 @@ typedef struct vr_ln_epilogue {
     float* mean;             /* mode 0 out / mode 1 in: [M] */
     float* rstd;
     const float* x;          /* mode 1: the LayerNorm's input saved by the forward, fp32 [M, ldc] */
-    float* dw;               /* mode 1: fp32 [N], accumulated with atomics */
+    float* dw;               /* mode 1: fp32 [max(grad_copies,1)][N], accumulated with atomics (see vr_ln_bwd) */
     float* db;
     void* gt_out;            /* mode 1, optional: bf16 [M, ldc] */
     const float* gt_scale;   /* [batch] or NULL */
     const int32_t* gt_keep;  /* [batch] or NULL */
+    int32_t grad_copies;     /* mode 1: rows of partial sums behind dw / db, 0 or 1 = accumulate into dw / db themselves */
 } vr_ln_epilogue;
 int vr_gemm_ln(const vr_gemm_args* args, const vr_ln_epilogue* ln, vr_stream_t stream);
 int vr_gemm_ln_supported(int32_t N);
@@ -200,6 +201,9 @@ int vr_ln_fwd(const float* x, const float* w, const float* b, void* y, float* me
 /*
  * Masked LayerNorm backward (nets/masked_layer_norm.py:55-88).  dx_out = (dx_in ? dx_in : 0) + dLN/dx;
  * dw/db (fp32 [C]) are accumulated with atomics (caller zeroes them).  dy has dtype `dy_dtype`.
+ * grad_copies > 1: dw and db are [grad_copies][C] rows of partial sums, workgroup i adds into row i % grad_copies (hundreds
+ *   of workgroups hitting the same 2C addresses cost a third of the kernel); vr_ln_grad_reduce folds the rows into the
+ *   parameter gradients afterwards.
  * gt_out (optional, dtype `dy_dtype`, [M,C]): the gradient entering the NEXT backward branch, written in the same pass --
  *   gt_out[m,c] = c < gt_keep[s] ? dx_out[m,c] * gt_scale[s] : 0   (s = m / rows_per_sample; NULL scale = 1, NULL keep = C)
  * i.e. what vr_scale_mask_cast would produce from dx_out (DropPath nets/drop.py:11-26 + ChannelDrop mask backward).
@@ -207,7 +211,22 @@ int vr_ln_fwd(const float* x, const float* w, const float* b, void* y, float* me
 int vr_ln_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
               const int32_t* keep, const float* dx_in, float* dx_out, float* dw, float* db,
               void* gt_out, const float* gt_scale, const int32_t* gt_keep,
-              int32_t M, int32_t C, int32_t rows_per_sample, int32_t dy_dtype, vr_stream_t stream);
+              int32_t M, int32_t C, int32_t rows_per_sample, int32_t dy_dtype, int32_t grad_copies, vr_stream_t stream);
+
+/*
+ * Fold the partial rows written by vr_ln_bwd / vr_gemm_ln (mode 1) with grad_copies = `copies` into the LayerNorm parameter
+ * gradients: dw[c] += sum_k part_w[k][c], db[c] += sum_k part_b[k][c]; the partial rows are zero again afterwards (the
+ * caller allocates them zero-filled once).  One launch per 32 slots.
+ */
+typedef struct vr_ln_grad_slot {
+    float* part_w;           /* [copies][C] */
+    float* part_b;           /* [copies][C] */
+    float* dw;               /* [C] */
+    float* db;               /* [C] */
+    int32_t C;
+    int32_t reserved;
+} vr_ln_grad_slot;
+int vr_ln_grad_reduce(const vr_ln_grad_slot* slots, int32_t count, int32_t copies, vr_stream_t stream);
 
 /*
  * Multi-head self-attention core (nets/supernet_blocks.py:105-109): qkv [B,N,3,H,D] -> o [B,N,H*D],

@@ -121,7 +121,7 @@ def ln_fwd(x, w, b, keep, rows_per_sample, eps, out_dtype):
     return y.view(x.shape).to(out_dtype), mu, rstd
 
 
-def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db, next_cast=None):
+def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db, next_cast=None, copies=1):
     C = x.shape[-1]
     X = x.reshape(-1, C).float()
     G = dy.reshape(-1, C).float()
@@ -136,8 +136,9 @@ def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db, next_cast
     if dx_in is not None:
         dx = dx + dx_in.reshape(-1, C)
     dx = dx * mask
-    dw += (G * z).sum(0)
-    db += G.sum(0)
+    # copies > 1: [copies, C] rows of partial sums (the kernels spread their workgroups over them) -- one row will do here
+    (dw[0] if copies > 1 else dw).add_((G * z).sum(0))
+    (db[0] if copies > 1 else db).add_(G.sum(0))
     dx = dx.view(x.shape)
     if next_cast is None:
         return dx
@@ -161,11 +162,20 @@ def gemm_ln_fwd(a, b, out, ln_w, ln_b, ln_keep, eps, *, M, N, K, lda, ldb, ldc, 
 
 
 def gemm_ln_bwd(du, wt, x, ln_w, mean, rstd, ln_keep, dx_in, dw, db, next_cast=None, *, M, N, K, lda, ldb, rows_in=0,
-                keep_k=None, k_period=0):
+                keep_k=None, k_period=0, copies=1):
     dy = torch.empty(x.shape, dtype=torch.float32)
     gemm(du.float(), wt.float(), dy, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, rows_in=rows_in, keep_k=keep_k, k_period=k_period)
-    out = ln_bwd(dy, x, ln_w, mean, rstd, ln_keep, rows_in or M, dx_in, dw, db, next_cast=next_cast)
+    out = ln_bwd(dy, x, ln_w, mean, rstd, ln_keep, rows_in or M, dx_in, dw, db, next_cast=next_cast, copies=copies)
     return out if next_cast is None else (out[0], out[1].to(torch.bfloat16))
+
+
+def ln_grad_reduce(slots, copies):
+    for pw, pb, dw, db in slots:
+        assert pw.shape == (copies, dw.numel()) and pb.shape == (copies, db.numel())
+        dw += pw.sum(0)
+        db += pb.sum(0)
+        pw.zero_()
+        pb.zero_()
 
 
 def attn_fwd(qkv, keep_hd, B, N, H, D, scale):
@@ -387,7 +397,7 @@ def patch_fold(col, B, gh, gw, P, C):
     return x.reshape(B * gh * P * gw * P, C).clone()
 
 
-ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "gemm_group", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "softce_train", "colsum", "scale_mask_cast",
+ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "gemm_group", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "ln_grad_reduce", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "softce_train", "colsum", "scale_mask_cast",
        "batchsum", "conv3x3", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
 
 

@@ -183,6 +183,40 @@ def test_layernorm_fwd_bwd(out_dtype, C, masked):
         assert torch.equal(gt.cpu(), ref)
 
 
+@pytest.mark.parametrize("C,copies", [(256, 64), (320, 7), (512, 64)])
+def test_layernorm_grad_partial_rows(C, copies):
+    """grad_copies: the workgroups spread their dgamma / dbeta sums over `copies` rows and vr_ln_grad_reduce folds them into
+    the gradients (which already hold a value) and leaves the rows zero; vr_gemm_ln mode 1 likewise."""
+    B, N = 24, 65
+    x = (rnd(B, N, C, seed=1) + 0.3).to(DEV)
+    w, b = (1 + 0.1 * rnd(C, seed=2)).to(DEV), (0.1 * rnd(C, seed=3)).to(DEV)
+    keep = torch.tensor([C, C // 2, C - 4, 8] * (B // 4), dtype=torch.int32, device=DEV)
+    y, mean, rstd = K.ln_fwd(x, w, b, keep, N, 1e-6, torch.bfloat16)
+    dy = rnd(B, N, C, seed=4).to(torch.bfloat16).to(DEV)
+    gin = rnd(B, N, C, seed=5).to(DEV)
+    base_w, base_b = rnd(C, seed=6).to(DEV), rnd(C, seed=7).to(DEV)
+    dw0, db0 = base_w.clone(), base_b.clone()
+    dx0 = K.ln_bwd(dy, x, w, mean, rstd, keep, N, gin, dw0, db0)
+    part = torch.zeros(2, copies, C, device=DEV)
+    dw1, db1 = base_w.clone(), base_b.clone()
+    dx1 = K.ln_bwd(dy, x, w, mean, rstd, keep, N, gin, part[0], part[1], copies=copies)
+    assert torch.equal(dx0, dx1)
+    assert torch.equal(dw1, base_w) and int((part[0].abs().sum(1) > 0).sum()) == copies
+    K.ln_grad_reduce([(part[0], part[1], dw1, db1)], copies)
+    assert relerr(dw1, dw0) < 1e-5 and relerr(db1, db0) < 1e-5
+    assert float(part.abs().max()) == 0.0
+    if K.gemm_ln_supported(dy, C, C):
+        Kd = 192
+        du, wt = _bf(rnd(B * N, Kd, seed=8)).to(DEV), _bf(rnd(C, Kd, seed=9, scale=Kd ** -0.5)).to(DEV)
+        dwa, dba, dwb, dbb = base_w.clone(), base_b.clone(), base_w.clone(), base_b.clone()
+        kw = dict(M=B * N, N=C, K=Kd, lda=Kd, ldb=Kd, rows_in=N)
+        dxa = K.gemm_ln_bwd(du, wt, x, w, mean, rstd, keep, gin, dwa, dba, **kw)
+        dxb = K.gemm_ln_bwd(du, wt, x, w, mean, rstd, keep, gin, part[0], part[1], copies=copies, **kw)
+        K.ln_grad_reduce([(part[0], part[1], dwb, dbb)], copies)
+        assert torch.equal(dxa, dxb)
+        assert relerr(dwb, dwa) < 1e-5 and relerr(dbb, dba) < 1e-5 and float(part.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,H,D", [(17, 2, 64), (65, 3, 48), (257, 2, 32), (257, 3, 64), (5, 2, 48), (2, 2, 64)])
 def test_attention_fwd_bwd(dtype, N, H, D):

@@ -395,12 +395,13 @@ __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, con
             *reinterpret_cast<float4*>(red + (1 * 4 + wave) * BN + 4 * (lane + 64 * v)) = gb[v];
         }
         __syncthreads();
+        const long long grow = (long long)(blockIdx.x % (unsigned)(f.grad_copies > 1 ? f.grad_copies : 1)) * p.N;
         for (int c = t; c < BN; c += NTHR) {
             if (c < p.N) {
                 const float a = red[0 * BN + c] + red[1 * BN + c] + red[2 * BN + c] + red[3 * BN + c];
                 const float b2 = red[4 * BN + c] + red[5 * BN + c] + red[6 * BN + c] + red[7 * BN + c];
-                atomicAdd(f.dw + c, a);
-                atomicAdd(f.db + c, b2);
+                atomicAdd(f.dw + grow + c, a);                 // partial row of this workgroup (vr_ln_bwd's grad_copies)
+                atomicAdd(f.db + grow + c, b2);
             }
         }
     }

@@ -3,6 +3,7 @@
 // write of y; backward: read dy,x once, write dx once).  The prefix mask of each sample is an int keep
 // count: statistics and outputs use only channels c < keep (channels beyond are exactly zero upstream).
 #include "common.h"
+#include <cstdlib>
 #include "../../include/vitres_hip.h"
 
 namespace {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TI* __restrict__ dy, 
                                                      const float* __restrict__ dx_in, float* __restrict__ dx_out,
                                                      float* __restrict__ dw, float* __restrict__ db, TI* __restrict__ gt_out,
                                                      const float* __restrict__ gt_scale, const int* __restrict__ gt_keep,
-                                                     int M, int C, int rps, int BWD_ROWS) {
+                                                     int M, int C, int rps, int BWD_ROWS, int copies) {
     __shared__ float red[2][4][64 * 4];  // [dw|db][wave][lane*4+e], reused per j
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 gw[MAXV], gb[MAXV], ww[MAXV];
@@ -199,10 +200,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TI* __restrict__ dy, 
         if (c < C) {
             const float a = red[0][0][e] + red[0][1][e] + red[0][2][e] + red[0][3][e];
             const float bsum = red[1][0][e] + red[1][1][e] + red[1][2][e] + red[1][3][e];
-            atomicAdd(dw + c, a);
-            atomicAdd(db + c, bsum);
+            // `copies` rows of partial sums (vr_ln_grad_reduce folds them): the atomics of ~500..2000 workgroups on the same
+            // 2C addresses were a third of this kernel's time
+            const long long row = (long long)(blockIdx.x % (unsigned)copies) * C;
+            atomicAdd(dw + row + c, a);
+            atomicAdd(db + row + c, bsum);
         }
     }
+}
+
+struct GradSlots {
+    static constexpr int MAX = 32;
+    vr_ln_grad_slot s[MAX];
+};
+
+// dw[c] += sum_k part_w[k][c] (same for db) and the partial rows go back to zero for the next backward
+__global__ __launch_bounds__(256) void ln_grad_reduce_kernel(GradSlots slots, int copies) {
+    const vr_ln_grad_slot& sl = slots.s[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int C = sl.C;
+    if (e >= 2 * C) return;
+    float* part = e < C ? sl.part_w + e : sl.part_b + (e - C);
+    float* dst = e < C ? sl.dw + e : sl.db + (e - C);
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= copies; k += 4) {
+        acc0 += part[(long long)(k + 0) * C];
+        acc1 += part[(long long)(k + 1) * C];
+        acc2 += part[(long long)(k + 2) * C];
+        acc3 += part[(long long)(k + 3) * C];
+    }
+    for (; k < copies; ++k) acc0 += part[(long long)k * C];
+    for (k = 0; k < copies; ++k) part[(long long)k * C] = 0.f;
+    *dst += (acc0 + acc1) + (acc2 + acc3);
 }
 
 }  // namespace
@@ -239,21 +269,26 @@ extern "C" int vr_ln_fwd(const float* x, const float* w, const float* b, void* y
 extern "C" int vr_ln_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
                          const int32_t* keep, const float* dx_in, float* dx_out, float* dw, float* db, void* gt_out,
                          const float* gt_scale, const int32_t* gt_keep, int32_t M, int32_t C, int32_t rows_per_sample,
-                         int32_t dy_dtype, vr_stream_t stream) {
-    if (!dy || !x || !w || !mean || !rstd || !dx_out || !dw || !db || M <= 0 || C <= 0) return VR_EINVAL;
+                         int32_t dy_dtype, int32_t grad_copies, vr_stream_t stream) {
+    if (!dy || !x || !w || !mean || !rstd || !dx_out || !dw || !db || M <= 0 || C <= 0 || grad_copies < 0) return VR_EINVAL;
+    const int copies = grad_copies > 1 ? grad_copies : 1;
     if (C % 4 || C > 64 * 4 * MAXV_LIMIT) return VR_EUNSUPPORTED;
     if (dy_dtype != VR_F32 && dy_dtype != VR_BF16) return VR_EUNSUPPORTED;
     if (rows_per_sample <= 0) rows_per_sample = M;
-    const int BWD_ROWS = M >= 32768 ? 64 : (M >= 8192 ? 32 : (M >= 2048 ? 8 : 4));
+    // rows per workgroup: with partial rows the atomics no longer collide, so many small workgroups (better tail) win
+    static const int knob_rows = std::getenv("VITRES_LN_BWD_ROWS") ? std::atoi(std::getenv("VITRES_LN_BWD_ROWS")) : 0;
+    const int BWD_ROWS = knob_rows > 0 ? knob_rows
+                         : copies > 1  ? (M >= 8192 ? 16 : (M >= 2048 ? 8 : 4))
+                                       : (M >= 32768 ? 64 : (M >= 8192 ? 32 : (M >= 2048 ? 8 : 4)));
     dim3 grid((M + BWD_ROWS - 1) / BWD_ROWS);
     const int nv = (C + 255) / 256;
 #define VR_LN_BWD(NV)                                                                                                  \
     if (dy_dtype == VR_F32)                                                                                            \
         hipLaunchKernelGGL((ln_bwd_kernel<float, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, x, w, \
-                           mean, rstd, keep, dx_in, dx_out, dw, db, (float*)gt_out, gt_scale, gt_keep, M, C, rows_per_sample, BWD_ROWS); \
+                           mean, rstd, keep, dx_in, dx_out, dw, db, (float*)gt_out, gt_scale, gt_keep, M, C, rows_per_sample, BWD_ROWS, copies); \
     else                                                                                                               \
         hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, \
-                           w, mean, rstd, keep, dx_in, dx_out, dw, db, (bf16_t*)gt_out, gt_scale, gt_keep, M, C, rows_per_sample, BWD_ROWS);
+                           w, mean, rstd, keep, dx_in, dx_out, dw, db, (bf16_t*)gt_out, gt_scale, gt_keep, M, C, rows_per_sample, BWD_ROWS, copies);
     switch (nv) {
         case 1: VR_LN_BWD(1) break;
         case 2: VR_LN_BWD(2) break;
@@ -264,5 +299,23 @@ extern "C" int vr_ln_bwd(const void* dy, const float* x, const float* w, const f
     }
 #undef VR_LN_BWD
     VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_ln_grad_reduce(const vr_ln_grad_slot* slots, int32_t count, int32_t copies, vr_stream_t stream) {
+    if (count < 0 || copies < 1 || (count > 0 && !slots)) return VR_EINVAL;
+    for (int i = 0; i < count; ++i)
+        if (!slots[i].part_w || !slots[i].part_b || !slots[i].dw || !slots[i].db || slots[i].C <= 0) return VR_EINVAL;
+    for (int first = 0; first < count; first += GradSlots::MAX) {
+        GradSlots g;
+        const int n = count - first < GradSlots::MAX ? count - first : GradSlots::MAX;
+        int cmax = 0;
+        for (int i = 0; i < n; ++i) {
+            g.s[i] = slots[first + i];
+            cmax = g.s[i].C > cmax ? g.s[i].C : cmax;
+        }
+        hipLaunchKernelGGL(ln_grad_reduce_kernel, dim3((2 * cmax + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, g, copies);
+        VR_CHECK_LAUNCH();
+    }
     return VR_OK;
 }

@@ -35,7 +35,12 @@ class GemmArgs(ctypes.Structure):
 class LnEpilogue(ctypes.Structure):
     _fields_ = [("mode", c_int32), ("eps", c_float), ("w", c_void_p), ("b", c_void_p), ("keep", c_void_p), ("y", c_void_p),
                 ("mean", c_void_p), ("rstd", c_void_p), ("x", c_void_p), ("dw", c_void_p), ("db", c_void_p),
-                ("gt_out", c_void_p), ("gt_scale", c_void_p), ("gt_keep", c_void_p)]
+                ("gt_out", c_void_p), ("gt_scale", c_void_p), ("gt_keep", c_void_p), ("grad_copies", c_int32)]
+
+
+class LnGradSlot(ctypes.Structure):
+    _fields_ = [("part_w", c_void_p), ("part_b", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("C", c_int32),
+                ("reserved", c_int32)]
 
 
 # name -> argtypes ; every entry point returns int.  Must list every symbol of include/vitres_hip.h
@@ -50,7 +55,8 @@ SYMBOLS = {
     "vr_adamw_flat_dev": [c_void_p] * 6 + [c_float, c_void_p, c_void_p, c_int32, c_int64, c_void_p],
     "vr_cast_transpose_batch": [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p],
     "vr_ln_fwd": [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_float, c_int32, c_void_p],
-    "vr_ln_bwd": [c_void_p] * 13 + [c_int32, c_int32, c_int32, c_int32, c_void_p],
+    "vr_ln_bwd": [c_void_p] * 13 + [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
+    "vr_ln_grad_reduce": [ctypes.POINTER(LnGradSlot), c_int32, c_int32, c_void_p],
     "vr_attn_fwd": [c_void_p] * 4 + [c_int32] * 4 + [c_float, c_int32, c_void_p],
     "vr_attn_bwd": [c_void_p] * 7 + [c_int32] * 4 + [c_float, c_int32, c_void_p],
     "vr_softce": [c_void_p] * 4 + [c_int32, c_int32, c_float, c_void_p],

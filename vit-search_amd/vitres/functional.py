@@ -38,6 +38,38 @@ PROJ_LATE = _os.environ.get('VITRES_PROJ_LATE', '0') != '0'      # issue proj's 
 FUSE_LN = int(_os.environ.get('VITRES_FUSE_LN', '3'))
 FUSE_LN_MAXN = int(_os.environ.get('VITRES_FUSE_LN_MAXN', '256'))
 FUSE_LN_FWD_MAXK = int(_os.environ.get('VITRES_FUSE_LN_FWD_MAXK', '4096'))
+# LayerNorm weight / bias gradients: the workgroups of a LayerNorm backward add their column sums into LN_COPIES rows of
+# partial sums (grads["<weight key>.part"], [2, LN_COPIES, C], kept zero between backwards) instead of all of them into
+# the same 2C addresses; flush_ln_grads() folds the rows of every LayerNorm of a backward part in one launch.  vr_ln_bwd at
+# (128 x 257, 256): 33 -> 23 us.  0 / 1 = accumulate straight into the parameter gradients.
+LN_COPIES = int(_os.environ.get('VITRES_LN_COPIES', '64'))
+_ln_pending = []
+
+
+def _ln_dst(grads, wk, bk):
+    """(dw, db, copies) for the LayerNorm backward kernels."""
+    part = grads.get(wk + ".part") if LN_COPIES > 1 else None
+    if part is None:
+        return grads[wk], grads[bk], 1
+    _ln_pending.append((part[0], part[1], grads[wk], grads[bk]))
+    return part[0], part[1], part.shape[1]
+
+
+def flush_ln_grads():
+    """Fold the partial rows written since the last flush into the parameter gradients (current stream)."""
+    if _ln_pending:
+        slots = list(_ln_pending)
+        _ln_pending.clear()
+        K.ln_grad_reduce(slots, slots[0][0].shape[0])
+
+
+def reset_ln_grads():
+    """Drop slots left behind by a backward that raised; returns True if there were any (their rows need re-zeroing)."""
+    dirty = bool(_ln_pending)
+    _ln_pending.clear()
+    return dirty
+
+
 STEM_SIDE = _os.environ.get('VITRES_STEM_SIDE', '1') != '0'      # conv-stem weight gradients on the side stream (+2 % since SIDE_DEFER)
 _side_streams = {}
 
@@ -264,14 +296,16 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     else:
         wgrad_qkv()
     if (FUSE_LN & 2) and C <= FUSE_LN_MAXN and p["qkv"].w_t is not None and K.gemm_ln_supported(dqkv, C, C):
-        out = K.gemm_ln_bwd(dqkv, p["qkv"].w_t, x, p["n1w"], mean, rstd, embed_keep, g, grads["n1w"], grads["n1b"],
+        dw, db, cp = _ln_dst(grads, "n1w", "n1b")
+        out = K.gemm_ln_bwd(dqkv, p["qkv"].w_t, x, p["n1w"], mean, rstd, embed_keep, g, dw, db,
                             next_cast=next_cast, M=M, N=C, K=3 * HD, lda=3 * HD, ldb=p["qkv"].ld_t, rows_in=N,
-                            keep_k=attn_keep, k_period=HD)
+                            keep_k=attn_keep, k_period=HD, copies=cp)
     else:
         dy = torch.empty((B, N, C), dtype=dt, device=x.device)
         linear_dgrad(dqkv, p["qkv"], dy, M, C, 3 * HD, 3 * HD, C, rows_in=N, keep_k=attn_keep, k_period=HD, keep_n=embed_keep,
                      sched=sch)
-        out = K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, grads["n1w"], grads["n1b"], next_cast=next_cast)
+        dw, db, cp = _ln_dst(grads, "n1w", "n1b")
+        out = K.ln_bwd(dy, x, p["n1w"], mean, rstd, embed_keep, N, g, dw, db, next_cast=next_cast, copies=cp)
     if ov and not DEFER_JOIN:
         join_side_lagged()
     return out
@@ -339,12 +373,14 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     else:
         wgrad_fc1()
     if (FUSE_LN & 2) and C <= FUSE_LN_MAXN and p["fc1"].w_t is not None and K.gemm_ln_supported(du, C, C):
-        out = K.gemm_ln_bwd(du, p["fc1"].w_t, x, p["n2w"], mean, rstd, embed_keep, g, grads["n2w"], grads["n2b"],
-                            next_cast=next_cast, M=M, N=C, K=F, lda=F, ldb=p["fc1"].ld_t, rows_in=N, keep_k=mlp_keep)
+        dw, db, cp = _ln_dst(grads, "n2w", "n2b")
+        out = K.gemm_ln_bwd(du, p["fc1"].w_t, x, p["n2w"], mean, rstd, embed_keep, g, dw, db,
+                            next_cast=next_cast, M=M, N=C, K=F, lda=F, ldb=p["fc1"].ld_t, rows_in=N, keep_k=mlp_keep, copies=cp)
     else:
         dy = torch.empty((B, N, C), dtype=dt, device=x.device)
         linear_dgrad(du, p["fc1"], dy, M, C, F, F, C, rows_in=N, keep_k=mlp_keep, keep_n=embed_keep, sched=sch)
-        out = K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, grads["n2w"], grads["n2b"], next_cast=next_cast)
+        dw, db, cp = _ln_dst(grads, "n2w", "n2b")
+        out = K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, dw, db, next_cast=next_cast, copies=cp)
     if ov and not DEFER_JOIN and not JOIN_PER_BLOCK:
         join_side_lagged()
     return out
@@ -407,7 +443,8 @@ def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep, gt=None, next_cast=
     K.sr_col2im(dcol, dy, B, g, C, T)
     linear_dgrad(gt, p["token"], dy, B * T, C, Co, Co, C, a_map=(T, No, 0), c_map=(T, Ni, 0), rows_in=T)
     gres = K.sr_resid_bwd(gout, B, g, C, Co, T)
-    out = K.ln_bwd(dy, x, p["nw"], mean, rstd, embed_keep, Ni, gres, grads["nw"], grads["nb"], next_cast=next_cast)
+    dw, db, cp = _ln_dst(grads, "nw", "nb")
+    out = K.ln_bwd(dy, x, p["nw"], mean, rstd, embed_keep, Ni, gres, dw, db, next_cast=next_cast, copies=cp)
     if _overlap(gout):
         join_side_lagged()                 # (a full join here stalled the main chain ~200 us behind the conv weight gradient)
     return out
@@ -520,4 +557,5 @@ def head_bwd(dcls, dpat, saved, p, grads, cfg, keep, next_cast=None, ready=False
         linear_dgrad(gp, p["patch"], dy, R, C, nc, ldp, C, c_map=(N - T, N, T))
     if side:
         on_side(lambda: [fn() for fn, _ in side], y, *[t_ for _, keep in side for t_ in keep])
-    return K.ln_bwd(dy, x, p["nw"], mean, rstd, keep, N, None, grads["nw"], grads["nb"], next_cast=next_cast)
+    dw, db, cp = _ln_dst(grads, "nw", "nb")
+    return K.ln_bwd(dy, x, p["nw"], mean, rstd, keep, N, None, dw, db, next_cast=next_cast, copies=cp)

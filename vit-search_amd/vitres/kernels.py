@@ -112,8 +112,9 @@ def gemm_ln_fwd(a, b, out, ln_w, ln_b, ln_keep, eps, *, M, N, K, lda, ldb, ldc, 
 
 
 def gemm_ln_bwd(du, wt, x, ln_w, mean, rstd, ln_keep, dx_in, dw, db, next_cast=None, *, M, N, K, lda, ldb, rows_in=0,
-                keep_k=None, k_period=0):
-    """LayerNorm backward of dy = du @ wt^T without writing dy -- vr_gemm_ln mode 1; returns dx or (dx, gt) like ln_bwd."""
+                keep_k=None, k_period=0, copies=1):
+    """LayerNorm backward of dy = du @ wt^T without writing dy -- vr_gemm_ln mode 1; returns dx or (dx, gt) like ln_bwd
+    (copies: dw / db are [copies, N] partial rows, see ln_bwd)."""
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     gt = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if next_cast is not None else None
     sc, kp = next_cast if next_cast is not None else (None, None)
@@ -123,6 +124,7 @@ def gemm_ln_bwd(du, wt, x, ln_w, mean, rstd, ln_keep, dx_in, dw, db, next_cast=N
     ln.mode, ln.eps = 1, 0.0
     ln.w, ln.keep, ln.mean, ln.rstd, ln.x = _p(ln_w), _p(ln_keep), _p(mean), _p(rstd), _p(x)
     ln.dw, ln.db, ln.gt_out, ln.gt_scale, ln.gt_keep = _p(dw), _p(db), _p(gt), _p(sc), _p(kp)
+    ln.grad_copies = copies
     _launch_gemm_ln(args, ln, du, M, N, K, rows_in, keep_k, ln_keep, k_period, M * N * (4 + 4 + 4 + 2))
     return dx if next_cast is None else (dx, gt)
 
@@ -245,16 +247,31 @@ def ln_fwd(x, w, b, keep, rows_per_sample, eps, out_dtype):
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db, next_cast=None):
+def ln_bwd(dy, x, w, mean, rstd, keep, rows_per_sample, dx_in, dw, db, next_cast=None, copies=1):
     """next_cast = (scale or None, keep or None): also return scale_mask_cast(dx, scale, keep) in dy's dtype (the gradient
-    entering the next backward branch), produced in the same pass."""
+    entering the next backward branch), produced in the same pass.
+    copies > 1: dw / db are [copies, C] rows of partial sums that ln_grad_reduce folds into the parameter gradients."""
     M, C = x.numel() // x.shape[-1], x.shape[-1]
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     gt = torch.empty(x.shape, dtype=dy.dtype, device=x.device) if next_cast is not None else None
     sc, kp = next_cast if next_cast is not None else (None, None)
     _lib.check(_lib.lib().vr_ln_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(keep), _p(dx_in), _p(dx), _p(dw), _p(db),
-                                    _p(gt), _p(sc), _p(kp), M, C, rows_per_sample, _dt(dy), _stream()), "vr_ln_bwd")
+                                    _p(gt), _p(sc), _p(kp), M, C, rows_per_sample, _dt(dy), copies, _stream()), "vr_ln_bwd")
     return dx if next_cast is None else (dx, gt)
+
+
+def ln_grad_reduce(slots, copies):
+    """slots: (part_w [copies, C], part_b [copies, C], dw [C], db [C]) per LayerNorm -- dw += part_w.sum(0), db likewise, and
+    the partial rows are zero again (vr_ln_grad_reduce)."""
+    if not slots:
+        return
+    arr = (_lib.LnGradSlot * len(slots))()
+    for i, (pw, pb, dw, db) in enumerate(slots):
+        C = dw.numel()
+        assert pw.numel() == copies * C and pb.numel() == copies * C and db.numel() == C
+        assert pw.is_contiguous() and pb.is_contiguous() and dw.is_contiguous() and db.is_contiguous()
+        arr[i].part_w, arr[i].part_b, arr[i].dw, arr[i].db, arr[i].C = _p(pw), _p(pb), _p(dw), _p(db), C
+    _lib.check(_lib.lib().vr_ln_grad_reduce(arr, len(slots), copies, _stream()), "vr_ln_grad_reduce")
 
 
 def attn_fwd(qkv, keep_hd, B, N, H, D, scale):

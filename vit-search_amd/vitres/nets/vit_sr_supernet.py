@@ -375,6 +375,23 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         off, n = a["offsets"][a["index"][id(p)]]
         return a["gcur"][off:off + n].view(p.shape)
 
+    def _ln_parts(self):
+        """id(LayerNorm weight) -> [2, LN_COPIES, C] zero-filled rows of partial weight / bias gradient sums
+        (functional.LN_COPIES; one allocation for the whole network, made before any capture can be running)."""
+        a = self._arena
+        parts = a.get("ln_parts")
+        if parts is None or a.get("ln_copies") != Fn.LN_COPIES:
+            norms = [m for m in self.modules() if isinstance(m, (nn.LayerNorm, MaskedLayerNorm)) and m.weight is not None]
+            total = sum(2 * Fn.LN_COPIES * m.weight.numel() for m in norms)
+            flat = torch.zeros(total, dtype=torch.float32, device=a["flat"].device)
+            parts, off = {}, 0
+            for m in norms:
+                n = 2 * Fn.LN_COPIES * m.weight.numel()
+                parts[id(m.weight)] = flat[off:off + n].view(2, Fn.LN_COPIES, m.weight.numel())
+                off += n
+            a["ln_parts"], a["ln_parts_flat"], a["ln_copies"] = parts, flat, Fn.LN_COPIES
+        return parts
+
     # ---- host-side mask plan -----------------------------------------------------------------------
     def sample_plan(self, B):
         """Host side of one forward: sample every ChannelDrop (reference RNG protocol, call order) and lay out which
@@ -791,6 +808,10 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             a["gcur"].zero_()
         a["gzeroed"] = False
         Fn.join_side()                     # transposed weight shadows (issued beside the forward)
+        if Fn.LN_COPIES > 1:
+            self._ln_parts()
+            if Fn.reset_ln_grads():        # a backward died between a LayerNorm kernel and flush_ln_grads()
+                a["ln_parts_flat"].zero_()
         st = {"rtape": list(reversed(tape)), "plan": plan, "dcls": dcls, "dpat": dpat, "i": 0, "g": None, "gt": None,
               "ready": ready}
         # _bwd_split = j: stop after the head and blocks[j:]; the rest runs in resume_backward() (a second hipGraph, so that the
@@ -866,6 +887,13 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 return (None, ekeep0)
             return None
         gt = st["gt"]
+        parts = a.get("ln_parts") if Fn.LN_COPIES > 1 else None
+
+        def with_parts(grads, *pairs):
+            if parts is not None:
+                for key, w in pairs:
+                    grads[key + ".part"] = parts[id(w)]
+            return grads
         for ti in range(st["i"], stop):
             entry = rtape[ti]
             kind = entry[0]
@@ -877,6 +905,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                     grads["patch.w"], grads["patch.b"] = gv(self.patch_head.weight), gv(self.patch_head.bias)
                 if self.dst_head is not None:
                     grads["dst.w"], grads["dst.b"] = gv(self.dst_head.weight), gv(self.dst_head.bias)
+                with_parts(grads, ("nw", self.norm.weight))
                 nc = consumer_cast(ti)
                 g = Fn.head_bwd(dcls, dpat, sv, hp, grads, hcfg, hk, next_cast=nc, ready=st.get("ready", False))
                 g, gt = g if nc is not None else (g, None)
@@ -887,6 +916,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                          "proj.w": gv(blk.attn.proj.weight), "proj.b": gv(blk.attn.proj.bias),
                          "fc1.w": gv(blk.mlp.fc1.weight), "fc1.b": gv(blk.mlp.fc1.bias),
                          "fc2.w": gv(blk.mlp.fc2.weight), "fc2.b": gv(blk.mlp.fc2.bias)}
+                with_parts(grads, ("n1w", blk.norm1.weight), ("n2w", blk.norm2.weight))
                 g, gt = Fn.mlp_branch_bwd(g, sm, p, grads, cfg, ek, km, ko, s2, gt=gt, next_cast=(s1, ko))      # gt: attention branch's
                 nc = consumer_cast(ti)
                 g = Fn.attn_branch_bwd(g, sa, p, grads, cfg, ek, ka, ko, s1, gt=gt, next_cast=nc)
@@ -903,6 +933,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 grads = {"nw": gv(blk.norm.weight), "nb": gv(blk.norm.bias), "token.w": gv(blk.token_transform.weight),
                          "token.b": gv(blk.token_transform.bias), "reduce.b": gv(blk.patch_reduce.bias),
                          "reduce.w": wtmp, "pos_sum": ptmp, "finish": finish}
+                with_parts(grads, ("nw", blk.norm.weight))
                 nc = consumer_cast(ti)
                 g = Fn.sr_bwd(g, sv, p, grads, cfg, ek, nk, gt=gt, next_cast=nc)
                 g, gt = g if nc is not None else (g, None)
@@ -923,6 +954,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                     from .. import stem
                     stem.embed_conv_bwd(self, g, sv, ep, ecfg, ekeep, gv, gt=gt)
                 gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:self.num_tokens, :])
+        Fn.flush_ln_grads()                # LayerNorm weight / bias gradients of this part: partial rows -> arena
         if stop >= len(rtape) or getattr(self, "_bwd_join_parts", True):
             Fn.join_side()                 # weight-gradient GEMMs trail on the side stream (functional.on_side); an intermediate
                                            # stop joins too unless the next part follows in the same capture (_bwd_join_parts)
