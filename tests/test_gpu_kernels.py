@@ -183,6 +183,31 @@ def test_layernorm_fwd_bwd(out_dtype, C, masked):
         assert torch.equal(gt.cpu(), ref)
 
 
+def test_cast_transpose_batch_wide_and_ragged_tiles():
+    """W^T bf16 shadows: interior 64 x 64 tiles of aligned matrices take the vector path, everything else the scalar one."""
+    shapes = [(256, 768, 256), (1000, 1024, 1000), (72, 68, 72), (130, 64, 136), (64, 66, 64), (8, 8, 8)]
+    offs, entries, src_parts, n_dst = 0, [], [], 0
+    for i, (rows, cols, ld) in enumerate(shapes):
+        pad = 0 if i != 3 else 2                       # a source that is only 8-byte aligned
+        src_parts.append(torch.zeros(pad))
+        offs += pad
+        entries.append((offs, n_dst, rows, cols, ld))
+        src_parts.append(rnd(rows * cols, seed=10 + i))
+        offs += rows * cols
+        tail = (-offs) % 4
+        src_parts.append(torch.zeros(tail))
+        offs += tail
+        n_dst += cols * ld
+    src = torch.cat(src_parts).to(DEV)
+    dst = torch.zeros(n_dst, dtype=torch.bfloat16, device=DEV)
+    K.cast_transpose_batch(src, dst, K.tr_descs(entries, DEV))
+    for (so, do, rows, cols, ld) in entries:
+        want = src[so:so + rows * cols].view(rows, cols).t().to(torch.bfloat16)
+        got = dst[do:do + cols * ld].view(cols, ld)
+        assert torch.equal(got[:, :rows], want), (rows, cols, ld)
+        assert float(got[:, rows:].float().abs().sum()) == 0.0
+
+
 @pytest.mark.parametrize("C,copies", [(256, 64), (320, 7), (512, 64)])
 def test_layernorm_grad_partial_rows(C, copies):
     """grad_copies: the workgroups spread their dgamma / dbeta sums over `copies` rows and vr_ln_grad_reduce folds them into

@@ -222,16 +222,22 @@ __global__ __launch_bounds__(256) void ln_grad_reduce_kernel(GradSlots slots, in
     if (e >= 2 * C) return;
     float* part = e < C ? sl.part_w + e : sl.part_b + (e - C);
     float* dst = e < C ? sl.dw + e : sl.db + (e - C);
+    // sixteen independent loads in flight per round (one dependent load per partial row made this a 11 us kernel)
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     int k = 0;
-    for (; k + 4 <= copies; k += 4) {
-        acc0 += part[(long long)(k + 0) * C];
-        acc1 += part[(long long)(k + 1) * C];
-        acc2 += part[(long long)(k + 2) * C];
-        acc3 += part[(long long)(k + 3) * C];
+    for (; k + 16 <= copies; k += 16) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = part[(long long)(k + u) * C];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) part[(long long)(k + u) * C] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { acc0 += t[u]; acc1 += t[u + 1]; acc2 += t[u + 2]; acc3 += t[u + 3]; }
     }
-    for (; k < copies; ++k) acc0 += part[(long long)k * C];
-    for (k = 0; k < copies; ++k) part[(long long)k * C] = 0.f;
+    for (; k < copies; ++k) {
+        acc0 += part[(long long)k * C];
+        part[(long long)k * C] = 0.f;
+    }
     *dst += (acc0 + acc1) + (acc2 + acc3);
 }
 
