@@ -284,9 +284,53 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     if (has_bias) loadw<float, CW>(p.bias, nc, bv, vecb, nv);
     const bool live = nvalid > 0;
     const RowMeta* meta = rowmeta + wm * WROWS + (lane / LPR);
-    // one round per 16-row fragment: park [16 rows][WCOLS columns] (<= 4 KB per wave), read back as rows
+    // one round per 16-row fragment: park [16 rows][WCOLS columns] (<= 4 KB per wave), read back as rows.
+    // Side operands of the epilogue (saved gelu'(u) / pre-activation of the fc2 data gradient, fp32 residual stream) are
+    // requested as raw 16-byte loads ahead of their use -- the bf16 one a whole round ahead, the fp32 one (16 registers per
+    // round: a second copy would spill) at the top of its round in front of the park / barrier: issued behind the barrier
+    // of their own round, four rounds of exposed HBM latency made the fc2 data gradient 1.4x slower than the fc1 forward
+    // of the same shape.
+    constexpr bool SIDE_D = EPI == EPI_DGELU || EPI == EPI_DMUL;
+    constexpr bool SIDE_R = EPI == EPI_STORE && (FEAT == 2 || FEAT == 3);
+    constexpr bool PREF = FAST && (SIDE_D || SIDE_R);
+    RowMeta rmn[NQ];
+    uint4 dn[NQ];
+    float4 rn[NQ][2];
+    auto prefetch = [&](int i) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            rmn[q] = meta[i * 16 + q * RPP];
+            const long long row = rmn[q].orow < 0 ? 0 : rmn[q].orow;
+            if constexpr (SIDE_D)
+                dn[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.dact_u) + row * p.ldu + nc);
+            if constexpr (SIDE_R) {
+                const float* r = p.resid + row * p.ldc + nc;
+                rn[q][0] = *reinterpret_cast<const float4*>(r);
+                rn[q][1] = *reinterpret_cast<const float4*>(r + 4);
+            }
+        }
+    };
+    if constexpr (SIDE_D && PREF) prefetch(0);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        if constexpr (SIDE_R && PREF) prefetch(i);
+        RowMeta rm[NQ];
+        long long oidx[NQ];
+        float rv[NQ][CW], pv[NQ][CW];
+        uint4 dc[NQ];
+        float4 rc[NQ][2];
+        if constexpr (PREF) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                rm[q] = rmn[q];
+                dc[q] = dn[q];
+                rc[q][0] = rn[q][0];
+                rc[q][1] = rn[q][1];
+            }
+            if constexpr (SIDE_D) {
+                if (i + 1 < MI) prefetch(i + 1);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int slot = (4 * j + (lane >> 4)) ^ (lane & (4 * NJ - 1));
@@ -294,17 +338,29 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        RowMeta rm[NQ];
-        long long oidx[NQ];
-        float rv[NQ][CW], pv[NQ][CW];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            rm[q] = meta[i * 16 + q * RPP];
-            oidx[q] = (long long)(rm[q].orow < 0 ? 0 : rm[q].orow) * p.ldc + nc;
-            if constexpr (EPI == EPI_DGELU || EPI == EPI_DMUL) loadw<bf16_t, CW>(p.dact_u, (long long)(rm[q].orow < 0 ? 0 : rm[q].orow) * p.ldu + nc, rv[q], vec, nv);
-            if constexpr (EPI == EPI_STORE) {
-                if (has_res) loadw<float, CW>(p.resid, oidx[q], rv[q], vec, nv);
-                if (has_pos) loadw<float, CW>(p.pos, (long long)rm[q].mloc * p.N + nc, pv[q], vecb, nv);
+            if constexpr (PREF) {
+                oidx[q] = (long long)(rm[q].orow < 0 ? 0 : rm[q].orow) * p.ldc + nc;
+                if constexpr (SIDE_D) {
+                    const uint32_t w[4] = {dc[q].x, dc[q].y, dc[q].z, dc[q].w};
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        rv[q][2 * h] = __uint_as_float(w[h] << 16);
+                        rv[q][2 * h + 1] = __uint_as_float(w[h] & 0xffff0000u);
+                    }
+                } else {
+                    rv[q][0] = rc[q][0].x; rv[q][1] = rc[q][0].y; rv[q][2] = rc[q][0].z; rv[q][3] = rc[q][0].w;
+                    rv[q][4] = rc[q][1].x; rv[q][5] = rc[q][1].y; rv[q][6] = rc[q][1].z; rv[q][7] = rc[q][1].w;
+                }
+            } else {
+                rm[q] = meta[i * 16 + q * RPP];
+                oidx[q] = (long long)(rm[q].orow < 0 ? 0 : rm[q].orow) * p.ldc + nc;
+                if constexpr (EPI == EPI_DGELU || EPI == EPI_DMUL) loadw<bf16_t, CW>(p.dact_u, (long long)(rm[q].orow < 0 ? 0 : rm[q].orow) * p.ldu + nc, rv[q], vec, nv);
+                if constexpr (EPI == EPI_STORE) {
+                    if (has_res) loadw<float, CW>(p.resid, oidx[q], rv[q], vec, nv);
+                    if (has_pos) loadw<float, CW>(p.pos, (long long)rm[q].mloc * p.N + nc, pv[q], vecb, nv);
+                }
             }
         }
 #pragma unroll
