@@ -9,7 +9,8 @@ import os
 from ctypes import c_float, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvitres_hip.so")
+# VITRES_LIB: another build of the same ABI (A/B timing of kernel changes on one box: tools/ab.sh)
+LIB_PATH = os.environ.get("VITRES_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libvitres_hip.so")
 
 VR_F32, VR_BF16 = 0, 1
 
