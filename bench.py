@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-table", default="", help="dev aid: write a per-shape table of the profiled GEMM launches to this file")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"], help="flat: vitres.optim.FlatAdamW (one "
                     "fused HIP pass over the arena); torch: torch.optim.AdamW(fused=True)")
@@ -358,9 +359,22 @@ def main():
     roof = None
     if args.profile_steps > 0:
         K.PROFILE = []
+        K.PROFILE_DESC = [] if args.launch_table else None
         for i in range(args.profile_steps):
             eager_step(10_000 + i, exchange=False)      # rank 0 only, after the timed region: no collectives here
         torch.cuda.synchronize()
+        if args.launch_table:                            # dev aid: per-shape table of the GEMM launches (time, TF/s, GB/s)
+            rows = {}
+            for (kind, fl, dense, by, e0, e1), desc in zip(K.PROFILE, K.PROFILE_DESC):
+                r = rows.setdefault(desc, [0, 0.0, 0.0, 0.0, 0.0])
+                r[0] += 1; r[1] += e0.elapsed_time(e1) * 1e-3; r[2] += fl; r[3] += dense; r[4] += by
+            with open(args.launch_table, "w") as f:
+                f.write("%-86s %5s %8s %8s %8s %8s %9s\n" % ("launch", "n", "us", "TF kept", "TF dense", "GB/s", "us/step"))
+                for desc, r in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+                    f.write("%-86s %5d %8.1f %8.1f %8.1f %8.1f %9.1f\n" % (desc[:86], r[0], r[1] / r[0] * 1e6, r[2] / r[1] / 1e12,
+                                                                         r[3] / r[1] / 1e12, r[4] / r[1] / 1e9,
+                                                                         r[1] / args.profile_steps * 1e6))
+            K.PROFILE_DESC = None
         agg = {}
         for kind, fl, dense, by, e0, e1 in K.PROFILE:
             a = agg.setdefault(kind, [0.0, 0.0, 0.0, 0, 0.0])

@@ -232,6 +232,27 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
             kt = next_live(kt + 1);
             if (kt < ntiles) issue(kt, 0);
         }
+    } else if constexpr (STAGES == 2) {
+        // two slices per round: both requested at once, both computed behind one wait -- twice the bytes in flight per
+        // workgroup for grids that leave a CU two or three workgroups (a single-buffered workgroup pays one full load latency
+        // per 64-wide slice: 24 x 1.4 us at K = 1536), in the LDS a second workgroup would not have used anyway
+        int c0 = next_live(0);
+        int c1 = c0 < ntiles ? next_live(c0 + 1) : ntiles;
+        if (c0 < ntiles) issue(c0, 0);
+        if (c1 < ntiles) issue(c1, 1);
+        fill_rowmeta();
+        if (c0 >= ntiles) __syncthreads();
+        while (c0 < ntiles) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            if (c1 < ntiles) compute(1);
+            __syncthreads();
+            c0 = c1 < ntiles ? next_live(c1 + 1) : ntiles;
+            c1 = c0 < ntiles ? next_live(c0 + 1) : ntiles;
+            if (c0 < ntiles) issue(c0, 0);
+            if (c1 < ntiles) issue(c1, 1);
+        }
     } else {
         fill_rowmeta();              // its global loads complete (the compiler waits for them) before any LDS-DMA is issued
         int c0 = next_live(0);
@@ -488,14 +509,19 @@ template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t 
     // tile by grid size (measured crossovers, tools/gemm_bench.py): 128x128 while it gives a CU two workgroups, 64x128
     // below that, 64x64 when even that leaves CUs with a single workgroup (long-K GEMMs of the last stage)
     const int tile = knob ? knob : (t128 >= 2LL * n_cu ? 1 : (t64 >= 2LL * n_cu ? 2 : 3));
+    static const int knob_pair = std::getenv("VITRES_NT_PAIR") ? std::atoi(std::getenv("VITRES_NT_PAIR")) : 1;
     if (tile == 1) launch2<TO, EPI, 4, 4>(a, stream, fast);
-    else if (tile == 2) launch2<TO, EPI, 2, 4>(a, stream, fast);
-    else {
+    else if (tile == 2) {
+        // every tile resident at three workgroups per CU and >= 8 slices: two slices per round (STAGES = 2)
+        if (knob_pair && t64 <= 3LL * n_cu && a.K >= 8 * BK) launch2<TO, EPI, 2, 4, 2>(a, stream, fast);
+        else launch2<TO, EPI, 2, 4>(a, stream, fast);
+    } else {
         // 64 x 64 tiles: with fewer than ~3 workgroups per CU and a long K the slices are pipelined inside the workgroup
         static const int knob_st = std::getenv("VITRES_NT_STAGES") ? std::atoi(std::getenv("VITRES_NT_STAGES")) : 0;
         const long long t3 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
         const bool ring = knob_st ? knob_st == 3 : (t3 < 3LL * n_cu && a.K >= 24 * BK);      // measured: +23 % at K = 3072, -3 % at K = 1024
         if (ring) launch2<TO, EPI, 2, 2, 3>(a, stream, fast);
+        else if (knob_pair && a.K >= 8 * BK) launch2<TO, EPI, 2, 2, 2>(a, stream, fast);
         else launch2<TO, EPI, 2, 2>(a, stream, fast);
     }
 }

@@ -16,6 +16,7 @@ IDENT = (0, 0, 0)
 # bench.py instrumentation: when a list, every vr_gemm launch is bracketed by HIP events on torch's current stream
 # (the stream the kernel is launched on) and (kind, flops, bytes, ev0, ev1) is appended.
 PROFILE = None
+PROFILE_DESC = None       # with PROFILE: one description per entry (tools/gemm_launches.py)
 
 
 def _dt(t):
@@ -94,6 +95,8 @@ def _launch_gemm_ln(args, ln, a, M, N, K, rows_in, keep_k, keep_n, k_period, ext
     _lib.check(_lib.lib().vr_gemm_ln(ctypes.byref(args), ctypes.byref(ln), _stream()), "vr_gemm_ln")
     e1.record()
     PROFILE.append((("bf16", 0, 0, 2), flops, 2.0 * M * N * K, float((M * K + N * K) * 2 + extra_bytes), e0, e1))
+    if PROFILE_DESC is not None:
+        PROFILE_DESC.append("ln%d M%d N%d K%d" % (ln.mode, M, N, K))
 
 
 def gemm_ln_fwd(a, b, out, ln_w, ln_b, ln_keep, eps, *, M, N, K, lda, ldb, ldc, bias=None, scale=None, keep_n=None,
@@ -148,6 +151,11 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     e1.record()
     PROFILE.append((("bf16" if args.in_dtype == VR_BF16 else "f32", int(a_trans), int(b_trans),
                      int(a_map is not None or b_map is not None)), flops, 2.0 * M * N * K, alg_bytes, e0, e1))
+    if PROFILE_DESC is not None:
+        PROFILE_DESC.append("%s M%d N%d K%d%s%s%s%s%s%s%s" % (
+            "tn" if a_trans else ("nn" if b_trans else "nt"), M, N, K, " act%d" % act if act else "", " bias" if bias is not None else "",
+            " res" if resid is not None else "", " scale" if scale is not None else "", " dact" if dact_u is not None else "",
+            " map" if (a_map or b_map or c_map) else "", " f32out" if out.dtype == torch.float32 and not a_trans else ""))
     return out
 
 
@@ -175,6 +183,8 @@ def gemm_group(calls):
     a0, kw0 = calls[0][0], calls[0][3]
     PROFILE.append((("bf16" if a0.dtype == torch.bfloat16 else "f32", int(kw0.get("a_trans", False)),
                      int(kw0.get("b_trans", False)), 0), flops, dense, alg, e0, e1))
+    if PROFILE_DESC is not None:
+        PROFILE_DESC.append("group " + " + ".join("M%d N%d K%d" % (kw["M"], kw["N"], kw["K"]) for _, _, _, kw in calls))
 
 
 def _gemm_work(a, out, M, N, K, a_trans, rows_in, keep_k, keep_n, k_period, n_period, out2=None, resid=None, dact_u=None,
