@@ -18,6 +18,8 @@
 //   transposing read ds_read_b64_tr_b16: a 16-lane group fetches a [4 rows][16 d] block, lane i supplying the address
 //   of row i/4, d 4(i%4)..+3 (8 contiguous bytes inside a chunk).  The chunk stride (Np + 8 rows) is an odd multiple
 //   of 128 B, so the two chunks a 32-lane half touches fall on different halves of the 256-B bank row.
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/vitres_hip.h"
 
@@ -519,6 +521,249 @@ __global__ __launch_bounds__(NW * 64, OCC) void bwd_dkv_kernel(const bf16_t* __r
 }
 
 // ==========================================================================================================
+// backward, short sequences (N <= 96: the 65- and 17-token stages): dQ, dK, dV in ONE launch.  Q, K, V and dO of the head are
+// staged once (53 KB at N = 65, D = 64 -- three workgroups per CU) and the two phases above run back to back on the staged
+// images: the query-tile phase (delta, dQ) reads its Q / dO fragments from LDS instead of global memory and leaves delta in
+// LDS for the key-tile phase.  The two-kernel form read q, k, v and dO twice and paid two launch tails on grids of 1024-2048
+// small workgroups (22 + 15 us at 128 x 65 x 8 x 64).  At N = 257 the four images (152 KB) would leave one workgroup per
+// CU: the long stage keeps the two kernels.
+// ==========================================================================================================
+template <int D, int MAXNP, int NTHR>
+__device__ __forceinline__ void stage_load(uint4 (&v)[(MAXNP * AC<D>::NCH + NTHR - 1) / NTHR], const bf16_t* __restrict__ src, int rs,
+                                           int N, int Np, int tid) {
+    constexpr int NCH = AC<D>::NCH, HP = NCH / 2;
+    constexpr int IT = (MAXNP * NCH + NTHR - 1) / NTHR;
+    const int total = Np * NCH;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NTHR;
+        const int q = idx >> 3, l8 = idx & 7;
+        const int rb = q / HP, cp = q - rb * HP;
+        const int n = 4 * rb + (l8 >> 1), ch = 2 * cp + (l8 & 1);
+        const bool ok = n < N && idx < total;
+        v[it] = *reinterpret_cast<const uint4*>(src + (long long)(ok ? n : 0) * rs + (ok ? ch : 0) * 8);
+        if (!ok) v[it] = make_uint4(0, 0, 0, 0);
+    }
+}
+template <int D, int MAXNP, int NTHR>
+__device__ __forceinline__ void stage_store(char* dst, const uint4 (&v)[(MAXNP * AC<D>::NCH + NTHR - 1) / NTHR], int Np, int tid) {
+    const int NpS = Np + 8;
+    constexpr int NCH = AC<D>::NCH, HP = NCH / 2;
+    constexpr int IT = (MAXNP * NCH + NTHR - 1) / NTHR;
+    const int total = Np * NCH;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * NTHR;
+        const int q = idx >> 3, l8 = idx & 7;
+        const int rb = q / HP, cp = q - rb * HP;
+        const int n = 4 * rb + (l8 >> 1), ch = 2 * cp + (l8 & 1);
+        if (idx < total) *reinterpret_cast<uint4*>(dst + ((size_t)ch * NpS + n) * 16) = v[it];
+    }
+}
+
+template <int D, int NKP, int NW, int OCC, bool FULL>
+__global__ __launch_bounds__(NW * 64, OCC) void bwd_short_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                                 const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                                 float* __restrict__ delta, bf16_t* __restrict__ dqkv,
+                                                                 const int* __restrict__ keep_hd, int B, int N, int H,
+                                                                 float scale) {
+    constexpr int NP = 32 * NKP, NT = NW * 64;
+    constexpr int IT = (NP * AC<D>::NCH + NT - 1) / NT;
+    typedef Img<D, NP> I;
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int HD = H * D, RS = 3 * HD;
+    const bf16_t* base = qkv + (long long)b * N * RS + h * D;
+    bf16_t* dbase = dqkv + (long long)b * N * RS + h * D;
+    if (keep_hd && h * D >= keep_hd[b]) {
+        for (int i = tid; i < N * (D / 8); i += NT) {
+            const int n = i / (D / 8), ch = i % (D / 8);
+            bf16_t* dst = dbase + (long long)n * RS + ch * 8;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(dst + HD) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(dst + 2 * HD) = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
+    const bf16_t* ob = o + (long long)b * N * HD + h * D;
+    const bf16_t* gb = d_o + (long long)b * N * HD + h * D;
+    const float* lb = lse + ((long long)b * H + h) * N;
+    float* db = delta + ((long long)b * H + h) * N;
+    char* Qc = sm;
+    char* Kc = Qc + I::BYTES;
+    char* Vc = Kc + I::BYTES;
+    char* Gc = Vc + I::BYTES;
+    float* Ls = reinterpret_cast<float*>(Gc + I::BYTES);      // lse * log2(e) per query (0 beyond N)
+    float* Ds = Ls + NP;                                      // delta per query (0 beyond N), written by the query-tile phase
+    int q0 = wave * 16;
+    bfv8 of[AC<D>::DK];                                       // O of the first query tile: in flight while the head is staged
+#pragma unroll
+    for (int dk = 0; dk < AC<D>::DK; ++dk) of[dk] = gfrag<D>(ob, HD, q0, N, dk, lane);
+    {
+        uint4 vq[IT], vk[IT], vv[IT], vg[IT];                 // every global load of the four images before the first LDS store
+        stage_load<D, NP, NT>(vq, base, RS, N, NP, tid);
+        stage_load<D, NP, NT>(vk, base + HD, RS, N, NP, tid);
+        stage_load<D, NP, NT>(vv, base + 2 * HD, RS, N, NP, tid);
+        stage_load<D, NP, NT>(vg, gb, HD, N, NP, tid);
+        for (int n = tid; n < NP; n += NT) {
+            Ls[n] = n < N ? lb[n] * LOG2E : 0.f;
+            Ds[n] = 0.f;
+        }
+        stage_store<D, NP, NT>(Qc, vq, NP, tid);
+        stage_store<D, NP, NT>(Kc, vk, NP, tid);
+        stage_store<D, NP, NT>(Vc, vv, NP, tid);
+        stage_store<D, NP, NT>(Gc, vg, NP, tid);
+    }
+    __syncthreads();
+    const char *qb[AC<D>::DK], *kb[AC<D>::DK], *vb[AC<D>::DK], *gcb[AC<D>::DK];
+#pragma unroll
+    for (int dk = 0; dk < AC<D>::DK; ++dk) {
+        qb[dk] = I::opaque(Qc + I::cbase(dk, lane));
+        kb[dk] = I::opaque(Kc + I::cbase(dk, lane));
+        vb[dk] = I::opaque(Vc + I::cbase(dk, lane));
+        gcb[dk] = I::opaque(Gc + I::cbase(dk, lane));
+    }
+    const char* kt_b = I::opaque(Kc + I::tbase(lane));
+    const char* qt_b = I::opaque(Qc + I::tbase(lane));
+    const char* gt_b = I::opaque(Gc + I::tbase(lane));
+    const float cs = scale * LOG2E;
+    // a fragment that plays the role the global-memory fragments play in the two-kernel form: D = 48 has 6 chunks, the lanes of
+    // k-step 1 that would hold chunks 6 / 7 must supply zeros (cread clamps the chunk and relies on a zero partner)
+    auto zfrag = [&](const char* lane_base, int row0, int dk) -> bfv8 {
+        bfv8 v = I::cread(lane_base, row0);
+        if constexpr (AC<D>::NCH % 4 != 0) {
+            if (dk * 4 + (lane >> 4) >= AC<D>::NCH) v = __builtin_bit_cast(bfv8, make_uint4(0, 0, 0, 0));
+        }
+        return v;
+    };
+
+    // ---- phase A: per 16-query tile delta and dQ (bwd_dq_kernel with Q / dO fragments from the staged images) ----
+    while (q0 < N) {
+        bfv8 qf[AC<D>::DK], gf[AC<D>::DK];
+#pragma unroll
+        for (int dk = 0; dk < AC<D>::DK; ++dk) {
+            qf[dk] = zfrag(qb[dk], q0, dk);
+            gf[dk] = zfrag(gcb[dk], q0, dk);
+        }
+        float d = 0.f;
+#pragma unroll
+        for (int dk = 0; dk < AC<D>::DK; ++dk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += (float)gf[dk][e] * (float)of[dk][e];
+        const float dl = gsum(d);
+        const float l2 = Ls[q0 + c];
+        if (g == 0 && q0 + c < N) {
+            db[q0 + c] = dl;
+            Ds[q0 + c] = dl;
+        }
+        f32x4 dq[AC<D>::DT];
+#pragma unroll
+        for (int dt = 0; dt < AC<D>::DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < NKP; ++kp) {
+            if (FULL || kp * 32 < N) {
+                f32x4 ds[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int k0 = (2 * kp + tt) * 16;
+                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    if (FULL || k0 < N) {
+#pragma unroll
+                        for (int dk = 0; dk < AC<D>::DK; ++dk) {
+                            sc = mfma16(I::cread(kb[dk], k0), qf[dk], sc);
+                            dp = mfma16(I::cread(vb[dk], k0), gf[dk], dp);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[r] = ex2(fmaf(sc[r], cs, -l2)) * ((dp[r] - dl) * scale);
+                    }
+                    ds[tt] = sc;
+                }
+                const bfv8 sf = pack8(ds[0], ds[1]);
+#pragma unroll
+                for (int dt = 0; dt < AC<D>::DT; ++dt) dq[dt] = mfma16(I::tread(kt_b, kp, dt), sf, dq[dt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int qs = q0;
+        q0 += NW * 16;
+        if (q0 < N) {
+#pragma unroll
+            for (int dk = 0; dk < AC<D>::DK; ++dk) of[dk] = gfrag<D>(ob, HD, q0, N, dk, lane);
+        }
+        if (qs + c < N) {
+#pragma unroll
+            for (int dt = 0; dt < AC<D>::DT; ++dt)
+                *reinterpret_cast<uint2*>(dbase + (long long)(qs + c) * RS + dt * 16 + 4 * g) =
+                    make_uint2(pack_bf2(dq[dt][0], dq[dt][1]), pack_bf2(dq[dt][2], dq[dt][3]));
+        }
+    }
+    __syncthreads();                                          // Ds complete
+
+    // ---- phase B: per 16-key tile dK, dV (bwd_dkv_kernel with K / V fragments from the staged images) ----
+    const int nqp = FULL ? NKP : (N + 31) / 32;
+    const float* lsg = Ls + 4 * g;
+    const float* dsg = Ds + 4 * g;
+    for (int u0 = wave * 16; u0 < N; u0 += NW * 16) {
+        bfv8 kf[AC<D>::DK], vf[AC<D>::DK];
+#pragma unroll
+        for (int dk = 0; dk < AC<D>::DK; ++dk) {
+            kf[dk] = zfrag(kb[dk], u0, dk);
+            vf[dk] = zfrag(vb[dk], u0, dk);
+        }
+        f32x4 dka[AC<D>::DT], dva[AC<D>::DT];
+#pragma unroll
+        for (int dt = 0; dt < AC<D>::DT; ++dt) {
+            dka[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dva[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int qp = 0; qp < NKP; ++qp) {
+            if (qp < nqp) {
+                f32x4 p[2], ds[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int qq = qp * 32 + tt * 16;
+                    const float4 l4 = *reinterpret_cast<const float4*>(lsg + qq);
+                    const float4 d4 = *reinterpret_cast<const float4*>(dsg + qq);
+                    const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+                    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int dk = 0; dk < AC<D>::DK; ++dk) {
+                        sc = mfma16(I::cread(qb[dk], qq), kf[dk], sc);
+                        dp = mfma16(I::cread(gcb[dk], qq), vf[dk], dp);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = ex2(fmaf(sc[r], cs, -lr[r]));
+                        p[tt][r] = pv;
+                        ds[tt][r] = pv * ((dp[r] - dr[r]) * scale);
+                    }
+                }
+                const bfv8 pf = pack8(p[0], p[1]), sf = pack8(ds[0], ds[1]);
+#pragma unroll
+                for (int dt = 0; dt < AC<D>::DT; ++dt) {
+                    dva[dt] = mfma16(I::tread(gt_b, qp, dt), pf, dva[dt]);
+                    dka[dt] = mfma16(I::tread(qt_b, qp, dt), sf, dka[dt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int k = u0 + c;
+        if (k < N) {
+#pragma unroll
+            for (int dt = 0; dt < AC<D>::DT; ++dt) {
+                bf16_t* dst = dbase + (long long)k * RS + dt * 16 + 4 * g;
+                *reinterpret_cast<uint2*>(dst + HD) =
+                    make_uint2(pack_bf2(dka[dt][0], dka[dt][1]), pack_bf2(dka[dt][2], dka[dt][3]));
+                *reinterpret_cast<uint2*>(dst + 2 * HD) =
+                    make_uint2(pack_bf2(dva[dt][0], dva[dt][1]), pack_bf2(dva[dt][2], dva[dt][3]));
+            }
+        }
+    }
+}
+
+// ==========================================================================================================
 // N > 288 (fine-tuning at 280 / 336 / 392 px: N = 401 / 577 / 785, reference scripts/vit-sr-nas/finetune/*): the head no
 // longer fits in LDS.  Same fragments and dataflow, but a workgroup owns 128 queries (or keys) and walks the other
 // sequence in blocks of 256 rows staged in LDS one after the other.  The forward makes two passes over the key blocks --
@@ -847,6 +1092,29 @@ static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, con
                       const int* keep, int B, int N, int H, float scale, hipStream_t st) {
     constexpr int NW = Plan<NKP>::NW, OCC = Plan<NKP>::OCC;
     const size_t l1 = (size_t)2 * Img<D, 32 * NKP>::BYTES, l2 = l1 + 2 * 32 * NKP * sizeof(float);
+    {       // one launch for dQ, dK, dV where the four staged images leave a CU two workgroups or more: the short sequences
+            // and N = 257 at D = 32 (76 KB: 50.5 -> 41.9 us at 64 x 257 x 8 x 32; D = 64 would be alone on its CU: 63 -> 69 us).
+            // VITRES_ATTN_BWD_SHORT=0: always the two kernels, 2: always the merged one
+        static const int knob = std::getenv("VITRES_ATTN_BWD_SHORT") ? std::atoi(std::getenv("VITRES_ATTN_BWD_SHORT")) : 1;
+        constexpr size_t L3 = (size_t)4 * Img<D, 32 * NKP>::BYTES + 2 * 32 * NKP * sizeof(float);
+        constexpr int SOCC = NKP <= 3 ? 3 : (L3 <= 80 * 1024 ? 2 : 1);
+        const bool merged = knob == 2 || (knob == 1 && SOCC >= 2);
+        if (merged) {
+            const size_t l3 = (size_t)4 * Img<D, 32 * NKP>::BYTES + 2 * 32 * NKP * sizeof(float);
+            if (N > 32 * (NKP - 1)) {
+                int rc = set_lds(bwd_short_kernel<D, NKP, NW, SOCC, true>, l3);
+                if (rc) return rc;
+                hipLaunchKernelGGL((bwd_short_kernel<D, NKP, NW, SOCC, true>), dim3(B * H), dim3(NW * 64), l3, st, qkv, o, d_o, lse, delta,
+                                   dqkv, keep, B, N, H, scale);
+            } else {
+                int rc = set_lds(bwd_short_kernel<D, NKP, NW, SOCC, false>, l3);
+                if (rc) return rc;
+                hipLaunchKernelGGL((bwd_short_kernel<D, NKP, NW, SOCC, false>), dim3(B * H), dim3(NW * 64), l3, st, qkv, o, d_o, lse, delta,
+                                   dqkv, keep, B, N, H, scale);
+            }
+            return 0;
+        }
+    }
     if (N > 32 * (NKP - 1)) {
         int rc = set_lds(bwd_dq_kernel<D, NKP, NW, OCC, true>, l1);
         if (rc) return rc;
