@@ -459,7 +459,8 @@ def _bf(t):
 
 
 @pytest.mark.parametrize("B,Nt,C,Kd,masked", [(6, 257, 256, 768, True), (4, 65, 512, 1536, True), (3, 50, 192, 256, False),
-                                              (5, 17, 448, 128, True), (2, 33, 8, 72, False)])
+                                              (5, 17, 448, 128, True), (2, 33, 8, 72, False), (5, 257, 320, 1280, True),
+                                              (3, 70, 296, 320, False)])
 def test_gemm_ln_forward(B, Nt, C, Kd, masked):
     """mode 0 == vr_gemm (residual epilogue) followed by vr_ln_fwd: same residual stream bit for bit (same MFMA order is not
     required: compared with tolerance), LayerNorm output / statistics within bf16 / fp32 rounding."""
@@ -496,7 +497,8 @@ def test_gemm_ln_forward(B, Nt, C, Kd, masked):
 
 @pytest.mark.parametrize("B,Nt,C,Kd,masked,nxt", [(6, 257, 256, 768, True, True), (4, 65, 512, 1536, True, True),
                                                   (3, 50, 192, 256, False, False), (5, 17, 448, 192, True, False),
-                                                  (2, 33, 8, 72, False, True)])
+                                                  (2, 33, 8, 72, False, True), (5, 257, 320, 960, True, True),
+                                                  (3, 70, 296, 320, False, False)])
 def test_gemm_ln_backward(B, Nt, C, Kd, masked, nxt):
     """mode 1 == data-gradient GEMM (fp32 result) followed by vr_ln_bwd."""
     M = B * Nt

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, con
     constexpr int BM = 16 * MI, BN = 64 * NJ, WCOLS = 16 * NJ;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int AP = BM / 32, BP = BN / 32;                      // LDS-DMA pieces (8 rows x 128 B) per wave
-    constexpr int NV = BN / 256;                                   // float4 column groups per lane in the row loop
+    constexpr int NV = (BN + 255) / 256;                           // float4 column groups per lane in the row loop (the last one
+                                                                   // partly outside the tile at BN = 320: cin[] / reads of dead slots)
     constexpr int HM = MI / 2, PR = 16 * HM;                       // 16-row fragments / rows parked per half tile
     constexpr int SLOTS = BN / 4;                                  // 16-byte slots per parked row
     static_assert(AP >= 1 && PR * BN * 4 <= A_BYTES + B_BYTES, "tile shape");
@@ -391,8 +392,10 @@ __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, con
         float* red = reinterpret_cast<float*>(smem);               // [2][4 waves][BN]
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            *reinterpret_cast<float4*>(red + (0 * 4 + wave) * BN + 4 * (lane + 64 * v)) = gw[v];
-            *reinterpret_cast<float4*>(red + (1 * 4 + wave) * BN + 4 * (lane + 64 * v)) = gb[v];
+            if (4 * (lane + 64 * v) < BN) {
+                *reinterpret_cast<float4*>(red + (0 * 4 + wave) * BN + 4 * (lane + 64 * v)) = gw[v];
+                *reinterpret_cast<float4*>(red + (1 * 4 + wave) * BN + 4 * (lane + 64 * v)) = gb[v];
+            }
         }
         __syncthreads();
         const long long grow = (long long)(blockIdx.x % (unsigned)(f.grad_copies > 1 ? f.grad_copies : 1)) * p.N;
@@ -441,5 +444,6 @@ extern "C" int vr_gemm_ln(const vr_gemm_args* g, const vr_ln_epilogue* ln, vr_st
         return VR_EINVAL;
     }
     if (a.N <= 256) return launch<4, 4>(a, *ln, (hipStream_t)stream);
+    if (a.N <= 320) return launch<4, 5>(a, *ln, (hipStream_t)stream);      // sr_small's first stage: 64 x 320 tiles
     return launch<2, 8>(a, *ln, (hipStream_t)stream);
 }

@@ -518,7 +518,11 @@ def head_bwd(dcls, dpat, saved, p, grads, cfg, keep, next_cast=None, ready=False
     B, N, C = x.shape
     dt = cfg["dtype"]
     nc = cfg["classes"]
-    dy = torch.zeros((B, N, C), dtype=dt, device=x.device)
+    T_ = cfg.get("tokens", 1)
+    # every token row is written by a head's data gradient when the class head and the per-patch head are both active (and one
+    # class token): no zero fill then
+    covered = dcls is not None and dpat is not None and "dst" not in p and ym is None and T_ == 1
+    dy = (torch.empty if covered else torch.zeros)((B, N, C), dtype=dt, device=x.device)
     ldp = (nc + 7) // 8 * 8                                                 # logits-gradient rows zero-padded to 16 B
 
     def padded(d2):                                                         # tiny [rows, classes] tensors: torch glue

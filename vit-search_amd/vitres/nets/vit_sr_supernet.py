@@ -680,7 +680,9 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 wc, ld = w.detach().view(w.shape[0], k), k
             else:
                 ld = (k + 7) // 8 * 8
-                wc = torch.zeros((w.shape[0], ld), dtype=torch.bfloat16, device=w.device)
+                wc = self._arena.get("embed_wc")            # persistent: the pad columns stay zero, one cast-copy per forward
+                if wc is None or wc.shape != (w.shape[0], ld) or wc.device != w.device:
+                    wc = self._arena["embed_wc"] = torch.zeros((w.shape[0], ld), dtype=torch.bfloat16, device=w.device)
                 wc[:, :k].copy_(w.detach().view(w.shape[0], k))
             return {"proj": Fn.Weights(w, pe.proj.bias.detach(), wc, ld), "pos": self.pos_embed.detach(),
                     "tokens": self.tokens.detach()}
@@ -924,9 +926,10 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             elif kind == "sr":
                 _, blk, p, cfg, (ek, nk), sv = entry
                 co, ci = blk.patch_reduce.weight.shape[0], blk.patch_reduce.weight.shape[1]
-                wtmp = torch.zeros((co, 9 * ci), dtype=torch.float32, device=dev)
                 nt = self.num_tokens
-                ptmp = torch.zeros((nt + blk.num_patches, co), dtype=torch.float32, device=dev)
+                ztmp = torch.zeros(co * 9 * ci + (nt + blk.num_patches) * co, dtype=torch.float32, device=dev)   # one fill
+                wtmp = ztmp[:co * 9 * ci].view(co, 9 * ci)
+                ptmp = ztmp[co * 9 * ci:].view(nt + blk.num_patches, co)
                 def finish(blk=blk, wtmp=wtmp, ptmp=ptmp, co=co, ci=ci, nt=nt):     # runs on the stream of the weight gradients
                     gv(blk.patch_reduce.weight).copy_(wtmp.view(co, 3, 3, ci).permute(0, 3, 1, 2))
                     gv(blk.pos_embed).copy_(ptmp[nt:].unsqueeze(0))
