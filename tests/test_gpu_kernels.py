@@ -355,6 +355,35 @@ def test_stem_kernels(dtype):
     assert torch.equal(r2.cpu(), a3) and torch.equal(e2, a3)
 
 
+@pytest.mark.parametrize("M,N,Kd,act", [(700, 256, 768, 0), (1300, 512, 1536, 2), (130, 72, 200, 0), (2176, 1024, 3072, 1),
+                                       (300, 64, 64, 2), (8320, 512, 512, 0)])
+def test_gemm_dgrad_reads_forward_weight(M, N, Kd, act):
+    """b_trans: dX = dY W with W [K = out, N = in] as the forward stores it (k-major weight slices, transposing LDS reads) --
+    equal to the statement on the transposed copy, with and without the gelu' epilogues, masks, K tails and narrow N."""
+    rows_in = 65 if M % 65 == 0 else 0
+    dy = _bf(rnd(M, Kd, seed=1))
+    w = _bf(rnd(Kd, N, seed=2, scale=Kd ** -0.5))
+    kw = dict(M=M, N=N, K=Kd, lda=Kd, ldb=N, ldc=N, b_trans=True)
+    if rows_in:
+        nb = M // rows_in
+        kw.update(rows_in=rows_in, keep_n=torch.tensor([N, N // 2, 8, N - 8] * (nb // 4 + 1), dtype=torch.int32)[:nb],
+                  keep_k=torch.tensor([Kd, Kd // 2, Kd, Kd // 4] * (nb // 4 + 1), dtype=torch.int32)[:nb])
+    if act:
+        u = _bf(rnd(M, N, seed=3))
+        kw.update(dact_u=u, ldu=N, act=2 if act == 2 else 0)
+    if rows_in:
+        dy = _bf(dy.float() * (torch.arange(Kd)[None, :] < kw["keep_k"].long().repeat_interleave(rows_in)[:, None]))
+    ref = E.gemm(dy, w, torch.zeros(M, N, dtype=torch.bfloat16), **kw)
+    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+    real = K.gemm(dy.to(DEV), w.to(DEV), torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV), **{k: to(v) for k, v in kw.items()})
+    assert relerr(real, ref) < tol(torch.bfloat16)
+    # and equal (same products, same order per k slice) to the K-contiguous form on W^T
+    kw2 = dict(kw, ldb=Kd, b_trans=False)
+    real2 = K.gemm(dy.to(DEV), w.t().contiguous().to(DEV), torch.zeros((M, N), dtype=torch.bfloat16, device=DEV),
+                   **{k: to(v) for k, v in kw2.items()})
+    assert relerr(real, real2.cpu()) < 2e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_masked_work_skipping(dtype):
     """keep_k / keep_n / periods only skip work that is zero by contract: results equal the dense statement."""

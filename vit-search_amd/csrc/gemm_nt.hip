@@ -60,7 +60,28 @@ struct RowMeta {
 // residual, 3: bias + residual + DropPath scale, 4: decided per launch from the arguments (pos-embed, any other mix; the only
 // form of the non-FAST kernels).  As run-time uniform conditions the compiler if-converts them into a v_cndmask per element
 // and term (measured: 890 VALU instructions per tile and wave against 128 MFMAs at K = 256, VALU pipe busy 2x the matrix pipe).
-template <typename TO, int EPI, bool FAST, int MI, int NJ, int STAGES, int FEAT>
+// BKM (b_trans: data gradients that read the forward's weight W [K = out features][N = in features] as it is): the weight slice
+// is staged k-major ([64 k rows][BN columns], the image of gemm_tn.hip: 16-byte slot s of row k holds column chunk s ^ swz(k))
+// and its MFMA fragments -- 8 consecutive k of one column -- come from the transposing LDS read ds_read_b64_tr_b16.  No
+// transposed bf16 copy of the weights (one batched transposing cast of every Linear per step, 383 MB of traffic) is needed.
+template <int BN> struct KMajor {      // geometry of the k-major weight slice (gemm_tn.hip Geo<TW>)
+    static constexpr int ROWB = BN * 2, SLOTS = BN / 8, TPP = 1024 / ROWB;
+    __device__ static __forceinline__ int swz(int t) {
+        if constexpr (BN == 128) return ((t & 3) << 1) ^ (((t >> 3) & 1) << 3);
+        else return (((t >> 1) & 1) << 1) | (((t >> 3) & 1) << 2);
+    }
+};
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+template <int ROWB> __device__ __forceinline__ bfv8 tr_frag(const char* p) {
+    typedef __attribute__((address_space(3))) s4v lds_s4v;
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(p));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(p + 4 * ROWB));
+    const s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bfv8, v);
+}
+
+template <typename TO, int EPI, bool FAST, int MI, int NJ, int STAGES, int FEAT, bool BKM = false>
 __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm_args p) {
     constexpr int BM = 32 * MI, WROWS = 16 * MI;      // tile rows, rows per wave
     constexpr int BN = 32 * NJ, WCOLS = 16 * NJ;      // tile columns, columns per wave
@@ -112,7 +133,21 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     const char* gA[AP];
     const char* gB[BP];
     int chunkA[AP], chunkB[BP];    // element offset of this lane's k-chunk inside a slice
-    {
+    int tokB[BP];                  // BKM: k row of this lane inside a slice, per piece
+    if constexpr (BKM) {
+        typedef KMajor<BN> G;
+#pragma unroll
+        for (int h = 0; h < BP; ++h) {
+            const int tk = (wave * BP + h) * G::TPP + lane / G::SLOTS;
+            const int c = (lane % G::SLOTS) ^ G::swz(tk);
+            // column chunks past the row's readable width (ldb >= roundup(N, 8)) come from the zero page: their products only
+            // reach outputs that are not stored
+            const bool bok = n0 + c * 8 + 8 <= p.ldb;
+            tokB[h] = tk;
+            gB[h] = bok ? reinterpret_cast<const char*>(p.B) + ((long long)tk * p.ldb + n0 + c * 8) * 2 : nullptr;
+            chunkB[h] = 0;
+        }
+    } else {
         const int rb = wave * (8 * BP) + (lane >> 3);
         if (bmap.rpi == 0 && n0 + BN <= p.N) {
             const char* b0 = reinterpret_cast<const char*>(p.B) + (long long)(n0 + rb) * p.ldb * 2;
@@ -133,6 +168,8 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
                 chunkB[h] = c * 8;
             }
         }
+    }
+    {
         const int ra = wave * (8 * AP) + (lane >> 3);
         if (amap.rpi == 0 && m0 + BM <= p.M) {
             const char* a0 = reinterpret_cast<const char*>(p.A) + (long long)(m0 + ra) * p.lda * 2;
@@ -155,13 +192,22 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         }
     }
     const char* zero = reinterpret_cast<const char*>(zero_chunk);
-    const bool ktail = (FEAT == 4) && (p.K % BK) != 0;   // FEAT 0..3: K % 64 == 0 (host check)
+    const bool ktail = (FEAT == 4 || BKM) && (p.K % BK) != 0;   // FEAT 0..3: K % 64 == 0 (host check; BKM: checked here)
 
     // ---- fragment read offsets: lane -> row (lane & 15) of a 16-row group, k-chunk 4 s + (lane >> 4) ----
     const int frow = lane & 15, fswz = (frow >> 1) & 7;
     const int slot0 = (((lane >> 4)) ^ fswz) << 4, slot1 = ((4 + (lane >> 4)) ^ fswz) << 4;
     const char* As = smem + (wm * WROWS + frow) * 128;
     const char* Bs = smem + A_BYTES + (wn * WCOLS + frow) * 128;
+    int offB[NJ];                  // BKM: byte offset of fragment j's first transposing read inside the k-major weight slice
+    if constexpr (BKM) {
+        typedef KMajor<BN> G;
+        const int li = lane & 15, g4 = lane >> 4;
+        const int xr2 = G::swz(8 * g4 + (li >> 2));
+        const int rowoff = (8 * g4 + (li >> 2)) * G::ROWB + (li & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) offB[j] = A_BYTES + rowoff + ((((BN / 16) * wn + 2 * j + ((li & 3) >> 1)) ^ xr2) * 16);
+    }
 
     f32x4 acc[MI][NJ];
 #pragma unroll
@@ -180,7 +226,9 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         }
 #pragma unroll
         for (int h = 0; h < BP; ++h) {
-            const char* sb = (!ktail || (k0 + chunkB[h] < p.K)) ? gB[h] + kb : zero;
+            const char* sb;
+            if constexpr (BKM) sb = (gB[h] && (!ktail || k0 + tokB[h] < p.K)) ? gB[h] + (long long)k0 * p.ldb * 2 : zero;
+            else sb = (!ktail || (k0 + chunkB[h] < p.K)) ? gB[h] + kb : zero;
             __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(dst + A_BYTES + (wave * (8 * BP) + h * 8) * 128), 16, 0, 0);
         }
     };
@@ -195,7 +243,10 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
 #pragma unroll
             for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bfv8*>(Ab + i * 2048 + so);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bfv8*>(Bb + j * 2048 + so);
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (BKM) b[j] = tr_frag<KMajor<BN>::ROWB>(smem + buf * STAGE_BYTES + offB[j] + s * 32 * KMajor<BN>::ROWB);
+                else b[j] = *reinterpret_cast<const bfv8*>(Bb + j * 2048 + so);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -475,6 +526,13 @@ template <typename TO, int EPI, int MI, int NJ, int STAGES, int FEAT> void launc
 }
 
 template <typename TO, int EPI, int MI, int NJ, int STAGES = 1> void launch2(const vr_gemm_args& a, hipStream_t stream, bool fast) {
+    if (a.b_trans) {     // weights as the forward stores them (vr_gemm_nt_launch admitted the form): bf16 data gradients only
+        if constexpr (sizeof(TO) == 2 && (EPI == EPI_STORE || EPI == EPI_DMUL || EPI == EPI_DGELU)) {
+            const long long total = (long long)((a.M + 32 * MI - 1) / (32 * MI)) * ((a.N + 32 * NJ - 1) / (32 * NJ));
+            hipLaunchKernelGGL((nt_kernel<TO, EPI, true, MI, NJ, STAGES, 0, true>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+        }
+        return;
+    }
     // epilogue form (see nt_kernel): the forms of the transformer-block Linears get their own kernels
     int feat = 4;
     if (fast && !a.pos && a.K % BK == 0) {
@@ -531,8 +589,17 @@ template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t 
 // Called by vr_gemm after validation.  Returns false when the form is not covered here.
 bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_nt;
-    if (a.in_dtype != VR_BF16 || a.a_trans || a.b_trans || a.atomic || a.split_k > 1 || a.bias_grad) return false;
+    if (a.in_dtype != VR_BF16 || a.a_trans || a.atomic || a.split_k > 1 || a.bias_grad) return false;
     const bool of32 = a.out_dtype == VR_F32;
+    if (a.b_trans) {
+        // B = W [K][N] row-major (the forward's weight): plain data gradients with a bf16 result (optionally times gelu'), 16-byte
+        // rows, the epilogue's vector form; anything else stays with the general kernel
+        static const bool knob_km = !(std::getenv("VITRES_NT_BKM") && std::getenv("VITRES_NT_BKM")[0] == '0');
+        const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);
+        if (!knob_km || of32 || a.act == 1 || (a.act == 2 && !a.dact_u) || a.bias || a.resid || a.scale || a.pos || a.C2 ||
+            a.b_map.rpi != 0 || !fast || a.ldb % 8 || ((uintptr_t)a.B & 15) || a.ldb < (a.N + 7) / 8 * 8)
+            return false;
+    }
     if (a.act == 1 || (a.act == 2 && !a.dact_u)) {
         if (of32) return false;
         launch1<bf16_t, EPI_GELU>(a, stream, n_cu);

@@ -334,11 +334,19 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 p.data = flat[off:off + n].view(p.shape)
         a = {"flat": flat, "params": params, "offsets": offsets, "index": {id(p): i for i, p in enumerate(params)},
              "shadow": torch.empty(total, dtype=torch.bfloat16, device=device), "gflat": None, "tmap": {}, "tr": None}
-        # transposed bf16 shadows W^T [in, roundup(out, 8)] of every nn.Linear weight: the data-gradient GEMMs then read
-        # their weights K-contiguous, like the forward (one batched transposing cast per step)
-        if self.compute_dtype == torch.bfloat16:
+        # transposed bf16 shadows W^T [in, roundup(out, 8)] (one batched transposing cast per step).  Round 2: the data-gradient
+        # GEMMs read the forward's weight itself (vr_gemm b_trans on the LDS-DMA kernel: k-major weight slices, transposing LDS
+        # reads); only the Linears whose data gradient runs inside vr_gemm_ln (qkv / fc1 of the narrow first stage) still get a
+        # transposed copy.  VITRES_WT_SHADOWS=all: every Linear (round-1 layout), none: no copies (no fused LayerNorm backward)
+        import os as _os
+        which = a["wt_mode"] = _os.environ.get("VITRES_WT_SHADOWS", "fused")
+        if self.compute_dtype == torch.bfloat16 and which != "none":
             entries, tot_t = [], 0
-            for mod in self.modules():
+            for name, mod in self.named_modules():
+                fused = (name.endswith("attn.qkv") or name.endswith("mlp.fc1")) and isinstance(mod, nn.Linear) and \
+                    mod.in_features <= Fn.FUSE_LN_MAXN
+                if which != "all" and not fused:
+                    continue
                 if isinstance(mod, nn.Linear) and id(mod.weight) in a["index"]:
                     w = mod.weight
                     out_f, in_f = w.shape
@@ -655,7 +663,9 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         if isinstance(blk, SpatialReductionPatchEmbedding):
             w = blk.patch_reduce.weight
             wperm = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(self.compute_dtype).contiguous()
-            wperm_t = wperm.t().contiguous() if self.compute_dtype == torch.bfloat16 and wperm.shape[0] % 8 == 0 else None
+            # (transposed copy for the data gradient only in the round-1 layout: the LDS-DMA kernel reads wperm itself, b_trans)
+            wperm_t = wperm.t().contiguous() if self.compute_dtype == torch.bfloat16 and wperm.shape[0] % 8 == 0 and \
+                self._arena.get("wt_mode") == "all" else None
             return {"nw": blk.norm.weight.detach(), "nb": blk.norm.bias.detach(),
                     "reduce": Fn.Weights(w, blk.patch_reduce.bias.detach(), wperm, wperm.shape[1], wperm_t,
                                          wperm.shape[0]),
