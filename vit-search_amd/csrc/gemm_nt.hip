@@ -283,26 +283,34 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
             kt = next_live(kt + 1);
             if (kt < ntiles) issue(kt, 0);
         }
-    } else if constexpr (STAGES == 2) {
-        // two slices per round: both requested at once, both computed behind one wait -- twice the bytes in flight per
-        // workgroup for grids that leave a CU two or three workgroups (a single-buffered workgroup pays one full load latency
-        // per 64-wide slice: 24 x 1.4 us at K = 1536), in the LDS a second workgroup would not have used anyway
-        int c0 = next_live(0);
-        int c1 = c0 < ntiles ? next_live(c0 + 1) : ntiles;
-        if (c0 < ntiles) issue(c0, 0);
-        if (c1 < ntiles) issue(c1, 1);
+    } else if constexpr (STAGES == 2 || STAGES == 4) {
+        // STAGES slices per round: all requested at once, all computed behind one wait -- two (four) times the bytes in flight
+        // per workgroup for grids that leave a CU two or three workgroups (one at most: the M = 128 GEMMs of the class-token
+        // rows, 8 - 32 workgroups on the whole chip, paid one full load latency per 64-wide slice), in LDS that no other
+        // workgroup would have used
+        int cs[STAGES];
+        int nxt = 0;
+#pragma unroll
+        for (int q = 0; q < STAGES; ++q) {
+            cs[q] = nxt < ntiles ? next_live(nxt) : ntiles;
+            nxt = cs[q] < ntiles ? cs[q] + 1 : ntiles;
+            if (cs[q] < ntiles) issue(cs[q], q);
+        }
         fill_rowmeta();
-        if (c0 >= ntiles) __syncthreads();
-        while (c0 < ntiles) {
+        if (cs[0] >= ntiles) __syncthreads();
+        while (cs[0] < ntiles) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            compute(0);
-            if (c1 < ntiles) compute(1);
+#pragma unroll
+            for (int q = 0; q < STAGES; ++q)
+                if (cs[q] < ntiles) compute(q);
             __syncthreads();
-            c0 = c1 < ntiles ? next_live(c1 + 1) : ntiles;
-            c1 = c0 < ntiles ? next_live(c0 + 1) : ntiles;
-            if (c0 < ntiles) issue(c0, 0);
-            if (c1 < ntiles) issue(c1, 1);
+#pragma unroll
+            for (int q = 0; q < STAGES; ++q) {
+                cs[q] = nxt < ntiles ? next_live(nxt) : ntiles;
+                nxt = cs[q] < ntiles ? cs[q] + 1 : ntiles;
+                if (cs[q] < ntiles) issue(cs[q], q);
+            }
         }
     } else {
         fill_rowmeta();              // its global loads complete (the compiler waits for them) before any LDS-DMA is issued
@@ -579,6 +587,7 @@ template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t 
         const long long t3 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
         const bool ring = knob_st ? knob_st == 3 : (t3 < 3LL * n_cu && a.K >= 24 * BK);      // measured: +23 % at K = 3072, -3 % at K = 1024
         if (ring) launch2<TO, EPI, 2, 2, 3>(a, stream, fast);
+        else if (knob_pair && t3 <= n_cu && a.K >= 4 * BK) launch2<TO, EPI, 2, 2, 4>(a, stream, fast);   // at most one workgroup per CU
         else if (knob_pair && a.K >= 8 * BK) launch2<TO, EPI, 2, 2, 2>(a, stream, fast);
         else launch2<TO, EPI, 2, 2>(a, stream, fast);
     }
