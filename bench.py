@@ -388,7 +388,7 @@ def main():
             dt_, at, bt, mapped = k
             if mapped == 2:
                 return "vr_gemm_ntln::ntln_kernel (Linear + LayerNorm epilogue)"
-            if dt_ == "bf16" and not at and not bt:
+            if dt_ == "bf16" and not at:         # (b_trans data gradients run on the same kernel since round 2: BKM)
                 return "vr_gemm_nt::nt_kernel (forward+dgrad)"
             if dt_ == "bf16" and at and bt:
                 return "vr_gemm_tn::tn_group_kernel / tn_kernel (wgrad)"
