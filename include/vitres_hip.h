@@ -86,7 +86,8 @@ typedef struct vr_gemm_args {
     int32_t out_dtype;   /* dtype of C/C2 */
     int32_t act;         /* 0 none; 1 gelu (dual store with C2: C = u, C2 = gelu(u); single store without: C = gelu(u)); 2 the
                             saved-derivative form of the same pair: forward (no dact_u) C = gelu'(u), C2 = gelu(u); data gradient
-                            (dact_u given) multiplies by dact_u as it is -- no transcendental in the backward epilogue */
+                            (dact_u given) multiplies by dact_u as it is -- no transcendental in the backward epilogue;
+                            3 relu, single store: C = max(u, 0) (no C2 / dact_u) */
     int32_t atomic;      /* 1: atomicAdd fp32 */
     int32_t split_k;     /* >= 1 */
     int32_t rows_in;     /* rows per sample of the M index (0: single sample); wgrad: tokens per sample of the K index */
@@ -354,6 +355,12 @@ int vr_col2im3x3(const void* dcol, void* dsrc, int32_t B, int32_t H, int32_t W, 
  */
 int vr_conv3x3(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                int32_t out_dtype, vr_stream_t stream);
+/*
+ * The same convolution with BatchNorm folded in for evaluation (nets/patch_conv.py:23-73 in eval mode: the caller scales the
+ * weights by gamma / sqrt(var + eps) per output channel): out = relu(conv(a, w) + bias[co]) (+ res[pixel, co], bf16).
+ */
+int vr_conv3x3_bias_relu(const void* a, const void* w, const float* bias, const void* res, void* out, int32_t B, int32_t H,
+                         int32_t W, int32_t Cin, int32_t Cout, int32_t out_dtype, vr_stream_t stream);
 /* Its weight gradient: dw[co, (kh,kw,ci)] (fp32, [Cout, 9*Cin]) += sum over pixels of dz[p, co] * a[p + (kh-1, kw-1), ci]; a, dz
  * bf16 NHWC.  Covered: Cin == Cout in {16, 24, 32} (the stem's conv2 / conv3); VR_EUNSUPPORTED otherwise. */
 int vr_conv3x3_wgrad(const void* a, const void* dz, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,

@@ -52,6 +52,9 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     nmask = ncol[None, :] < keep[:, None]
     orow = _rows(M, c_map)
     C2d = _flat2d(out, ldc)
+    if act == 3:                                           # relu, single store
+        C2d[orow, :N] = torch.where(nmask, torch.relu(v), torch.zeros_like(v)).to(out.dtype)
+        return out
     if act in (1, 2) and dact_u is None:
         v = torch.where(nmask, v, torch.zeros_like(v))
         h = torch.where(nmask, F.gelu(v), torch.zeros_like(v))
@@ -263,6 +266,13 @@ def conv3x3(a, w, B, H, W, Cin, Cout, out_dtype):
     return y.permute(0, 2, 3, 1).reshape(B * H * W, Cout).to(out_dtype)
 
 
+def conv3x3_bias_relu(a, w, bias, res, B, H, W, Cin, Cout, out_dtype):
+    y = torch.relu(conv3x3(a, w, B, H, W, Cin, Cout, torch.float32) + bias[None, :])
+    if res is not None:
+        y = y + res.float()
+    return y.to(out_dtype)
+
+
 def conv3x3_wgrad_supported(a, Cin, Cout):
     return a.dtype == torch.bfloat16 and Cin == Cout and Cin in (16, 24, 32)
 
@@ -398,7 +408,7 @@ def patch_fold(col, B, gh, gw, P, C):
 
 
 ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "gemm_group", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "ln_grad_reduce", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "softce_train", "colsum", "scale_mask_cast",
-       "batchsum", "conv3x3", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
+       "batchsum", "conv3x3", "conv3x3_bias_relu", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
 
 
 def install(monkeypatch):

@@ -452,6 +452,33 @@ def test_direct_conv3x3(Cin, Cout, out_dtype):
         assert abs(lhs - rhs) < 2e-3 * max(abs(lhs), 1.0)
 
 
+@pytest.mark.parametrize("Cin,Cout,with_res", [(24, 24, True), (32, 32, False), (16, 24, True)])
+def test_direct_conv3x3_bias_relu(Cin, Cout, with_res):
+    """vr_conv3x3_bias_relu (evaluation stem, BatchNorm folded): relu(conv + bias) (+ residual) in the convolution's epilogue."""
+    B, H, W = 2, 37, 20
+    a = rnd(B * H * W, Cin, seed=1).to(torch.bfloat16)
+    w = (rnd(Cout, 9 * Cin, seed=2) * (9 * Cin) ** -0.5).to(torch.bfloat16)
+    bias = 0.3 * rnd(Cout, seed=3)
+    res = rnd(B * H * W, Cout, seed=4).to(torch.bfloat16) if with_res else None
+    ref = E.conv3x3_bias_relu(a, w, bias, res, B, H, W, Cin, Cout, torch.bfloat16)
+    out = K.conv3x3_bias_relu(a.to(DEV), w.to(DEV), bias.to(DEV), None if res is None else res.to(DEV), B, H, W, Cin, Cout,
+                              torch.bfloat16)
+    assert relerr(out, ref) < 1e-2
+    assert float(out.float().min()) >= (0.0 if res is None else float(res.float().min()) - 1e-6)
+
+
+@pytest.mark.parametrize("M,N,Kd", [(1000, 24, 32), (300, 256, 192), (130, 72, 200)])
+def test_gemm_relu_epilogue(M, N, Kd):
+    """act = 3: C = relu(A B^T + bias), single bf16 store (the conv1 GEMM of the BatchNorm-folded evaluation stem)."""
+    a, w, bias = _bf(rnd(M, Kd, seed=1)), _bf(rnd(N, Kd, seed=2, scale=Kd ** -0.5)), rnd(N, seed=3)
+    kw = dict(M=M, N=N, K=Kd, lda=Kd, ldb=Kd, ldc=N, bias=bias, act=3)
+    ref = E.gemm(a, w, torch.zeros(M, N, dtype=torch.bfloat16), **kw)
+    real = K.gemm(a.to(DEV), w.to(DEV), torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV),
+                  **{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+    assert relerr(real, ref) < tol(torch.bfloat16)
+    assert float(real.float().min()) == 0.0
+
+
 @pytest.mark.parametrize("C", [24, 32, 16])
 def test_direct_conv3x3_wgrad(C):
     """vr_conv3x3_wgrad == the weight gradient of conv2d on the same bf16 operands (edge tiles, accumulation into dw)."""

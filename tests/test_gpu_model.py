@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import vitres.kernels as K_
 
 import recipe
 import vitres
@@ -114,6 +115,36 @@ def test_micro_bf16_close_to_reference(et, mode):
             worst = max(worst, rel(params[k[9:]].grad, g[k]))
     # conv stems add three bf16 convolutions + train-mode BatchNorm on 16-channel maps in front of the gradient path
     assert worst < (8e-2 if et == 0 else 1.5e-1), worst
+
+
+@pytest.mark.parametrize("et", [4, 5])
+def test_micro_bf16_eval_with_folded_batchnorm(et, monkeypatch):
+    """Evaluation in bf16 on the conv patch embedding: BatchNorm folded into the convolutions (vr_conv3x3_bias_relu, relu GEMM)
+    against the reference's eval logits and against the same forward with the separate BatchNorm kernels."""
+    import vitres.stem as stem
+    g = np.load(os.path.join(G, "f1_micro_t%d_plain.npz" % et))
+    prod, orc, sd = build_pair(et, "plain", 100 + et)
+    prod.set_compute_dtype(torch.bfloat16)
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    prod.eval()
+    calls = []
+    real = K_.conv3x3_bias_relu
+    monkeypatch.setattr(K_, "conv3x3_bias_relu", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        monkeypatch.setattr(stem, "FOLD_BN", True)
+        folded = prod(x.to(DEV))
+        assert len(calls) == 2
+        monkeypatch.setattr(stem, "FOLD_BN", False)
+        plain = prod(x.to(DEV))
+        assert len(calls) == 2
+    assert rel(folded, g["eval.cls"]) < 3e-2, rel(folded, g["eval.cls"])
+    assert rel(folded, plain.cpu()) < 2e-2, rel(folded, plain.cpu())
+    # the cache follows the weights: a changed BatchNorm statistic changes the folded weights
+    with torch.no_grad():
+        prod.patch_embed.conv2.bn.running_var.mul_(4.0)
+        monkeypatch.setattr(stem, "FOLD_BN", True)
+        moved = prod(x.to(DEV))
+    assert rel(moved, folded.cpu()) > 1e-3
 
 
 def test_full_size_sr_tiny_supernet_fp32_vs_reference():

@@ -20,7 +20,8 @@ constexpr int TH = 16, TW = 16, PH = TH + 2, PW = TW + 2;
 
 template <int NC, typename TO>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ w,
-                                                      TO* __restrict__ out, int B, int H, int W, int Cout) {
+                                                      TO* __restrict__ out, int B, int H, int W, int Cout,
+                                                      const float* __restrict__ bias, const bf16_t* __restrict__ res) {
     constexpr int Cin = 8 * NC, K9 = 9 * NC, STEPS = (K9 + 3) / 4;
     constexpr int PS = Cin * 2 + ((NC & 1) ? 0 : 16);                 // pixel stride in LDS, bytes
     __shared__ __attribute__((aligned(16))) char patch[PH * PW * PS];
@@ -86,7 +87,17 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const bf16_t* __restrict__
             for (int nt = 0; nt < 2; ++nt) {
                 const int co = 16 * nt + 4 * g;
                 if (co < Cout) {
-                    const f32x4 r4 = nt == 0 ? acc0 : acc1;
+                    f32x4 r4 = nt == 0 ? acc0 : acc1;
+                    if (bias) {      // evaluation: BatchNorm folded into the weights, out = relu(conv + shift) (+ residual)
+                        const float4 bb = *reinterpret_cast<const float4*>(bias + co);
+                        r4[0] = fmaxf(r4[0] + bb.x, 0.f); r4[1] = fmaxf(r4[1] + bb.y, 0.f);
+                        r4[2] = fmaxf(r4[2] + bb.z, 0.f); r4[3] = fmaxf(r4[3] + bb.w, 0.f);
+                        if (res) {
+                            const uint2 rr = *reinterpret_cast<const uint2*>(res + (((long long)b * H + oy) * W + ox) * Cout + co);
+                            r4[0] += __uint_as_float(rr.x << 16); r4[1] += __uint_as_float(rr.x & 0xffff0000u);
+                            r4[2] += __uint_as_float(rr.y << 16); r4[3] += __uint_as_float(rr.y & 0xffff0000u);
+                        }
+                    }
                     if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(dst + co) = make_float4(r4[0], r4[1], r4[2], r4[3]);
                     else *reinterpret_cast<uint2*>(dst + co) = make_uint2(pack_bf2(r4[0], r4[1]), pack_bf2(r4[2], r4[3]));
                 }
@@ -208,10 +219,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
     }
 }
 
-template <int NC> int launch(const bf16_t* a, const bf16_t* w, void* out, int B, int H, int W, int Cout, int out_dtype, hipStream_t st) {
+template <int NC> int launch(const bf16_t* a, const bf16_t* w, void* out, int B, int H, int W, int Cout, int out_dtype, hipStream_t st,
+                             const float* bias = nullptr, const bf16_t* res = nullptr) {
     const unsigned grid = (unsigned)(B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW));
-    if (out_dtype == VR_F32) hipLaunchKernelGGL((conv3x3_kernel<NC, float>), dim3(grid), dim3(256), 0, st, a, w, (float*)out, B, H, W, Cout);
-    else hipLaunchKernelGGL((conv3x3_kernel<NC, bf16_t>), dim3(grid), dim3(256), 0, st, a, w, (bf16_t*)out, B, H, W, Cout);
+    if (out_dtype == VR_F32) hipLaunchKernelGGL((conv3x3_kernel<NC, float>), dim3(grid), dim3(256), 0, st, a, w, (float*)out, B, H, W, Cout, bias, res);
+    else hipLaunchKernelGGL((conv3x3_kernel<NC, bf16_t>), dim3(grid), dim3(256), 0, st, a, w, (bf16_t*)out, B, H, W, Cout, bias, res);
     return 0;
 }
 
@@ -234,17 +246,31 @@ extern "C" int vr_conv3x3_wgrad(const void* a, const void* dz, float* dw, int32_
     return VR_OK;
 }
 
+static int conv3x3_entry(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                         int32_t out_dtype, const float* bias, const void* res, vr_stream_t stream);
+
 extern "C" int vr_conv3x3(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                           int32_t out_dtype, vr_stream_t stream) {
+    return conv3x3_entry(a, w, out, B, H, W, Cin, Cout, out_dtype, nullptr, nullptr, stream);
+}
+
+extern "C" int vr_conv3x3_bias_relu(const void* a, const void* w, const float* bias, const void* res, void* out, int32_t B,
+                                    int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t out_dtype, vr_stream_t stream) {
+    if (!bias || ((uintptr_t)bias & 15) || (res && ((uintptr_t)res & 7))) return VR_EINVAL;
+    return conv3x3_entry(a, w, out, B, H, W, Cin, Cout, out_dtype, bias, res, stream);
+}
+
+static int conv3x3_entry(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                         int32_t out_dtype, const float* bias, const void* res, vr_stream_t stream) {
     if (!a || !w || !out || B <= 0 || H <= 0 || W <= 0) return VR_EINVAL;
     if (out_dtype != VR_F32 && out_dtype != VR_BF16) return VR_EUNSUPPORTED;
     if (Cout <= 0 || Cout > 32 || Cout % 4) return VR_EUNSUPPORTED;
     if (((uintptr_t)a & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return VR_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     switch (Cin) {
-        case 16: launch<2>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st); break;
-        case 24: launch<3>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st); break;
-        case 32: launch<4>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st); break;
+        case 16: launch<2>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res); break;
+        case 24: launch<3>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res); break;
+        case 32: launch<4>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res); break;
         default: return VR_EUNSUPPORTED;
     }
     VR_CHECK_LAUNCH();

@@ -394,7 +394,7 @@ __device__ __forceinline__ void epilogue_all(const vr_gemm_args& p, f32x16 (&acc
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = kc[e] ? v[e] : 0.f;       // masked hidden units: u = 0, gelu(u) = 0 (their K loop may be skipped)
-                        h[e] = kc[e] ? (sizeof(T) == 2 ? gelu_fast(v[e]) : gelu_f(v[e])) : 0.f;
+                        h[e] = kc[e] ? (p.act == 3 ? fmaxf(v[e], 0.f) : (sizeof(T) == 2 ? gelu_fast(v[e]) : gelu_f(v[e]))) : 0.f;
                         if (p.act == 2) v[e] = kc[e] ? (sizeof(T) == 2 ? dgelu_fast(v[e]) : dgelu_f(v[e])) : 0.f;   // C = gelu'(u)
                     }
                     if (any) {
@@ -506,7 +506,7 @@ __device__ __forceinline__ void epilogue_lds(const vr_gemm_args& p, f32x16 (&acc
 #pragma unroll
                 for (int e = 0; e < CW; ++e) {
                     v[e] = kc[e] ? v[e] : 0.f;       // masked hidden units: u = 0, gelu(u) = 0 (their K loop may be skipped)
-                    h[e] = kc[e] ? (sizeof(T) == 2 ? gelu_fast(v[e]) : gelu_f(v[e])) : 0.f;
+                    h[e] = kc[e] ? (p.act == 3 ? fmaxf(v[e], 0.f) : (sizeof(T) == 2 ? gelu_fast(v[e]) : gelu_f(v[e]))) : 0.f;
                     if (p.act == 2) v[e] = kc[e] ? (sizeof(T) == 2 ? dgelu_fast(v[e]) : dgelu_f(v[e])) : 0.f;   // C = gelu'(u)
                 }
                 if (any) {
@@ -736,7 +736,7 @@ int launch(const vr_gemm_args& a, hipStream_t stream) {
         else return VR_EUNSUPPORTED;
     } else if (a.a_trans) {
         return VR_EUNSUPPORTED;
-    } else if (a.act == 1 || (a.act == 2 && !a.dact_u)) {
+    } else if (a.act == 1 || a.act == 3 || (a.act == 2 && !a.dact_u)) {
         if (a.b_trans || of32 != (sizeof(T) == 4)) return VR_EUNSUPPORTED;
         launch1<T, false, false, T, EPI_GELU>(a, stream);
     } else if (a.dact_u) {
@@ -764,6 +764,7 @@ static int gemm_validate(vr_gemm_args& a) {
     if (a.split_k > 1 && !a.atomic) return VR_EINVAL;
     if (a.atomic && a.out_dtype != VR_F32) return VR_EINVAL;
     if (a.bias_grad && !(a.a_trans && a.atomic)) return VR_EINVAL;
+    if (a.act < 0 || a.act > 3 || (a.act == 3 && (a.C2 || a.dact_u))) return VR_EINVAL;
     if (a.in_dtype != VR_F32 && a.in_dtype != VR_BF16) return VR_EUNSUPPORTED;
     if (a.out_dtype != VR_F32 && a.out_dtype != VR_BF16) return VR_EUNSUPPORTED;
     const int epc = a.in_dtype == VR_BF16 ? 8 : 4;

@@ -481,6 +481,9 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
                         hh[e] = v[e] * cdf;
                         v[e] = fmaf(v[e], pdf, cdf);
                     }
+                } else if (p.act == 3) {                           // ReLU (BatchNorm-folded convolutions of the evaluation stem)
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) hh[e] = fmaxf(v[e], 0.f);
                 } else {
 #pragma unroll
                     for (int e = 0; e < CW; ++e) hh[e] = gelu_fast(v[e]);
@@ -609,7 +612,7 @@ bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
             a.b_map.rpi != 0 || !fast || a.ldb % 8 || ((uintptr_t)a.B & 15) || a.ldb < (a.N + 7) / 8 * 8)
             return false;
     }
-    if (a.act == 1 || (a.act == 2 && !a.dact_u)) {
+    if (a.act == 1 || a.act == 3 || (a.act == 2 && !a.dact_u)) {
         if (of32) return false;
         launch1<bf16_t, EPI_GELU>(a, stream, n_cu);
     } else if (a.dact_u) {

@@ -429,6 +429,14 @@ def conv3x3(a, w, B, H, W, Cin, Cout, out_dtype):
     return out
 
 
+def conv3x3_bias_relu(a, w, bias, res, B, H, W, Cin, Cout, out_dtype):
+    """relu(conv3x3(a, w) + bias[co]) (+ res): the evaluation form with BatchNorm folded into w / bias (vr_conv3x3_bias_relu)."""
+    out = torch.empty((B * H * W, Cout), dtype=out_dtype, device=a.device)
+    _lib.check(_lib.lib().vr_conv3x3_bias_relu(_p(a), _p(w), _p(bias), _p(res), _p(out), B, H, W, Cin, Cout, _dtcode(out_dtype),
+                                               _stream()), "vr_conv3x3_bias_relu")
+    return out
+
+
 def conv3x3_wgrad_supported(a, Cin, Cout):
     return a.dtype == torch.bfloat16 and Cin == Cout and Cin in (16, 24, 32)
 

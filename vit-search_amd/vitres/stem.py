@@ -62,8 +62,66 @@ def _bn_affine(z, bn, training):
     return scale.contiguous(), shift.contiguous(), mean.contiguous(), rstd.contiguous()
 
 
+# Evaluation (frozen weights, running statistics): BatchNorm folds into the convolution in front of it -- the weights are scaled
+# per output channel by gamma / sqrt(var + eps), the shift becomes a bias, ReLU (and conv3's residual) move into the kernel's
+# epilogue: three bn_relu passes and the fp32 pre-BatchNorm tensors disappear (15 % of the candidate-scoring step was the stem).
+FOLD_BN = __import__("os").environ.get("VITRES_STEM_FOLD_BN", "1") != "0"
+
+
+def _folded_params(model):
+    """bf16 [(w1', t1), (w2', t2), (w3', t3)] with BatchNorm folded in; cached until a parameter / buffer of the stem changes."""
+    pe = model.patch_embed
+    convs = (pe.conv1, pe.conv2, pe.conv3)
+    ver = tuple(t._version for c in convs for t in (c.conv.weight, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var))
+    ptr = tuple(c.conv.weight.data_ptr() for c in convs)
+    cache = getattr(model, "_stem_fold", None)
+    if cache is not None and cache[0] == (ver, ptr):
+        return cache[1]
+    out = []
+    for i, c in enumerate(convs):
+        bn = c.bn
+        scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+        shift = (bn.bias.detach().float() - bn.running_mean.detach().float() * scale).contiguous()
+        w = c.conv.weight.detach().float()
+        o, k = w.shape[0], w.shape[1] * w.shape[2] * w.shape[3]
+        wp = w.permute(0, 2, 3, 1).reshape(o, k) * scale[:, None]
+        ld = 32 if i == 0 else k
+        wf = torch.zeros((o, ld), dtype=torch.bfloat16, device=w.device)
+        wf[:, :k] = wp
+        out.append((wf, shift))
+    model._stem_fold = ((ver, ptr), out)
+    return out
+
+
+def _embed_conv_eval(model, x, p, cfg, keep):
+    pe, dt = model.patch_embed, cfg["dtype"]
+    B, _, H, W = x.shape
+    m, C, P = pe.mid_chans, cfg["dim"], cfg["patches"]
+    Hm, Wm = H // 2, W // 2
+    R = B * Hm * Wm
+    g = Hm // (model.patch_size // 2)
+    T = cfg.get("tokens", 1)
+    N = P + T
+    (w1, t1), (w2, t2), (w3, t3) = _folded_params(model)
+    col1 = K.im2col3x3_image(x, 2, 32, dt)
+    a1 = torch.empty((R, m), dtype=dt, device=x.device)
+    K.gemm(col1, w1, a1, M=R, N=m, K=32, lda=32, ldb=32, ldc=m, bias=t1, act=3)
+    a2 = K.conv3x3_bias_relu(a1, w2, t2, None, B, Hm, Wm, m, m, dt)
+    a3 = K.conv3x3_bias_relu(a2, w3, t3, a1, B, Hm, Wm, m, m, dt)
+    ps = model.patch_size // 2
+    colp = K.patch_unfold(a3, B, g, g, ps, m)
+    ldk = ps * ps * m
+    out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
+    K.gemm(colp, p["proj"].w_c, out, M=B * P, N=C, K=ldk, lda=ldk, ldb=ldk, ldc=C, bias=p["proj"].b,
+           pos=p["pos"][0, T:], keep_n=keep, rows_in=P, c_map=(P, N, T))
+    K.embed_cls(p["tokens"], p["pos"], out, keep, T)
+    return out, None
+
+
 def embed_conv_fwd(model, x, p, cfg, keep, save):
     pe, dt = model.patch_embed, cfg["dtype"]
+    if FOLD_BN and not save and not model.training and dt == torch.bfloat16 and K.conv3x3_supported(x.new_empty(0, dtype=dt), pe.mid_chans, pe.mid_chans):
+        return _embed_conv_eval(model, x, p, cfg, keep)
     B, _, H, W = x.shape
     m, C, P = pe.mid_chans, cfg["dim"], cfg["patches"]
     Hm, Wm = H // 2, W // 2
