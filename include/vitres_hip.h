@@ -361,6 +361,14 @@ int vr_conv3x3(const void* a, const void* w, void* out, int32_t B, int32_t H, in
  */
 int vr_conv3x3_bias_relu(const void* a, const void* w, const float* bias, const void* res, void* out, int32_t B, int32_t H,
                          int32_t W, int32_t Cin, int32_t Cout, int32_t out_dtype, vr_stream_t stream);
+
+/*
+ * conv1 of the conv patch embedding (nets/patch_conv.py:63: 3x3 / stride 2 / pad 1, 3 -> Cout <= 32 channels) straight from
+ * the fp32 NCHW image: out [B*Ho*Wo, Cout] (NHWC, fp32 or bf16) = conv(img, w) (+ bias, relu: the evaluation form with
+ * BatchNorm folded in).  w bf16 [Cout, 32]: k = (kh, kw, c) in the first 27 columns, zeros behind.  No im2col matrix.
+ */
+int vr_conv1_direct(const float* img, const void* w, const float* bias, void* out, int32_t B, int32_t H, int32_t W, int32_t Cout,
+                    int32_t relu, int32_t out_dtype, vr_stream_t stream);
 /* Its weight gradient: dw[co, (kh,kw,ci)] (fp32, [Cout, 9*Cin]) += sum over pixels of dz[p, co] * a[p + (kh-1, kw-1), ci]; a, dz
  * bf16 NHWC.  Covered: Cin == Cout in {16, 24, 32} (the stem's conv2 / conv3); VR_EUNSUPPORTED otherwise. */
 int vr_conv3x3_wgrad(const void* a, const void* dz, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,

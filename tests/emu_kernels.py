@@ -266,6 +266,23 @@ def conv3x3(a, w, B, H, W, Cin, Cout, out_dtype):
     return y.permute(0, 2, 3, 1).reshape(B * H * W, Cout).to(out_dtype)
 
 
+def conv1_direct_supported(img, w, Cout):
+    return img.dtype == torch.float32 and img.shape[1] == 3 and w.dtype == torch.bfloat16 and w.shape[1] == 32
+
+
+def conv1_direct(img, w, bias, relu, out_dtype):
+    B, _, H, W = img.shape
+    Cout = w.shape[0]
+    wt = w.float()[:, :27].view(Cout, 3, 3, 3).permute(0, 3, 1, 2)          # (kh, kw, c) -> [co, c, kh, kw]
+    y = torch.nn.functional.conv2d(img.to(torch.bfloat16).float(), wt, stride=2, padding=1)
+    y = y.permute(0, 2, 3, 1).reshape(-1, Cout)
+    if bias is not None:
+        y = y + bias[None, :]
+    if relu:
+        y = torch.relu(y)
+    return y.to(out_dtype)
+
+
 def conv3x3_bias_relu(a, w, bias, res, B, H, W, Cin, Cout, out_dtype):
     y = torch.relu(conv3x3(a, w, B, H, W, Cin, Cout, torch.float32) + bias[None, :])
     if res is not None:
@@ -408,7 +425,7 @@ def patch_fold(col, B, gh, gw, P, C):
 
 
 ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "gemm_group", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "ln_grad_reduce", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "softce_train", "colsum", "scale_mask_cast",
-       "batchsum", "conv3x3", "conv3x3_bias_relu", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
+       "batchsum", "conv3x3", "conv1_direct", "conv1_direct_supported", "conv3x3_bias_relu", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
 
 
 def install(monkeypatch):

@@ -467,6 +467,27 @@ def test_direct_conv3x3_bias_relu(Cin, Cout, with_res):
     assert float(out.float().min()) >= (0.0 if res is None else float(res.float().min()) - 1e-6)
 
 
+@pytest.mark.parametrize("H,W,Cout,fold", [(56, 56, 24, False), (224, 224, 32, True), (37, 61, 16, True), (30, 20, 8, False)])
+def test_direct_conv1_from_image(H, W, Cout, fold):
+    """vr_conv1_direct: 3x3 / stride 2 / pad 1 from the fp32 NCHW image == conv2d on the bf16-rounded image and weights;
+    odd sizes exercise the padding and the edge tiles; fold = the evaluation epilogue relu(. + bias)."""
+    B = 2
+    img = rnd(B, 3, H, W, seed=1)
+    w = torch.zeros(Cout, 32, dtype=torch.bfloat16)
+    w[:, :27] = (rnd(Cout, 27, seed=2) * 27 ** -0.5).to(torch.bfloat16)
+    bias = 0.3 * rnd(Cout, seed=3) if fold else None
+    for od in (torch.float32, torch.bfloat16):
+        ref = E.conv1_direct(img, w, bias, fold, od)
+        out = K.conv1_direct(img.to(DEV), w.to(DEV), None if bias is None else bias.to(DEV), fold, od)
+        assert out.shape == ref.shape and out.dtype == od
+        assert relerr(out, ref) < (2e-5 if od == torch.float32 else 1e-2)
+    # the gather + GEMM form it replaces gives the same numbers
+    col = K.im2col3x3_image(img.to(DEV), 2, 32, torch.bfloat16)
+    z = torch.empty((col.shape[0], Cout), dtype=torch.float32, device=DEV)
+    K.gemm(col, w.to(DEV), z, M=col.shape[0], N=Cout, K=32, lda=32, ldb=32, ldc=Cout)
+    assert relerr(K.conv1_direct(img.to(DEV), w.to(DEV), None, False, torch.float32), z.cpu()) < 2e-5
+
+
 @pytest.mark.parametrize("M,N,Kd", [(1000, 24, 32), (300, 256, 192), (130, 72, 200)])
 def test_gemm_relu_epilogue(M, N, Kd):
     """act = 3: C = relu(A B^T + bias), single bf16 store (the conv1 GEMM of the BatchNorm-folded evaluation stem)."""

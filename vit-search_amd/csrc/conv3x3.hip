@@ -106,6 +106,89 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const bf16_t* __restrict__
     }
 }
 
+// ---- conv1 of the patch embedding: 3x3 / stride 2 / pad 1 from the fp32 NCHW image (3 channels) -> NHWC [B*Ho*Wo, Cout] --------
+// (reference nets/patch_conv.py:63: the first convolution).  The gather + GEMM form wrote a [B*Ho*Wo, 32] bf16 im2col matrix
+// (205 MB at B = 256) with a one-element-per-thread kernel (0.6 TB/s) and read it back; here a workgroup stages the 17 x 65 x 3
+// input patch of its 8 x 32 output tile in LDS as bf16 and gathers the MFMA operand from it: contraction index k = (kh, kw, c),
+// 27 of the 32 slots (the weights [Cout, 32] are zero in the rest).  Weights first, as above: a lane owns one pixel and four
+// consecutive output channels.  Optional epilogue (evaluation, BatchNorm folded into w): relu(. + bias).
+constexpr int C1_TH = 8, C1_TW = 32, C1_IH = 2 * C1_TH + 1, C1_IW = 2 * C1_TW + 1, C1_IWP = C1_IW + 1;
+
+template <typename TO>
+__global__ __launch_bounds__(256) void conv1_direct_kernel(const float* __restrict__ img, const bf16_t* __restrict__ w,
+                                                           const float* __restrict__ bias, TO* __restrict__ out, int B, int H, int W,
+                                                           int Ho, int Wo, int Cout, int relu) {
+    __shared__ bf16_t patch[3 * C1_IH * C1_IWP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int tiles_x = (Wo + C1_TW - 1) / C1_TW, tiles_y = (Ho + C1_TH - 1) / C1_TH;
+    const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+    const int oy0 = ty * C1_TH, ox0 = tx * C1_TW;
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
+    const float* src = img + (long long)b * 3 * H * W;
+    for (int idx = tid; idx < 3 * C1_IH * C1_IW; idx += 256) {
+        const int ch = idx / (C1_IH * C1_IW), rem = idx - ch * (C1_IH * C1_IW);
+        const int y = rem / C1_IW, x = rem - y * C1_IW;
+        const int iy = iy0 + y, ix = ix0 + x;
+        const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? src[((long long)ch * H + iy) * W + ix] : 0.f;
+        patch[(ch * C1_IH + y) * C1_IWP + x] = f2bf(v);
+    }
+    // weight fragments: channel 16 nf + c, k = 8 g .. 8 g + 7
+    bfv8 wf[2];
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) {
+        const int ch = 16 * nf + c;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ch < Cout) v = *reinterpret_cast<const uint4*>(w + (long long)ch * 32 + 8 * g);
+        wf[nf] = __builtin_bit_cast(bfv8, v);
+    }
+    // LDS offsets of this lane's 8 contraction slots relative to the pixel's window origin
+    int off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * g + j;
+        const int tap = k / 3, ch = k - 3 * tap, kh = tap / 3, kw = tap - 3 * kh;
+        off[j] = k < 27 ? (ch * C1_IH + kh) * C1_IWP + kw : 0;     // slots 27..31 meet zero weights: any finite value will do
+    }
+    __syncthreads();
+    const bool two = Cout > 16;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int oyl = 2 * wave + rr;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int oxl = 16 * f + c;
+            const bf16_t* base = patch + (2 * oyl) * C1_IWP + 2 * oxl;
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = base[off[j]];
+            const uint4 av = make_uint4((unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                                        (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16));
+            const bfv8 af = __builtin_bit_cast(bfv8, av);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], af, acc0, 0, 0, 0);
+            if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], af, acc1, 0, 0, 0);
+            const int oy = oy0 + oyl, ox = ox0 + oxl;
+            if (oy < Ho && ox < Wo) {
+                TO* dst = out + (((long long)b * Ho + oy) * Wo + ox) * Cout;
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) {
+                    const int co = 16 * nf + 4 * g;
+                    if (co < Cout) {
+                        f32x4 r4 = nf == 0 ? acc0 : acc1;
+                        if (bias) {
+                            const float4 bb = *reinterpret_cast<const float4*>(bias + co);
+                            r4[0] += bb.x; r4[1] += bb.y; r4[2] += bb.z; r4[3] += bb.w;
+                        }
+                        if (relu) { r4[0] = fmaxf(r4[0], 0.f); r4[1] = fmaxf(r4[1], 0.f); r4[2] = fmaxf(r4[2], 0.f); r4[3] = fmaxf(r4[3], 0.f); }
+                        if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(dst + co) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+                        else *reinterpret_cast<uint2*>(dst + co) = make_uint2(pack_bf2(r4[0], r4[1]), pack_bf2(r4[2], r4[3]));
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- weight gradient:  dW[co, (kh, kw, ci)] += sum over pixels of dz[p, co] * a[p + (kh-1, kw-1), ci] --------------------
 // Same tiles and halo patch; the contraction now runs over the 256 pixels of a tile, so BOTH MFMA operands are needed
 // "pixel-contiguous" while LDS holds [pixel][channel]: both come from transposing reads (ds_read_b64_tr_b16, as gemm_tn.hip), the
@@ -273,6 +356,25 @@ static int conv3x3_entry(const void* a, const void* w, void* out, int32_t B, int
         case 32: launch<4>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res); break;
         default: return VR_EUNSUPPORTED;
     }
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
+extern "C" int vr_conv1_direct(const float* img, const void* w, const float* bias, void* out, int32_t B, int32_t H, int32_t W,
+                               int32_t Cout, int32_t relu, int32_t out_dtype, vr_stream_t stream) {
+    if (!img || !w || !out || B <= 0 || H <= 0 || W <= 0) return VR_EINVAL;
+    if (out_dtype != VR_F32 && out_dtype != VR_BF16) return VR_EUNSUPPORTED;
+    if (Cout <= 0 || Cout > 32 || Cout % 4) return VR_EUNSUPPORTED;
+    if (((uintptr_t)w & 15) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15))) return VR_EALIGN;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const unsigned grid = (unsigned)(B * ((Ho + C1_TH - 1) / C1_TH) * ((Wo + C1_TW - 1) / C1_TW));
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dtype == VR_F32)
+        hipLaunchKernelGGL((conv1_direct_kernel<float>), dim3(grid), dim3(256), 0, st, img, (const bf16_t*)w, bias, (float*)out, B, H, W,
+                           Ho, Wo, Cout, relu);
+    else
+        hipLaunchKernelGGL((conv1_direct_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, img, (const bf16_t*)w, bias, (bf16_t*)out, B, H,
+                           W, Ho, Wo, Cout, relu);
     VR_CHECK_LAUNCH();
     return VR_OK;
 }

@@ -67,6 +67,7 @@ SYMBOLS = {
     "vr_conv3x3_wgrad": [c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
     "vr_conv3x3": [c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p],
     "vr_conv3x3_bias_relu": [c_void_p] * 5 + [c_int32] * 6 + [c_void_p],
+    "vr_conv1_direct": [c_void_p] * 4 + [c_int32] * 6 + [c_void_p],
     "vr_token_mix": [c_void_p] * 6 + [c_int32] * 11 + [c_float] * 6 + [c_void_p],
     "vr_token_mean": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "vr_token_mean_bwd": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],

@@ -429,6 +429,23 @@ def conv3x3(a, w, B, H, W, Cin, Cout, out_dtype):
     return out
 
 
+def conv1_direct_supported(img, w, Cout):
+    return img.dtype == torch.float32 and img.shape[1] == 3 and w.dtype == torch.bfloat16 and w.shape[1] == 32 and \
+        Cout <= 32 and Cout % 4 == 0
+
+
+def conv1_direct(img, w, bias, relu, out_dtype):
+    """3x3 / stride 2 / pad 1 convolution of the fp32 NCHW image (3 channels): w bf16 [Cout, 32] (kh, kw, c; zero padded)
+    -> NHWC [B*Ho*Wo, Cout], optionally relu(. + bias) (vr_conv1_direct)."""
+    B, _, H, W = img.shape
+    Cout = w.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((B * Ho * Wo, Cout), dtype=out_dtype, device=img.device)
+    _lib.check(_lib.lib().vr_conv1_direct(_p(img), _p(w), _p(bias), _p(out), B, H, W, Cout, int(bool(relu)), _dtcode(out_dtype),
+                                          _stream()), "vr_conv1_direct")
+    return out
+
+
 def conv3x3_bias_relu(a, w, bias, res, B, H, W, Cin, Cout, out_dtype):
     """relu(conv3x3(a, w) + bias[co]) (+ res): the evaluation form with BatchNorm folded into w / bias (vr_conv3x3_bias_relu)."""
     out = torch.empty((B * H * W, Cout), dtype=out_dtype, device=a.device)

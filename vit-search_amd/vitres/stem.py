@@ -66,6 +66,9 @@ def _bn_affine(z, bn, training):
 # per output channel by gamma / sqrt(var + eps), the shift becomes a bias, ReLU (and conv3's residual) move into the kernel's
 # epilogue: three bn_relu passes and the fp32 pre-BatchNorm tensors disappear (15 % of the candidate-scoring step was the stem).
 FOLD_BN = __import__("os").environ.get("VITRES_STEM_FOLD_BN", "1") != "0"
+# conv1 straight from the NCHW image (vr_conv1_direct) instead of im2col + GEMM; in training the im2col matrix is only built
+# in the backward, beside the data-gradient chain, for conv1's weight gradient
+DIRECT_CONV1 = __import__("os").environ.get("VITRES_STEM_DIRECT_CONV1", "1") != "0"
 
 
 def _folded_params(model):
@@ -103,9 +106,12 @@ def _embed_conv_eval(model, x, p, cfg, keep):
     T = cfg.get("tokens", 1)
     N = P + T
     (w1, t1), (w2, t2), (w3, t3) = _folded_params(model)
-    col1 = K.im2col3x3_image(x, 2, 32, dt)
-    a1 = torch.empty((R, m), dtype=dt, device=x.device)
-    K.gemm(col1, w1, a1, M=R, N=m, K=32, lda=32, ldb=32, ldc=m, bias=t1, act=3)
+    if DIRECT_CONV1 and K.conv1_direct_supported(x, w1, m):
+        a1 = K.conv1_direct(x, w1, t1, True, dt)
+    else:
+        col1 = K.im2col3x3_image(x, 2, 32, dt)
+        a1 = torch.empty((R, m), dtype=dt, device=x.device)
+        K.gemm(col1, w1, a1, M=R, N=m, K=32, lda=32, ldb=32, ldc=m, bias=t1, act=3)
     a2 = K.conv3x3_bias_relu(a1, w2, t2, None, B, Hm, Wm, m, m, dt)
     a3 = K.conv3x3_bias_relu(a2, w3, t3, a1, B, Hm, Wm, m, m, dt)
     ps = model.patch_size // 2
@@ -135,8 +141,12 @@ def embed_conv_fwd(model, x, p, cfg, keep, save):
         z = torch.empty((R, m), dtype=torch.float32, device=x.device)
         K.gemm(col, w, z, M=R, N=m, K=ld, lda=ld, ldb=ld, ldc=m)
         return z
-    col1 = K.im2col3x3_image(x, 2, 32, dt)
-    z1 = conv(col1, p["w1"], 32)
+    if DIRECT_CONV1 and K.conv1_direct_supported(x, p["w1"], m):
+        col1 = None                                            # (built in the backward from the saved image)
+        z1 = K.conv1_direct(x, p["w1"], None, False, torch.float32)
+    else:
+        col1 = K.im2col3x3_image(x, 2, 32, dt)
+        z1 = conv(col1, p["w1"], 32)
     bn1 = _bn_affine(z1, pe.conv1.bn, tr)
     a1 = K.bn_relu(z1, bn1[0], bn1[1], None, dt)
     # conv2 / conv3: direct MFMA convolution when the shape is covered (bf16, m in {16,24,32}); the im2col matrix (9x the
@@ -163,7 +173,8 @@ def embed_conv_fwd(model, x, p, cfg, keep, save):
     K.gemm(colp, p["proj"].w_c, out, M=B * P, N=C, K=ldk, lda=ldk, ldb=ldk, ldc=C, bias=p["proj"].b,
            pos=p["pos"][0, T:], keep_n=keep, rows_in=P, c_map=(P, N, T))
     K.embed_cls(p["tokens"], p["pos"], out, keep, T)
-    saved = (col1, z1, bn1, col2, z2, bn2, col3, z3, bn3, colp, (B, Hm, Wm, m, g, ps, tr, direct)) if save else None
+    saved = (col1 if col1 is not None else ("image", x), z1, bn1, col2, z2, bn2, col3, z3, bn3, colp,
+             (B, Hm, Wm, m, g, ps, tr, direct)) if save else None
     return out, saved
 
 
@@ -208,7 +219,10 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
             if direct_w:                        # `col` is the saved NHWC activation: direct weight-gradient kernel
                 K.conv3x3_wgrad(col, dz, wg, B, Hm, Wm, cin, m)
             else:
-                Fn.linear_wgrad(dz, col, wg, R, m, ld, m, ld, sched=1 if ov else 0)
+                c_ = col
+                if isinstance(c_, tuple):       # conv1 ran straight from the image: its im2col matrix is built here
+                    c_ = K.im2col3x3_image(c_[1], 2, ld, dt)
+                Fn.linear_wgrad(dz, c_, wg, R, m, ld, m, ld, sched=1 if ov else 0)
             gv(conv_mod.conv.weight).copy_(wg[:, :9 * cin].reshape(m, 3, 3, cin).permute(0, 3, 1, 2))
         Fn.on_side(wgrad, dz, wg) if ov else wgrad()
         if not need_dx:
