@@ -43,6 +43,7 @@ FUSE_LN_FWD_MAXK = int(_os.environ.get('VITRES_FUSE_LN_FWD_MAXK', '4096'))
 # the same 2C addresses; flush_ln_grads() folds the rows of every LayerNorm of a backward part in one launch.  vr_ln_bwd at
 # (128 x 257, 256): 33 -> 23 us.  0 / 1 = accumulate straight into the parameter gradients.
 LN_COPIES = int(_os.environ.get('VITRES_LN_COPIES', '64'))
+_DBG_SKIP_WGRAD = _os.environ.get('VITRES_DBG_SKIP_WGRAD', '0') != '0'
 _ln_pending = []
 
 
@@ -212,6 +213,8 @@ def flush_wgrads():
         return
     calls = list(_block_wgrads)
     del _block_wgrads[:]
+    if _DBG_SKIP_WGRAD:                                     # timing experiment only (wrong gradients): the main chain alone
+        return
     if not OVERLAP:                                         # single-stream runs (profiling passes): same kernel, in line
         return K.gemm_group(calls)
     on_side(lambda: K.gemm_group(calls), *[t_ for c_ in calls for t_ in c_[:2]])
