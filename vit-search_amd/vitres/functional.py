@@ -214,6 +214,9 @@ def flush_wgrads():
     calls = list(_block_wgrads)
     del _block_wgrads[:]
     if _DBG_SKIP_WGRAD:                                     # timing experiment only (wrong gradients): the main chain alone
+        if _os.environ.get('VITRES_DBG_SKIP_WGRAD') == '2':  # ... with the fork / join edges kept (a one-element kernel on the side)
+            t0 = calls[0][0]
+            on_side(lambda: t0.view(-1)[:1].add_(0), t0)
         return
     if not OVERLAP:                                         # single-stream runs (profiling passes): same kernel, in line
         return K.gemm_group(calls)
