@@ -172,6 +172,30 @@ def test_emulated_patch_output_avg(monkeypatch, mode):
             assert rel(p[k[len(mode) + 6:]].grad, torch.from_numpy(g[k])) < 2e-4, k
 
 
+@pytest.mark.parametrize("et", [4, 5])
+def test_emulated_eval_stem_with_folded_batchnorm(monkeypatch, et):
+    """Host logic of the evaluation stem (vitres/stem.py): BatchNorm folded into the three convolutions' weights / biases, conv1
+    straight from the image, residual in conv3's epilogue -- same logits as the reference's eval forward (bf16 rounding of the
+    operands apart) and as the un-folded kernel sequence; the folded weights follow a changed running statistic."""
+    import vitres.stem as stem
+    emu_kernels.install(monkeypatch)
+    g = np.load(os.path.join(G, "f1_micro_t%d_plain.npz" % et))
+    prod, orc, sd = build_pair(et, "plain", 100 + et)
+    prod.set_compute_dtype(torch.bfloat16)
+    x, _, _, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    prod.eval()
+    with torch.no_grad():
+        monkeypatch.setattr(stem, "FOLD_BN", True)
+        folded = prod(x).clone()
+        monkeypatch.setattr(stem, "FOLD_BN", False)
+        plain = prod(x).clone()
+        assert rel(folded, torch.from_numpy(g["eval.cls"])) < 3e-2
+        assert rel(folded, plain) < 2e-2
+        prod.patch_embed.conv2.bn.running_var.mul_(4.0)
+        monkeypatch.setattr(stem, "FOLD_BN", True)
+        assert rel(prod(x), folded) > 1e-3
+
+
 def test_cpu_tensor_is_refused():
     prod, _, _ = build_pair(0, "plain", 100)
     with pytest.raises(RuntimeError):
