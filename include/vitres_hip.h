@@ -341,6 +341,8 @@ int vr_mask_rows(float* x, const int32_t* keep, int32_t M, int32_t C, int32_t ro
  *  vr_bn_relu     : out = relu(z * scale[c] + shift[c]) (+ res)          (ConvBnAct.forward :34-38 with folded BN affine).
  *  vr_bn_bwd      : g = da * [bn(z) > 0]; sg[c] += sum g; sgz[c] += sum g*zhat (caller zeroes); then
  *                   dz = scale * (g - sg/R - zhat*sgz/R) (training) or scale * g (eval).  d gamma = sgz, d beta = sg.
+ *  z (the pre-BatchNorm convolution output) is fp32 or, with bf16 activations, bf16 (`z_dtype`; what autocast gives the reference's
+ *  convolutions): statistics and gradients are accumulated in fp32 either way.
  *  vr_patch_unfold: non-overlapping P x P patches, a NHWC [B, gh*P, gw*P, C] <-> col [B*gh*gw, (i, j, c)] (fold != 0: col -> a).
  */
 int vr_im2col3x3(const void* src, void* col, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride,
@@ -373,11 +375,12 @@ int vr_conv1_direct(const float* img, const void* w, const float* bias, void* ou
  * bf16 NHWC.  Covered: Cin == Cout in {16, 24, 32} (the stem's conv2 / conv3); VR_EUNSUPPORTED otherwise. */
 int vr_conv3x3_wgrad(const void* a, const void* dz, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                      vr_stream_t stream);
-int vr_bn_stats(const float* z, float* sum, float* sumsq, int64_t R, int32_t C, vr_stream_t stream);
-int vr_bn_relu(const float* z, const float* scale, const float* shift, const void* res, void* out, int64_t R, int32_t C,
-               int32_t dtype, vr_stream_t stream);
-int vr_bn_bwd(const void* da, const float* z, const float* scale, const float* shift, const float* mean, const float* rstd,
-              float* sg, float* sgz, void* dz, int64_t R, int32_t C, int32_t training, int32_t dtype, vr_stream_t stream);
+int vr_bn_stats(const void* z, float* sum, float* sumsq, int64_t R, int32_t C, int32_t z_dtype, vr_stream_t stream);
+int vr_bn_relu(const void* z, const float* scale, const float* shift, const void* res, void* out, int64_t R, int32_t C,
+               int32_t dtype, int32_t z_dtype, vr_stream_t stream);
+int vr_bn_bwd(const void* da, const void* z, const float* scale, const float* shift, const float* mean, const float* rstd,
+              float* sg, float* sgz, void* dz, int64_t R, int32_t C, int32_t training, int32_t dtype, int32_t z_dtype,
+              vr_stream_t stream);
 int vr_patch_unfold(void* a, void* col, int32_t B, int32_t gh, int32_t gw, int32_t P, int32_t C, int32_t fold, int32_t dtype,
                     vr_stream_t stream);
 

@@ -394,18 +394,20 @@ def col2im3x3(dcol, B, H, W, C):
 
 
 def bn_stats(z, s, q):
+    z = z.float()
     s += z.sum(0)
     q += (z * z).sum(0)
 
 
 def bn_relu(z, scale, shift, res, out_dtype):
-    v = torch.relu(z * scale + shift)
+    v = torch.relu(z.float() * scale + shift)
     if res is not None:
         v = v + res.float()
     return v.to(out_dtype)
 
 
 def bn_bwd(da, z, scale, shift, mean, rstd, sg, sgz, training):
+    z = z.float()
     g = da.float() * ((z * scale + shift) > 0)
     zh = (z - mean) * rstd
     sg += g.sum(0)

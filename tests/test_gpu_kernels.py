@@ -348,6 +348,20 @@ def test_stem_kernels(dtype):
         dz = K.bn_bwd(da.to(DEV), z.to(DEV), scale.to(DEV), shift.to(DEV), mean.to(DEV), rstd.to(DEV), sg, sgz, training)
         assert relerr(sg, sg_r) < 1e-4 and relerr(sgz, sgz_r) < 1e-4
         assert relerr(dz, dz_r) < (1e-4 if dtype == torch.float32 else 1.5e-2)
+    if dtype == torch.bfloat16:        # the pre-BatchNorm tensor stored in bf16 (z_dtype): same kernels, fp32 sums
+        zb = z.to(torch.bfloat16)
+        s_ref, q_ref = torch.zeros(m), torch.zeros(m)
+        E.bn_stats(zb, s_ref, q_ref)
+        sd, qd = torch.zeros(m, device=DEV), torch.zeros(m, device=DEV)
+        K.bn_stats(zb.to(DEV), sd, qd)
+        assert relerr(sd, s_ref) < 1e-5 and relerr(qd, q_ref) < 1e-5
+        r, e = both("bn_relu", (zb, scale, shift, res, dtype))
+        assert relerr(r, e) < tol(dtype)
+        sg_r, sgz_r = torch.zeros(m), torch.zeros(m)
+        dz_r = E.bn_bwd(da, zb, scale, shift, mean, rstd, sg_r, sgz_r, True)
+        sg, sgz = torch.zeros(m, device=DEV), torch.zeros(m, device=DEV)
+        dz = K.bn_bwd(da.to(DEV), zb.to(DEV), scale.to(DEV), shift.to(DEV), mean.to(DEV), rstd.to(DEV), sg, sgz, True)
+        assert relerr(sg, sg_r) < 1e-4 and relerr(sgz, sgz_r) < 1e-4 and relerr(dz, dz_r) < 1.5e-2
     a3 = rnd(B * 14 * 14, m, seed=9).to(dtype)
     r, e = both("patch_unfold", (a3, B, 2, 2, 7, m))
     assert torch.equal(r.cpu(), e)

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void col2im3x3_nhwc_kernel(const T* __restrict
 
 // ---- BatchNorm pieces --------------------------------------------------------------------------------------
 // per-channel sum and sum of squares of z fp32 [R, C]; block = 256 threads = (256/C8N rows) x C8N channel octets
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, float* __restrict__ sum,
+template <typename TZ>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const TZ* __restrict__ z, float* __restrict__ sum,
                                                        float* __restrict__ sumsq, long long R, int C) {
     __shared__ float red[2][256 * 8 / 8 * 8];
     const int c8n = C / 8;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     if (rl < rows_par) {
         for (long long r = (long long)blockIdx.x * rows_par + rl; r < R; r += (long long)gridDim.x * rows_par) {
             float f[8];
-            V8<float>::load(z + r * C + c8 * 8, f);
+            V8<TZ>::load(z + r * C + c8 * 8, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 s[e] += f[e];
@@ -147,15 +148,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 }
 
 // out = relu(z * scale[c] + shift[c]) (+ res)
-template <typename T>
-__global__ __launch_bounds__(256) void bn_relu_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+template <typename T, typename TZ>
+__global__ __launch_bounds__(256) void bn_relu_kernel(const TZ* __restrict__ z, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const T* __restrict__ res,
                                                       T* __restrict__ out, long long total8, int C) {
     const int c8n = C / 8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
         const int c0 = (int)(i % c8n) * 8;
         float f[8], r[8];
-        V8<float>::load(z + i * 8, f);
+        V8<TZ>::load(z + i * 8, f);
         if (res) V8<T>::load(res + i * 8, r);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -168,8 +169,8 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const float* __restrict__ 
 }
 
 // backward reduction: g = da * [z*scale+shift > 0];  sg[c] += g ; sgz[c] += g * zhat,  zhat = (z - mean) * rstd
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ da, const float* __restrict__ z,
+template <typename T, typename TZ>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ da, const TZ* __restrict__ z,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             float* __restrict__ sg, float* __restrict__ sgz, long long R,
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         }
         for (long long r = (long long)blockIdx.x * rows_par + rl; r < R; r += (long long)gridDim.x * rows_par) {
             float f[8], g[8];
-            V8<float>::load(z + r * C + c8 * 8, f);
+            V8<TZ>::load(z + r * C + c8 * 8, f);
             V8<T>::load(da + r * C + c8 * 8, g);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -216,8 +217,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // dz = gamma*rstd * (g - sg/n - zhat * sgz/n)   [training]   or   gamma*rstd * g   [eval: inv_n = 0]
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ da, const float* __restrict__ z,
+template <typename T, typename TZ>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ da, const TZ* __restrict__ z,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ sg, const float* __restrict__ sgz,
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
         const int c0 = (int)(i % c8n) * 8;
         float f[8], g[8];
-        V8<float>::load(z + i * 8, f);
+        V8<TZ>::load(z + i * 8, f);
         V8<T>::load(da + i * 8, g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -306,52 +307,64 @@ extern "C" int vr_col2im3x3(const void* dcol, void* dsrc, int32_t B, int32_t H, 
     return VR_OK;
 }
 
-extern "C" int vr_bn_stats(const float* z, float* sum, float* sumsq, int64_t R, int32_t C, vr_stream_t stream) {
+extern "C" int vr_bn_stats(const void* z, float* sum, float* sumsq, int64_t R, int32_t C, int32_t z_dtype, vr_stream_t stream) {
     if (!z || !sum || !sumsq || R <= 0 || C <= 0) return VR_EINVAL;
     if (C % 8 || C > 256) return VR_EUNSUPPORTED;
+    if (z_dtype != VR_F32 && z_dtype != VR_BF16) return VR_EUNSUPPORTED;
     const int rows_par = 256 / (C / 8);
     long long blocks = (R + rows_par * 64 - 1) / (rows_par * 64);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, sum, sumsq, (long long)R, C);
+    if (z_dtype == VR_F32)
+        hipLaunchKernelGGL((bn_stats_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)z, sum, sumsq, (long long)R, C);
+    else
+        hipLaunchKernelGGL((bn_stats_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, sum, sumsq, (long long)R, C);
     VR_CHECK_LAUNCH();
     return VR_OK;
 }
 
-extern "C" int vr_bn_relu(const float* z, const float* scale, const float* shift, const void* res, void* out, int64_t R,
-                          int32_t C, int32_t dtype, vr_stream_t stream) {
+extern "C" int vr_bn_relu(const void* z, const float* scale, const float* shift, const void* res, void* out, int64_t R,
+                          int32_t C, int32_t dtype, int32_t z_dtype, vr_stream_t stream) {
     if (!z || !scale || !shift || !out || R <= 0 || C <= 0) return VR_EINVAL;
     if (C % 8) return VR_EUNSUPPORTED;
+    if (z_dtype != VR_F32 && !(z_dtype == VR_BF16 && dtype == VR_BF16)) return VR_EUNSUPPORTED;
     const long long total8 = (long long)R * (C / 8);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VR_F32)
-        hipLaunchKernelGGL((bn_relu_kernel<float>), dim3(grid_for(total8)), dim3(256), 0, st, z, scale, shift, (const float*)res, (float*)out, total8, C);
+        hipLaunchKernelGGL((bn_relu_kernel<float, float>), dim3(grid_for(total8)), dim3(256), 0, st, (const float*)z, scale, shift, (const float*)res, (float*)out, total8, C);
+    else if (dtype == VR_BF16 && z_dtype == VR_F32)
+        hipLaunchKernelGGL((bn_relu_kernel<bf16_t, float>), dim3(grid_for(total8)), dim3(256), 0, st, (const float*)z, scale, shift, (const bf16_t*)res, (bf16_t*)out, total8, C);
     else if (dtype == VR_BF16)
-        hipLaunchKernelGGL((bn_relu_kernel<bf16_t>), dim3(grid_for(total8)), dim3(256), 0, st, z, scale, shift, (const bf16_t*)res, (bf16_t*)out, total8, C);
+        hipLaunchKernelGGL((bn_relu_kernel<bf16_t, bf16_t>), dim3(grid_for(total8)), dim3(256), 0, st, (const bf16_t*)z, scale, shift, (const bf16_t*)res, (bf16_t*)out, total8, C);
     else
         return VR_EUNSUPPORTED;
     VR_CHECK_LAUNCH();
     return VR_OK;
 }
 
-extern "C" int vr_bn_bwd(const void* da, const float* z, const float* scale, const float* shift, const float* mean,
+extern "C" int vr_bn_bwd(const void* da, const void* z, const float* scale, const float* shift, const float* mean,
                          const float* rstd, float* sg, float* sgz, void* dz, int64_t R, int32_t C, int32_t training,
-                         int32_t dtype, vr_stream_t stream) {
+                         int32_t dtype, int32_t z_dtype, vr_stream_t stream) {
     if (!da || !z || !scale || !shift || !mean || !rstd || !sg || !sgz || !dz || R <= 0 || C <= 0) return VR_EINVAL;
     if (C % 8 || C > 256) return VR_EUNSUPPORTED;
     if (dtype != VR_F32 && dtype != VR_BF16) return VR_EUNSUPPORTED;
+    if (z_dtype != VR_F32 && !(z_dtype == VR_BF16 && dtype == VR_BF16)) return VR_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int rows_par = 256 / (C / 8);
     long long blocks = (R + rows_par * 64 - 1) / (rows_par * 64);
     if (blocks > 2048) blocks = 2048;
     const long long total8 = (long long)R * (C / 8);
     const float inv_n = training ? 1.0f / (float)R : 0.f;
-    if (dtype == VR_F32) {
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)da, z, scale, shift, mean, rstd, sg, sgz, (long long)R, C);
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid_for(total8)), dim3(256), 0, st, (const float*)da, z, scale, shift, mean, rstd, sg, sgz, inv_n, (float*)dz, total8, C);
-    } else {
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)da, z, scale, shift, mean, rstd, sg, sgz, (long long)R, C);
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(grid_for(total8)), dim3(256), 0, st, (const bf16_t*)da, z, scale, shift, mean, rstd, sg, sgz, inv_n, (bf16_t*)dz, total8, C);
-    }
+#define VR_BN_BWD(T, TZ)                                                                                                       \
+    do {                                                                                                                       \
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, TZ>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)da, (const TZ*)z,  \
+                           scale, shift, mean, rstd, sg, sgz, (long long)R, C);                                                \
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TZ>), dim3(grid_for(total8)), dim3(256), 0, st, (const T*)da, (const TZ*)z,   \
+                           scale, shift, mean, rstd, sg, sgz, inv_n, (T*)dz, total8, C);                                       \
+    } while (0)
+    if (dtype == VR_F32) VR_BN_BWD(float, float);
+    else if (z_dtype == VR_F32) VR_BN_BWD(bf16_t, float);
+    else VR_BN_BWD(bf16_t, bf16_t);
+#undef VR_BN_BWD
     VR_CHECK_LAUNCH();
     return VR_OK;
 }

@@ -82,9 +82,9 @@ SYMBOLS = {
     "vr_mask_rows": [c_void_p, c_void_p] + [c_int32] * 3 + [c_void_p],
     "vr_im2col3x3": [c_void_p, c_void_p] + [c_int32] * 8 + [c_void_p],
     "vr_col2im3x3": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
-    "vr_bn_stats": [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p],
-    "vr_bn_relu": [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_void_p],
-    "vr_bn_bwd": [c_void_p] * 9 + [c_int64, c_int32, c_int32, c_int32, c_void_p],
+    "vr_bn_stats": [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p],
+    "vr_bn_relu": [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32, c_void_p],
+    "vr_bn_bwd": [c_void_p] * 9 + [c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "vr_patch_unfold": [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p],
 }
 

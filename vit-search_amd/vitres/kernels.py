@@ -472,13 +472,13 @@ def col2im3x3(dcol, B, H, W, C):
 
 def bn_stats(z, s, q):
     R, C = z.shape
-    _lib.check(_lib.lib().vr_bn_stats(_p(z), _p(s), _p(q), R, C, _stream()), "vr_bn_stats")
+    _lib.check(_lib.lib().vr_bn_stats(_p(z), _p(s), _p(q), R, C, _dt(z), _stream()), "vr_bn_stats")
 
 
 def bn_relu(z, scale, shift, res, out_dtype):
     R, C = z.shape
     out = torch.empty((R, C), dtype=out_dtype, device=z.device)
-    _lib.check(_lib.lib().vr_bn_relu(_p(z), _p(scale), _p(shift), _p(res), _p(out), R, C, _dtcode(out_dtype), _stream()),
+    _lib.check(_lib.lib().vr_bn_relu(_p(z), _p(scale), _p(shift), _p(res), _p(out), R, C, _dtcode(out_dtype), _dt(z), _stream()),
                "vr_bn_relu")
     return out
 
@@ -487,7 +487,7 @@ def bn_bwd(da, z, scale, shift, mean, rstd, sg, sgz, training):
     R, C = z.shape
     dz = torch.empty((R, C), dtype=da.dtype, device=z.device)
     _lib.check(_lib.lib().vr_bn_bwd(_p(da), _p(z), _p(scale), _p(shift), _p(mean), _p(rstd), _p(sg), _p(sgz), _p(dz), R, C,
-                                    int(training), _dt(da), _stream()), "vr_bn_bwd")
+                                    int(training), _dt(da), _dt(z), _stream()), "vr_bn_bwd")
     return dz
 
 
