@@ -327,7 +327,8 @@ bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
     // Every workgroup pays |tile| x 4 B of fp32 atomics whatever its share of the tokens, so the token split is coarse: 32
     // slices (2048 tokens) per workgroup (measured inside the two-stream training step: +3 % over 16/32 adaptive; 24 / 40 /
     // 48 / 64 slower; VITRES_TN_S overrides), never more than 4 workgroups per CU.  64 x 64 tiles give 4x the workgroups at the
-    // same atomic volume.
+    // same atomic volume.  (Round 2: splitting the few-tile problems -- patch-embedding and head weights, 64 - 160 workgroups --
+    // finer until the chip holds two workgroups per CU: step 7.77 -> 7.86 ms, their atomics and the contention cost more.)
     long long split = (slices + knob_s - 1) / knob_s;
     // (64 x 64 is opt-in, VITRES_TN_TW=64: alone on the chip it is up to 2x faster for stage-1 weights, but inside the training
     // step the extra workgroups take CUs from the data-gradient chain they run beside: measured -3 %)
