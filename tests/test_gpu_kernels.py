@@ -243,7 +243,8 @@ def test_layernorm_grad_partial_rows(C, copies):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,H,D", [(17, 2, 64), (65, 3, 48), (257, 2, 32), (257, 3, 64), (5, 2, 48), (2, 2, 64)])
+@pytest.mark.parametrize("N,H,D", [(17, 2, 64), (65, 3, 48), (257, 2, 32), (257, 3, 64), (5, 2, 48), (2, 2, 64), (40, 2, 64),
+                                   (50, 3, 32), (96, 2, 48), (197, 3, 64), (130, 2, 32), (32, 2, 64), (64, 2, 32)])
 def test_attention_fwd_bwd(dtype, N, H, D):
     B = 3
     qkv = rnd(B, N, 3 * H * D, seed=1).to(dtype)
