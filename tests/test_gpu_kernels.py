@@ -399,6 +399,40 @@ def test_gemm_dgrad_reads_forward_weight(M, N, Kd, act):
     assert relerr(real, real2.cpu()) < 2e-3
 
 
+@pytest.mark.parametrize("M,N,Kd,form", [(8320, 512, 1536, "res"), (8320, 512, 512, "plain"), (8320, 1536, 512, "gelu2"),
+                                          (128, 1024, 1000, "plain"), (128, 512, 1024, "res"), (2176, 1024, 768, "res"),
+                                          (2176, 768, 1024, "bias")])
+def test_gemm_several_slices_per_round(M, N, Kd, form):
+    """The grid-dependent K-loop forms of the LDS-DMA kernel (two / four slices per round on grids of <= 3 / <= 1 workgroups per
+    CU, the three-buffer ring) at the step's second- and third-stage shapes, with masks, against the emulation."""
+    rows_in = 65 if M % 65 == 0 else (17 if M % 17 == 0 else 1)
+    nb = M // rows_in
+    a = _bf(rnd(M, Kd, seed=1))
+    w = _bf(rnd(N, Kd, seed=2, scale=Kd ** -0.5))
+    keep_k = torch.tensor([Kd, Kd // 2, Kd, (Kd // 4) // 8 * 8] * (nb // 4 + 1), dtype=torch.int32)[:nb]
+    keep_n = torch.tensor([N, N // 2, 8, N - 8] * (nb // 4 + 1), dtype=torch.int32)[:nb]
+    a = _bf(a.float() * (torch.arange(Kd)[None, :] < keep_k.long().repeat_interleave(rows_in)[:, None]))
+    kw = dict(M=M, N=N, K=Kd, lda=Kd, ldb=Kd, ldc=N, rows_in=rows_in, keep_k=keep_k, keep_n=keep_n)
+    out_dt = torch.bfloat16
+    outs = {}
+    if form == "res":
+        out_dt = torch.float32
+        kw.update(bias=rnd(N, seed=3), resid=rnd(M, N, seed=4), scale=torch.tensor([1.25, 0.0, 1.0, 1.25] * (nb // 4 + 1))[:nb])
+    elif form == "bias":
+        kw.update(bias=rnd(N, seed=3))
+    elif form == "gelu2":
+        kw.update(bias=rnd(N, seed=3), act=2)
+        outs = dict(out2=torch.zeros(M, N, dtype=out_dt))
+    ref2 = dict(outs)
+    ref = E.gemm(a, w, torch.zeros(M, N, dtype=out_dt), **kw, **ref2)
+    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+    dev2 = {k: torch.zeros_like(v).to(DEV) for k, v in outs.items()}
+    real = K.gemm(a.to(DEV), w.to(DEV), torch.full((M, N), 7.0, dtype=out_dt, device=DEV), **{k: to(v) for k, v in kw.items()}, **dev2)
+    assert relerr(real, ref) < (2e-3 if out_dt == torch.float32 else tol(torch.bfloat16))
+    for k in outs:
+        assert relerr(dev2[k], ref2[k]) < tol(torch.bfloat16)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_masked_work_skipping(dtype):
     """keep_k / keep_n / periods only skip work that is zero by contract: results equal the dense statement."""
