@@ -662,7 +662,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                     "fc1": self._lin(blk.mlp.fc1), "fc2": self._lin(blk.mlp.fc2)}
         if isinstance(blk, SpatialReductionPatchEmbedding):
             w = blk.patch_reduce.weight
-            wperm = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(self.compute_dtype).contiguous()
+            # [co, ci, 3, 3] -> [co, (kh, kw, ci)] from the compute-dtype shadow of the weight: one strided copy, no cast pass
+            wperm = self._wc(w).view(w.shape).permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
             # (transposed copy for the data gradient only in the round-1 layout: the LDS-DMA kernel reads wperm itself, b_trans)
             wperm_t = wperm.t().contiguous() if self.compute_dtype == torch.bfloat16 and wperm.shape[0] % 8 == 0 and \
                 self._arena.get("wt_mode") == "all" else None
