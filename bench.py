@@ -325,8 +325,16 @@ def main():
     losses = []
     if graphed is not None and world > 1:
         graphed.exposed = []
+    gap_probe = [] if os.environ.get("VITRES_DBG_GAP") else None   # dev aid: GPU time inside a step / between two steps
     for i in range(args.steps):
+        if gap_probe is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         losses.append(step(args.warmup + i))
+        if gap_probe is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            gap_probe.append((e0, e1))
     host_enqueue = time.perf_counter() - t0              # host time to issue the K steps (the GPU may still be running)
     if world > 1:
         dist.barrier()
@@ -338,6 +346,11 @@ def main():
     elapsed = float(tmax.item())
     lossv = torch.stack(losses).tolist()
     assert all(v == v and abs(v) != float("inf") for v in lossv), "non-finite loss"
+    if gap_probe:
+        inside = sum(a.elapsed_time(b) for a, b in gap_probe) / len(gap_probe)
+        between = sum(gap_probe[i][1].elapsed_time(gap_probe[i + 1][0]) for i in range(len(gap_probe) - 1)) / max(len(gap_probe) - 1, 1)
+        print("gap probe: %.3f ms inside a step, %.3f ms between the end of one step and the start of the next" % (inside, between),
+              file=sys.stderr)
     exchange = None
     if world > 1:
         n_arena = model._arena["flat"].numel()
