@@ -1062,7 +1062,8 @@ template <typename K> static int set_lds(K kernel, size_t bytes) {
 
 // waves per (batch, head) and workgroups per CU the register budget is set for (a multiple of the 4 SIMDs, see above)
 template <int NKP> struct Plan {
-    // (NKP = 3, N = 65 = 5 tiles of 16: five waves in one round instead of four waves in two were measured slower, bwd 27 -> 34 us)
+    // (NKP = 3, N = 65 = 5 tiles of 16: five waves in one round instead of four waves in two were measured slower, bwd 27 -> 34 us;
+    //  N = 257 with four waves -- 17 tiles in 5 rounds instead of 3 rounds of eight -- also: fwd 25.1 -> 28.8, bwd 63 -> 71 us)
     static constexpr int NW = NKP >= 9 ? 8 : 4;
     static constexpr int OCC = 4;                            // NW = 8: two workgroups per CU; NW = 4: four
     static constexpr int PB = NKP >= 9 ? 3 : NKP;
