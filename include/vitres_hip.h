@@ -96,11 +96,21 @@ typedef struct vr_gemm_args {
     int32_t sched;       /* scheduling hints (bit mask, 0 = default): 1 = launched beside another kernel on a second stream (general
                             kernel: 128x128 tile, one workgroup per tile instead of persistent workgroups); 2 = keep the hardware's
                             round-robin workgroup -> XCD order (default: tiles remapped so that an XCD owns a contiguous run);
-                            4 = always use the general kernel (gemm.hip) -- measurement aid */
+                            4 = always use the general kernel (gemm.hip) -- measurement aid; 8 = 8-wave stream-K kernel (gemm_ntw.hip) wherever it
+                            is admissible; 16 = never */
     vr_rowmap a_map;     /* remap of A's token rows (M index if a_trans==0, K index if a_trans==1) */
     vr_rowmap b_map;     /* remap of B's token rows (only meaningful when b_trans==1 && a_trans==1) */
     vr_rowmap c_map;     /* remap of output rows */
+    void* ws;            /* optional workspace of the stream-K forward / data-gradient kernel (gemm_ntw.hip): output tiles that do
+                            not fill a round of the chip are shared slice-wise between workgroups, which exchange fp32 partial
+                            accumulators through it.  >= vr_gemm_ws_bytes() bytes, 16-byte aligned, ZERO before its first use (the
+                            kernels leave its tickets at zero), never shared by launches that may run concurrently (one per
+                            stream).  NULL: every tile is computed by one workgroup. */
+    int64_t ws_bytes;
 } vr_gemm_args;
+
+/* bytes of vr_gemm_args.ws that enable tile sharing on the current device */
+int vr_gemm_ws_bytes(void);
 
 int vr_gemm(const vr_gemm_args* args, vr_stream_t stream);
 

@@ -70,6 +70,76 @@ def test_gemm_forward_epilogues(dtype, M, N, K_):
             assert relerr(kw_d["out2"], ref2) < tol(dtype)
 
 
+def _wide_case(M, N, K_, variant, rows_in, seed=0):
+    """Operands of one forward / data-gradient GEMM form of the transformer blocks (bf16) with prefix masks on both sides."""
+    Bn = M // rows_in
+    g = torch.Generator().manual_seed(100 + seed)
+    bt = variant in ("dgrad", "dmul")
+    a = rnd(M, K_, seed=seed + 1).to(torch.bfloat16)
+    keep_k = torch.randint(K_ // 3, K_ + 1, (Bn,), generator=g).int()
+    keep_k[: Bn // 2] = K_                                                  # (two architecture groups: one dense, one pruned)
+    keep_k[Bn // 2:] = int(keep_k[Bn // 2])
+    a = a * (torch.arange(K_)[None, :] < keep_k.long().repeat_interleave(rows_in)[:, None])      # the contract of keep_k
+    b = rnd(K_, N, seed=seed + 2, scale=K_ ** -0.5).to(torch.bfloat16) if bt else rnd(N, K_, seed=seed + 2, scale=K_ ** -0.5).to(torch.bfloat16)
+    keep_n = torch.randint(N // 4, N + 1, (Bn,), generator=g).int()
+    keep_n[: Bn // 2] = N
+    kw = dict(M=M, N=N, K=K_, lda=K_, ldb=N if bt else K_, ldc=N, b_trans=bt, rows_in=rows_in, keep_n=keep_n, keep_k=keep_k)
+    out_dtype = torch.bfloat16
+    if variant == "fwd":
+        kw.update(bias=rnd(N, seed=seed + 3))
+    elif variant == "gelu":
+        kw.update(bias=rnd(N, seed=seed + 3), act=2, out2=torch.zeros(M, N, dtype=torch.bfloat16))
+    elif variant == "res":
+        out_dtype = torch.float32
+        kw.update(bias=rnd(N, seed=seed + 3), resid=rnd(M, N, seed=seed + 4), scale=torch.rand(Bn, generator=g) + 0.5)
+    elif variant == "dmul":
+        kw.update(dact_u=rnd(M, N, seed=seed + 5).to(torch.bfloat16), ldu=N, act=2)
+    return a, b, torch.zeros(M, N, dtype=out_dtype), kw
+
+
+@pytest.mark.parametrize("M,N,K_,rows_in", [(2176, 1024, 3072, 17), (8320, 512, 1536, 65), (1300, 320, 640, 65), (2176, 768, 1024, 17),
+                                            (4 * 257, 1536, 512, 257), (33 * 256, 256, 768, 256)])
+@pytest.mark.parametrize("variant", ["fwd", "gelu", "res", "dgrad", "dmul"])
+def test_gemm_wide_streamk(M, N, K_, rows_in, variant):
+    """8-wave ring-pipelined kernel with tiles shared slice-wise between workgroups (gemm_ntw.hip, sched bit 8) against the
+    emulation: fp32 outputs to 1e-4 (bf16-rounded inputs, fp32 accumulation: only the summation order differs), bf16 outputs
+    to bf16 rounding; and against the 4-wave kernels (bit 16) launch after launch -- the tickets must come back to zero."""
+    a, b, out, kw = _wide_case(M, N, K_, variant, rows_in)
+    ref = E.gemm(a, b, out.clone(), **{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+    kw_d = {k: to(v) for k, v in kw.items()}
+    ad, bd = a.to(DEV), b.to(DEV)
+    t_ = 1e-4 if out.dtype == torch.float32 else 5e-3
+    for rep in range(3):
+        real = K.gemm(ad, bd, torch.full_like(out, float("nan")).to(DEV), sched=8, **kw_d)
+        torch.cuda.synchronize()
+        assert relerr(real, ref) < t_, (variant, rep, relerr(real, ref))
+    if variant == "gelu":
+        ref2 = torch.zeros(M, N, dtype=torch.bfloat16)
+        kw2 = dict(kw); kw2["out2"] = ref2
+        E.gemm(a, b, out.clone(), **kw2)
+        assert relerr(kw_d["out2"], ref2) < t_
+    narrow = K.gemm(ad, bd, torch.zeros_like(out).to(DEV), sched=16, **kw_d)
+    assert relerr(narrow, ref) < t_
+    # uneven load: another stream keeps some CUs busy while a burst of wide launches runs back to back on fresh operands
+    side = torch.cuda.Stream()
+    busy = torch.randn(4096, 4096, device=DEV)
+    outs = []
+    with torch.cuda.stream(side):
+        for _ in range(4):
+            busy = torch.tanh(busy @ busy * 1e-2)
+    for rep in range(6):
+        a2 = (ad.float() * (1.0 + 0.25 * rep)).to(torch.bfloat16)
+        o_w = K.gemm(a2, bd, torch.full_like(out, float("nan")).to(DEV), sched=8, **kw_d)
+        o_n = K.gemm(a2, bd, torch.zeros_like(out).to(DEV), sched=16, **kw_d)
+        outs.append((o_w, o_n))
+    torch.cuda.synchronize()
+    for o_w, o_n in outs:
+        assert relerr(o_w, o_n) < (2e-5 if out.dtype == torch.float32 else 5e-3), (variant, relerr(o_w, o_n))
+    ws = K._workspace(torch.device(DEV, torch.cuda.current_device()))
+    assert int(ws[: 4096 * 4].view(torch.int32).abs().sum()) == 0           # every ticket is back at zero
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_rowmaps_and_pos(dtype):
     B, P, C, Kd = 3, 16, 64, 592

@@ -26,6 +26,7 @@
 
 bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);   // gemm_nt.hip
 bool vr_gemm_tn_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);   // gemm_tn.hip
+size_t vr_gemm_ntw_ws_bytes(int n_cu);                                          // gemm_ntw.hip
 bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t stream, int n_cu);
 
 namespace {
@@ -788,8 +789,11 @@ static int gemm_validate(vr_gemm_args& a) {
         (a.dact_u && ((uintptr_t)a.dact_u & 15)))
         return VR_EALIGN;
     if (a.in_dtype == VR_F32 && a.out_dtype == VR_BF16) return VR_EUNSUPPORTED;
+    if (a.ws && (((uintptr_t)a.ws & 15) || a.ws_bytes < 0)) return VR_EALIGN;
     return VR_OK;
 }
+
+extern "C" int vr_gemm_ws_bytes(void) { return (int)vr_gemm_ntw_ws_bytes(cu_count()); }
 
 extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
     if (!args) return VR_EINVAL;

@@ -1,0 +1,393 @@
+// bf16 forward / data-gradient GEMM, wide form:  C[M,N] = epilogue(A[M,K] * B[N,K]^T)   (or B = W [K][N] k-major, b_trans)
+//
+// The Linears of the second and third ViT-Res stages (reference nets/supernet_blocks.py:37-52,102-119 at 65 / 17 tokens per
+// sample: M = 8320 / 2176 rows, K and N = 512 ... 3072).  gemm_nt.hip covers them with 128 x 128 (or 64 x 128) tiles, one slice
+// in flight per workgroup and several workgroups per CU: 130 - 540 tiles on 256 CUs, each walking its 16 - 48 K slices serially
+// at ~1 us per slice, 64 flop per byte moved into LDS (exactly the CU's load-path balance): 350 - 400 TFLOP/s, bound by neither
+// roof.  This kernel changes the three things that bound them:
+//
+//   * 256 x 128 tile per 512-thread workgroup (8 waves as 4 x 2, each 64 x 64 = 4 x 4 v_mfma_f32_16x16x32_bf16): 85 flop per
+//     byte of LDS fill, one workgroup per CU;
+//   * a ring of three 48 KB slice buffers filled by LDS-DMA, two slices in flight behind the one being multiplied, ONE raw
+//     s_barrier and one counted s_waitcnt vmcnt per slice (all LDS is one array: a second __shared__ object makes hipcc drain
+//     the DMA queue in front of every fragment read);
+//   * stream-K: the (tile, slice) space of the tiles that do not fill a whole round of the chip is cut into equal contiguous
+//     shares, one per workgroup, so that 132 tiles x 24 slices become 256 shares of 12.4 slices instead of 132 busy and 124
+//     idle CUs.  A tile cut between workgroups is summed by the LAST of them to arrive: every contributor writes its fp32
+//     accumulators (register layout, 16 B per lane: no transposition) write-through to its own slab, drains, takes a ticket;
+//     the holder of the last ticket acquires, adds the other slabs to its registers and runs the epilogue.  Nobody waits for
+//     anybody, so the scheme needs no co-residency and no dispatch order; tickets are left at zero for the next launch.
+//
+// Per-wave MFMA code, LDS images (XOR-swizzled 128-B rows; k-major weight slice + ds_read_b64_tr_b16 for b_trans) and the
+// epilogue are those of gemm_nt.hip (gemm_nt_parts.h).
+#include <cstdlib>
+
+#include "gemm_nt_parts.h"
+
+namespace vr_gemm_nt {
+
+constexpr int WTHR = 512;
+constexpr int W_BM = 256, W_BN = 128;
+constexpr int SLAB_FLOATS = W_BM * W_BN;            // one workgroup's accumulators: 128 KB
+
+__device__ const uint4 zero_chunk_w[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+
+struct NtwPlan {
+    int tiles_m, tiles_n, ns;      // output tiles; K slices of a tile
+    int sk_tiles;                  // tiles [0, sk_tiles) are shared slice-wise; the others go round-robin, whole
+    int grid;                      // workgroups
+    float* slabs;                  // [grid][2][SLAB_FLOATS] partial accumulators
+    int* tickets;                  // [sk_tiles], zero on entry and on exit
+};
+
+__device__ __forceinline__ void store_wt(float* p, const f32x4 v) {        // write-through (sc1) 16-byte store
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <typename TO, int EPI, int FEAT, bool BKM>
+__global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, const NtwPlan pl) {
+    constexpr int MI = 4, NJ = 4, BM = W_BM, BN = W_BN, WROWS = 64, WCOLS = 64;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, AP = 4, BP = 2;      // LDS-DMA pieces (1 KB) per wave and slice
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES, STAGES = 3;
+    constexpr int META_OFF = STAGES * STAGE_BYTES, FLAG_OFF = META_OFF + BM * (int)sizeof(RowMeta);
+    __shared__ __attribute__((aligned(1024))) char smem[FLAG_OFF + 16];   // ring | row metadata | ticket broadcast
+    RowMeta* rowmeta = reinterpret_cast<RowMeta*>(smem + META_OFF);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int G = pl.grid, ns = pl.ns;
+    // workgroup ids are dealt round-robin to the 8 XCDs: an XCD owns a contiguous run of shares (n-fastest tile order: its L2
+    // fetches an A panel once)
+    int w = blockIdx.x;
+    if (G >= 16) {
+        const int xq = G >> 3, xr = G & 7, x = w & 7;
+        w = x * xq + min(x, xr) + (w >> 3);
+    }
+    const long long U = (long long)pl.sk_tiles * ns;          // slice units of the shared tiles
+    const int lo = (int)(U * w / G), hi = (int)(U * (w + 1) / G);
+    const int tiles = pl.tiles_m * pl.tiles_n;
+    const RowMap amap = {p.a_map.rpi, p.a_map.rps, p.a_map.off};
+    const RowMap bmap = {p.b_map.rpi, p.b_map.rps, p.b_map.off};
+    const char* zero = reinterpret_cast<const char*>(zero_chunk_w);
+
+    // fragment read offsets (gemm_nt.hip): lane -> row (lane & 15) of a 16-row group, k-chunk 4 s + (lane >> 4)
+    const int frow = lane & 15, fswz = (frow >> 1) & 7;
+    const int slot0 = ((lane >> 4) ^ fswz) << 4, slot1 = ((4 + (lane >> 4)) ^ fswz) << 4;
+    const int offA = (wm * WROWS + frow) * 128, offBn = A_BYTES + (wn * WCOLS + frow) * 128;
+    int offB[NJ];
+    if constexpr (BKM) {
+        typedef KMajor<BN> KG;
+        const int li = lane & 15, g4 = lane >> 4;
+        const int xr2 = KG::swz(8 * g4 + (li >> 2));
+        const int rowoff = (8 * g4 + (li >> 2)) * KG::ROWB + (li & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) offB[j] = A_BYTES + rowoff + ((((BN / 16) * wn + 2 * j + ((li & 3) >> 1)) ^ xr2) * 16);
+    }
+
+    int u = lo, dp_tile = pl.sk_tiles + w;
+    while (true) {
+        // ---- next segment: slices [kb, ke) of a tile ----
+        int tile, kb, ke;
+        bool first_seg = false;
+        if (u < hi) {
+            tile = u / ns;
+            kb = u - tile * ns;
+            ke = min(ns, kb + (hi - u));
+            first_seg = u == lo;
+            u += ke - kb;
+        } else if (dp_tile < tiles) {
+            tile = dp_tile;
+            kb = 0;
+            ke = ns;
+            dp_tile += G;
+        } else {
+            break;
+        }
+        const int tn = tile % pl.tiles_n, tm = tile / pl.tiles_n;
+        const int m0 = tm * BM, n0 = tn * BN;
+
+        // ---- masked-work skipping (rules of the general kernel; the keep arrays are read with scalar loads) ----
+        int kmax = 1 << 30;
+        bool n_any = true;
+        if (p.keep_k || p.keep_n) {
+            int s_lo = 0, s_hi = 0;
+            if (p.rows_in > 0) { s_lo = m0 / p.rows_in; s_hi = (min(m0 + BM, p.M) - 1) / p.rows_in; }
+            kmax = max_keep(p.keep_k, s_lo, s_hi, 1 << 30);
+            const int nmax = max_keep(p.keep_n, s_lo, s_hi, 1 << 30);
+            n_any = range_has_kept(n0, BN, p.n_period, nmax);
+        }
+        // live slices are walked with a cursor (slice nk, nr = (nk * BK) % k_period kept incrementally): the test of the general
+        // kernel (range_has_kept: a modulo per call) costs ~100 scalar instructions per slice between the barrier and the MFMAs
+        const bool masked = p.keep_k != nullptr;
+        const int period = p.k_period >= BK ? p.k_period : 0;        // periods below a slice: every slice holds kept columns
+        const bool prefix = masked && p.k_period <= 0;               // plain prefix: slices below kmax
+        int nk = (n_any && kmax > 0) ? kb : ke;
+        int nr = period > 0 ? (kb * BK) % period : kb * BK;
+        auto take = [&]() -> int {                                   // next live slice in [nk, ke) (ke: none); moves the cursor past it
+            while (nk < ke) {
+                const bool lv = !masked || (period > 0 ? (nr < kmax || nr + BK > period) : (!prefix || nr < kmax));
+                const int cur = nk;
+                ++nk;
+                nr += BK;
+                if (period > 0 && nr >= period) nr -= period;
+                if (lv) return cur;
+                if (prefix) { nk = ke; break; }                      // beyond a prefix nothing is kept
+            }
+            return ke;
+        };
+
+        // ---- LDS-DMA source addressing: piece h of this wave = 8 rows of 128 B, lane -> (row, 16-byte slot) ----
+        const char* gA[AP];
+        const char* gB[BP];
+        {
+            const int ra = wave * (8 * AP) + (lane >> 3);
+            if (amap.rpi == 0 && m0 + BM <= p.M) {
+                const char* a0 = reinterpret_cast<const char*>(p.A) + (long long)(m0 + ra) * p.lda * 2;
+                const long long step = (long long)p.lda * 16;
+#pragma unroll
+                for (int h = 0; h < AP; ++h) gA[h] = a0 + h * step + (((lane & 7) ^ (((ra + 8 * h) >> 1) & 7)) << 4);
+            } else {
+#pragma unroll
+                for (int h = 0; h < AP; ++h) {
+                    const int r = ra + h * 8;
+                    const int ma = min(m0 + r, p.M - 1);
+                    gA[h] = reinterpret_cast<const char*>(p.A) + map_row(amap, ma) * (long long)p.lda * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+                }
+            }
+        }
+        if constexpr (BKM) {
+            typedef KMajor<BN> KG;
+#pragma unroll
+            for (int h = 0; h < BP; ++h) {
+                const int tk = (wave * BP + h) * KG::TPP + lane / KG::SLOTS;
+                const int c = (lane % KG::SLOTS) ^ KG::swz(tk);
+                // column chunks past the row's readable width (ldb >= roundup(N, 8)) come from the zero page: their products only
+                // reach outputs that are not stored
+                const bool bok = n0 + c * 8 + 8 <= p.ldb;
+                gB[h] = bok ? reinterpret_cast<const char*>(p.B) + ((long long)tk * p.ldb + n0 + c * 8) * 2 : nullptr;
+            }
+        } else {
+            const int rb = wave * (8 * BP) + (lane >> 3);
+            if (bmap.rpi == 0 && n0 + BN <= p.N) {
+                const char* b0 = reinterpret_cast<const char*>(p.B) + (long long)(n0 + rb) * p.ldb * 2;
+                const long long step = (long long)p.ldb * 16;
+#pragma unroll
+                for (int h = 0; h < BP; ++h) gB[h] = b0 + h * step + (((lane & 7) ^ (((rb + 8 * h) >> 1) & 7)) << 4);
+            } else {
+#pragma unroll
+                for (int h = 0; h < BP; ++h) {
+                    const int r = rb + h * 8;
+                    const int nb = min(n0 + r, p.N - 1);
+                    gB[h] = reinterpret_cast<const char*>(p.B) + map_row(bmap, nb) * (long long)p.ldb * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+                }
+            }
+        }
+
+        f32x4 acc[MI][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        auto issue = [&](int kt, int buf) {
+            const long long kbytes = (long long)kt * (BK * 2);
+            char* dst = smem + buf * STAGE_BYTES;
+#pragma unroll
+            for (int h = 0; h < AP; ++h)
+                __builtin_amdgcn_global_load_lds((glb_void*)(gA[h] + kbytes), (lds_void*)(dst + (wave * (8 * AP) + h * 8) * 128), 16, 0, 0);
+#pragma unroll
+            for (int h = 0; h < BP; ++h) {
+                const char* sb;
+                if constexpr (BKM) sb = gB[h] ? gB[h] + (long long)kt * BK * p.ldb * 2 : zero;
+                else sb = gB[h] + kbytes;
+                __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(dst + A_BYTES + (wave * (8 * BP) + h * 8) * 128), 16, 0, 0);
+            }
+        };
+        auto compute = [&](int buf) {
+            const char* sb_ = smem + buf * STAGE_BYTES;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int so = s == 0 ? slot0 : slot1;
+                bfv8 a[MI], b[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bfv8*>(sb_ + offA + i * 2048 + so);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if constexpr (BKM) b[j] = tr_frag<KMajor<BN>::ROWB>(sb_ + offB[j] + s * 32 * KMajor<BN>::ROWB);
+                    else b[j] = *reinterpret_cast<const bfv8*>(sb_ + offBn + j * 2048 + so);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+        };
+
+        // ---- K loop: ring of three slice buffers, two slices in flight behind the one being multiplied ----
+        int c0 = take();
+        int c1 = take();
+        if (c0 < ke) issue(c0, 0);
+        if (c1 < ke) issue(c1, 1);
+        if (t < BM) {          // per-row epilogue metadata (its loads drain behind the first two slices)
+            const int m = m0 + t;
+            RowMeta rm;
+            rm.keep = 1 << 30; rm.scale = 1.0f; rm.orow = -1; rm.mloc = 0;
+            if (m < p.M) {
+                const int sample = p.rows_in > 0 ? m / p.rows_in : 0;
+                rm.mloc = p.rows_in > 0 ? m - sample * p.rows_in : m;
+                rm.orow = (int)map_row({p.c_map.rpi, p.c_map.rps, p.c_map.off}, m);
+                if (p.scale) rm.scale = p.scale[sample];
+                if (p.keep_n) rm.keep = p.keep_n[sample];
+            }
+            rowmeta[t] = rm;
+        }
+        while (c0 < ke) {
+#pragma unroll
+            for (int b = 0; b < STAGES; ++b) {
+                if (c0 >= ke) break;
+                // slice c0 has landed when at most the pieces of the younger slice c1 are outstanding
+                if (c1 < ke) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();         // ... for every wave, and every wave is done with the buffer re-filled next
+                const int c2 = take();
+                if (c2 < ke) issue(c2, (b + 2) % STAGES);
+                compute(b);
+                c0 = c1;
+                c1 = c2;
+            }
+            // (a segment whose live-slice count is not a multiple of three ends inside the ring: the next segment starts at
+            // buffer 0 again behind the workgroup barrier below)
+        }
+        __syncthreads();
+
+        // ---- a tile cut between workgroups: the last contributor to arrive sums the partial accumulators ----
+        bool finish = kb == 0 && ke == ns;
+        if (!finish) {
+            const long long u0 = (long long)tile * ns;
+            const int w_first = (int)(((u0 + 1) * G - 1) / U), w_last = (int)(((u0 + ns) * G - 1) / U);
+            float* mine = pl.slabs + ((size_t)w * 2 + (first_seg ? 0 : 1)) * SLAB_FLOATS + t * 4;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) store_wt(mine + (i * NJ + j) * (WTHR * 4), acc[i][j]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(smem + FLAG_OFF);
+            if (t == 0) *flag = __hip_atomic_fetch_add(pl.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int ticket = *flag;
+            if (ticket == w_last - w_first) {
+                if (t == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    __hip_atomic_store(pl.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                for (int wc = w_first; wc <= w_last; ++wc) {
+                    if (wc == w) continue;
+                    const int lo_c = (int)(U * wc / G);
+                    const float* src = pl.slabs + ((size_t)wc * 2 + (lo_c / ns == tile ? 0 : 1)) * SLAB_FLOATS + t * 4;
+                    f32x4 part[MI * NJ];
+#pragma unroll
+                    for (int r = 0; r < MI * NJ; ++r) part[r] = *reinterpret_cast<const f32x4*>(src + r * (WTHR * 4));
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[i][j] += part[i * NJ + j];
+                }
+                finish = true;
+            }
+        }
+        if (finish)
+            epilogue<TO, EPI, true, MI, NJ, FEAT>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wm * WROWS, n0 + wn * WCOLS, lane);
+        __syncthreads();
+    }
+}
+
+template <typename TO, int EPI, int FEAT, bool BKM = false> void wlaunch(const vr_gemm_args& a, const NtwPlan& pl, hipStream_t stream) {
+    hipLaunchKernelGGL((ntw_kernel<TO, EPI, FEAT, BKM>), dim3((unsigned)pl.grid), dim3(WTHR), 0, stream, a, pl);
+}
+
+}  // namespace vr_gemm_nt
+
+// bytes of workspace the wide kernel wants for a chip of n_cu CUs (tickets + two slabs per workgroup)
+size_t vr_gemm_ntw_ws_bytes(int n_cu) {
+    return (size_t)4096 * 4 + (size_t)n_cu * 2 * vr_gemm_nt::SLAB_FLOATS * sizeof(float);
+}
+
+// Called by vr_gemm_nt_launch for forms both kernels cover.  mode: 1 = use the wide kernel where the cost model prefers it,
+// 2 = wherever it is admissible.  Returns false when the 4-wave kernels should run.
+bool vr_gemm_ntw_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu, int mode) {
+    using namespace vr_gemm_nt;
+    if (a.in_dtype != VR_BF16 || a.a_trans || a.atomic || a.split_k > 1 || a.bias_grad || a.pos || a.K % BK || a.K < 2 * BK) return false;
+    const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);
+    if (!fast) return false;
+    const bool of32 = a.out_dtype == VR_F32;
+    int feat = -1;
+    if (!a.bias && !a.resid && !a.scale) feat = 0;
+    else if (a.bias && !a.resid && !a.scale) feat = 1;
+    else if (a.bias && a.resid && !a.scale) feat = 2;
+    else if (a.bias && a.resid && a.scale) feat = 3;
+    if (feat < 0) return false;
+    const bool gelu = a.act == 1 || a.act == 3 || (a.act == 2 && !a.dact_u);
+    if (gelu && (of32 || feat > 1)) return false;
+    if (a.dact_u && (of32 || feat != 0)) return false;
+    if (a.b_trans && (of32 || feat != 0 || gelu)) return false;      // (vr_gemm_nt_launch admitted the k-major form already)
+
+    NtwPlan pl;
+    pl.tiles_m = (a.M + W_BM - 1) / W_BM;
+    pl.tiles_n = (a.N + W_BN - 1) / W_BN;
+    pl.ns = a.K / BK;
+    const long long tiles = (long long)pl.tiles_m * pl.tiles_n;
+    const int G = n_cu;
+    static const int knob_fix = std::getenv("VITRES_NTW_FIX") ? std::atoi(std::getenv("VITRES_NTW_FIX")) : 8;   // a cut tile ~ this many slices
+    static const int knob_sk = std::getenv("VITRES_NTW_SK") ? std::atoi(std::getenv("VITRES_NTW_SK")) : 1;      // 0: never share tiles
+    const size_t need = vr_gemm_ntw_ws_bytes(G);
+    const bool can_sk = knob_sk && a.ws && (size_t)a.ws_bytes >= need && tiles + G <= 4096;
+    const long long rounds = tiles / G, rem = tiles % G;
+    const long long dp_cost = (rounds + (rem ? 1 : 0)) * pl.ns;
+    long long sk_tiles = 0, cost = dp_cost;
+    if (can_sk && rem) {
+        const long long skt = rounds ? rem + G : rem;               // two-tile form: every share holds at least one whole tile
+        const long long sk_cost = (rounds ? rounds - 1 : 0) * pl.ns + (skt * pl.ns + G - 1) / G + knob_fix;
+        if (sk_cost < dp_cost || knob_sk == 2) { sk_tiles = skt; cost = sk_cost; }
+    }
+    if (mode == 1) {
+        // the 4-wave kernels keep the short-K, many-tile GEMMs (first stage: HBM-bound, four workgroups per CU hide the latency)
+        if (pl.ns < 8 || cost * G > 2 * tiles * pl.ns) return false;
+    }
+    pl.sk_tiles = (int)sk_tiles;
+    pl.grid = (int)(sk_tiles ? G : (tiles < G ? tiles : G));
+    pl.tickets = reinterpret_cast<int*>(a.ws);
+    pl.slabs = a.ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(a.ws) + 4096 * 4) : nullptr;
+
+    if (a.b_trans) {
+        if (a.dact_u) {
+            if (a.act == 2) wlaunch<bf16_t, EPI_DMUL, 0, true>(a, pl, stream);
+            else wlaunch<bf16_t, EPI_DGELU, 0, true>(a, pl, stream);
+        } else {
+            wlaunch<bf16_t, EPI_STORE, 0, true>(a, pl, stream);
+        }
+    } else if (gelu) {
+        if (feat == 1) wlaunch<bf16_t, EPI_GELU, 1>(a, pl, stream);
+        else wlaunch<bf16_t, EPI_GELU, 0>(a, pl, stream);
+    } else if (a.dact_u) {
+        if (a.act == 2) wlaunch<bf16_t, EPI_DMUL, 0>(a, pl, stream);
+        else wlaunch<bf16_t, EPI_DGELU, 0>(a, pl, stream);
+    } else if (of32) {
+        switch (feat) {
+            case 0: wlaunch<float, EPI_STORE, 0>(a, pl, stream); break;
+            case 1: wlaunch<float, EPI_STORE, 1>(a, pl, stream); break;
+            case 2: wlaunch<float, EPI_STORE, 2>(a, pl, stream); break;
+            default: wlaunch<float, EPI_STORE, 3>(a, pl, stream); break;
+        }
+    } else {
+        switch (feat) {
+            case 0: wlaunch<bf16_t, EPI_STORE, 0>(a, pl, stream); break;
+            case 1: wlaunch<bf16_t, EPI_STORE, 1>(a, pl, stream); break;
+            case 2: wlaunch<bf16_t, EPI_STORE, 2>(a, pl, stream); break;
+            default: wlaunch<bf16_t, EPI_STORE, 3>(a, pl, stream); break;
+        }
+    }
+    return true;
+}

@@ -30,6 +30,7 @@ class GemmArgs(ctypes.Structure):
         ("in_dtype", c_int32), ("out_dtype", c_int32),
         ("act", c_int32), ("atomic", c_int32), ("split_k", c_int32), ("rows_in", c_int32), ("n_period", c_int32), ("k_period", c_int32), ("sched", c_int32),
         ("a_map", RowMap), ("b_map", RowMap), ("c_map", RowMap),
+        ("ws", c_void_p), ("ws_bytes", c_int64),
     ]
 
 
@@ -51,6 +52,7 @@ SYMBOLS = {
     "vr_gemm_group": [ctypes.POINTER(GemmArgs), ctypes.c_int32, c_void_p],
     "vr_gemm_ln": [ctypes.POINTER(GemmArgs), ctypes.POINTER(LnEpilogue), c_void_p],
     "vr_gemm_ln_supported": [c_int32],
+    "vr_gemm_ws_bytes": [],
     "vr_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "vr_adamw_flat": [c_void_p] * 6 + [c_float, c_void_p, c_void_p, c_int32, c_int64, c_void_p],
     "vr_adamw_flat_dev": [c_void_p] * 6 + [c_float, c_void_p, c_void_p, c_int32, c_int64, c_void_p],

@@ -47,10 +47,48 @@ def _rm(m):
     return RowMap(*(m or IDENT))
 
 
+# Workspaces of the stream-K GEMM (vr_gemm_args.ws): one per (device, role).  A role is a chain of launches that never overlap
+# one another: 0 = the main stream, 1.. = the side streams of vitres.functional (which switches the role around what it runs
+# there).  Created zeroed on first use -- outside graph capture (engine.GraphedTrainStep calls ensure_workspaces first): a launch
+# that finds none while capturing simply runs without tile sharing.
+_WS = {}
+_WS_ROLE = [0]
+
+
+class ws_role:
+    def __init__(self, role):
+        self.role = role
+
+    def __enter__(self):
+        self.prev, _WS_ROLE[0] = _WS_ROLE[0], self.role
+
+    def __exit__(self, *exc):
+        _WS_ROLE[0] = self.prev
+
+
+def _workspace(dev, role=None):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _WS_ROLE[0] if role is None else role)
+    ws = _WS.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        ws = _WS[key] = torch.zeros(int(_lib.lib().vr_gemm_ws_bytes()), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def ensure_workspaces(dev, roles=(0, 1)):
+    for r in roles:
+        _workspace(torch.device(dev), r)
+
+
 def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
                scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
-               a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0):
+               a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0, ws="auto"):
     args = GemmArgs()
+    if isinstance(ws, str):
+        ws = _workspace(a.device) if (not a_trans and a.dtype == torch.bfloat16 and a.is_cuda and M >= 256 and K >= 512) else None
+    if ws is not None:
+        args.ws, args.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
     args.A, args.B, args.C, args.C2 = _p(a), _p(b), _p(out), _p(out2)
     args.bias, args.pos, args.scale, args.keep_n = _p(bias), _p(pos), _p(scale), _p(keep_n)
     args.resid, args.dact_u, args.bias_grad, args.keep_k = _p(resid), _p(dact_u), _p(bias_grad), _p(keep_k)
@@ -134,12 +172,13 @@ def gemm_ln_bwd(du, wt, x, ln_w, mean, rstd, ln_keep, dx_in, dw, db, next_cast=N
 
 def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
          scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
-         a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0):
-    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T) -- see vr_gemm in include/vitres_hip.h."""
+         a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0, ws="auto"):
+    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T) -- see vr_gemm in include/vitres_hip.h.  ws: stream-K workspace (a uint8 tensor),
+    None, or "auto" = the current role's (see _workspace)."""
     args = _gemm_args(a, b, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, a_trans=a_trans, b_trans=b_trans, out2=out2,
                       bias=bias, pos=pos, scale=scale, keep_n=keep_n, resid=resid, dact_u=dact_u, ldu=ldu, act=act,
                       atomic=atomic, split_k=split_k, rows_in=rows_in, a_map=a_map, b_map=b_map, c_map=c_map,
-                      bias_grad=bias_grad, keep_k=keep_k, n_period=n_period, k_period=k_period, sched=sched)
+                      bias_grad=bias_grad, keep_k=keep_k, n_period=n_period, k_period=k_period, sched=sched, ws=ws)
     if PROFILE is None:
         _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
         return out
