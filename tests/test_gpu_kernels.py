@@ -98,9 +98,11 @@ def _wide_case(M, N, K_, variant, rows_in, seed=0):
 
 
 @pytest.mark.parametrize("M,N,K_,rows_in", [(2176, 1024, 3072, 17), (8320, 512, 1536, 65), (1300, 320, 640, 65), (2176, 768, 1024, 17),
-                                            (4 * 257, 1536, 512, 257), (33 * 256, 256, 768, 256)])
+                                            (4 * 257, 1536, 512, 257), (33 * 256, 256, 768, 256), (32896, 1024, 256, 257)])
 @pytest.mark.parametrize("variant", ["fwd", "gelu", "res", "dgrad", "dmul"])
 def test_gemm_wide_streamk(M, N, K_, rows_in, variant):
+    if M > 30000 and variant not in ("fwd", "res"):
+        pytest.skip("the 516-tile case (whole rounds + shared tiles in one launch) runs two forms")
     """8-wave ring-pipelined kernel with tiles shared slice-wise between workgroups (gemm_ntw.hip, sched bit 8) against the
     emulation: fp32 outputs to 1e-4 (bf16-rounded inputs, fp32 accumulation: only the summation order differs), bf16 outputs
     to bf16 rounding; and against the 4-wave kernels (bit 16) launch after launch -- the tickets must come back to zero."""

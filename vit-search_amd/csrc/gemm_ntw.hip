@@ -2,24 +2,27 @@
 //
 // The Linears of the second and third ViT-Res stages (reference nets/supernet_blocks.py:37-52,102-119 at 65 / 17 tokens per
 // sample: M = 8320 / 2176 rows, K and N = 512 ... 3072).  gemm_nt.hip covers them with 128 x 128 (or 64 x 128) tiles, one slice
-// in flight per workgroup and several workgroups per CU: 130 - 540 tiles on 256 CUs, each walking its 16 - 48 K slices serially
-// at ~1 us per slice, 64 flop per byte moved into LDS (exactly the CU's load-path balance): 350 - 400 TFLOP/s, bound by neither
-// roof.  This kernel changes the three things that bound them:
+// in flight per workgroup and several un-synchronised workgroups per CU.  Two things bound that form below either roof:
+// a 64 x 64 wave tile reads 0.5 KB of LDS per MFMA (the LDS pipe is as busy as the matrix pipe would be at its peak), and a
+// 128 x 128 tile moves 1 byte into LDS per 64 flop -- exactly the balance of a CU's load path.  This kernel:
 //
-//   * 256 x 128 tile per 512-thread workgroup (8 waves as 4 x 2, each 64 x 64 = 4 x 4 v_mfma_f32_16x16x32_bf16): 85 flop per
-//     byte of LDS fill, one workgroup per CU;
-//   * a ring of three 48 KB slice buffers filled by LDS-DMA, two slices in flight behind the one being multiplied, ONE raw
-//     s_barrier and one counted s_waitcnt vmcnt per slice (all LDS is one array: a second __shared__ object makes hipcc drain
-//     the DMA queue in front of every fragment read);
-//   * stream-K: the (tile, slice) space of the tiles that do not fill a whole round of the chip is cut into equal contiguous
-//     shares, one per workgroup, so that 132 tiles x 24 slices become 256 shares of 12.4 slices instead of 132 busy and 124
-//     idle CUs.  A tile cut between workgroups is summed by the LAST of them to arrive: every contributor writes its fp32
-//     accumulators (register layout, 16 B per lane: no transposition) write-through to its own slab, drains, takes a ticket;
-//     the holder of the last ticket acquires, adds the other slabs to its registers and runs the epilogue.  Nobody waits for
-//     anybody, so the scheme needs no co-residency and no dispatch order; tickets are left at zero for the next launch.
+//   * 256 x 256 tile per 512-thread workgroup, 8 waves as 2 (M) x 4 (N), each 128 x 64 = 8 x 4 v_mfma_f32_16x16x32_bf16
+//     (0.375 KB of LDS reads per MFMA, 128 flop per byte of LDS fill), 128 accumulator registers, one workgroup per CU;
+//   * the two wave rows are the two halves of a ping-pong: a K slice (64) is four phases per wave, each {fragment reads of one
+//     64 x 32 quadrant + two LDS-DMA pieces} | s_barrier | {16 MFMAs} | s_barrier, and the second wave row runs one barrier
+//     behind the first, so that on every SIMD one wave multiplies while its partner reads and stages;
+//   * two 64 KB slice buffers of four 16 KB half-tiles (A rows 0-127 / 128-255, B columns 0-127 / 128-255); every phase stages
+//     one half-tile of a later slice (8 waves x 2 pieces), three half-tiles stay in flight across the barriers and ONE counted
+//     s_waitcnt vmcnt per slice retires them (all LDS is one array: a second __shared__ object makes hipcc drain the DMA queue in
+//     front of every fragment read);
+//   * stream-K (optional, vr_gemm_args.ws): tiles that do not fill a round of the chip are cut into equal contiguous shares of
+//     (tile, slice) units, one per workgroup.  A tile cut between workgroups is summed by the LAST of them to arrive: every
+//     contributor writes its fp32 accumulators (register layout, 16 B per lane: no transposition) write-through to its own
+//     slab, drains, takes a ticket; the holder of the last ticket acquires, adds the other slabs to its registers and runs the
+//     epilogue.  Nobody waits for anybody: no co-residency or dispatch order is assumed; tickets return to zero.
 //
-// Per-wave MFMA code, LDS images (XOR-swizzled 128-B rows; k-major weight slice + ds_read_b64_tr_b16 for b_trans) and the
-// epilogue are those of gemm_nt.hip (gemm_nt_parts.h).
+// LDS images (XOR-swizzled 128-B rows; k-major weight half + ds_read_b64_tr_b16 for b_trans) and the epilogue are those of
+// gemm_nt.hip (gemm_nt_parts.h).
 #include <cstdlib>
 
 #include "gemm_nt_parts.h"
@@ -27,8 +30,9 @@
 namespace vr_gemm_nt {
 
 constexpr int WTHR = 512;
-constexpr int W_BM = 256, W_BN = 128;
-constexpr int SLAB_FLOATS = W_BM * W_BN;            // one workgroup's accumulators: 128 KB
+constexpr int W_BM = 256, W_BN = 256;
+constexpr int SLAB_FLOATS = W_BM * W_BN;            // one workgroup's accumulators: 256 KB
+constexpr int TICKET_BYTES = 4096 * 4;
 
 __device__ const uint4 zero_chunk_w[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 
@@ -46,15 +50,15 @@ __device__ __forceinline__ void store_wt(float* p, const f32x4 v) {        // wr
 
 template <typename TO, int EPI, int FEAT, bool BKM>
 __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, const NtwPlan pl) {
-    constexpr int MI = 4, NJ = 4, BM = W_BM, BN = W_BN, WROWS = 64, WCOLS = 64;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, AP = 4, BP = 2;      // LDS-DMA pieces (1 KB) per wave and slice
-    constexpr int STAGE_BYTES = A_BYTES + B_BYTES, STAGES = 3;
-    constexpr int META_OFF = STAGES * STAGE_BYTES, FLAG_OFF = META_OFF + BM * (int)sizeof(RowMeta);
-    __shared__ __attribute__((aligned(1024))) char smem[FLAG_OFF + 16];   // ring | row metadata | ticket broadcast
+    constexpr int MI = 8, NJ = 4, BM = W_BM, BN = W_BN, WROWS = 128, WCOLS = 64;
+    constexpr int HALF = 128 * BK * 2;                  // a half-tile: 128 rows (or k-major: 64 k x 128 columns) = 16 KB = 16 pieces
+    constexpr int STAGE_BYTES = 4 * HALF;               // [A rows 0-127][A rows 128-255][B columns 0-127][B columns 128-255]
+    constexpr int META_OFF = 2 * STAGE_BYTES, FLAG_OFF = META_OFF + BM * (int)sizeof(RowMeta);
+    __shared__ __attribute__((aligned(1024))) char smem[FLAG_OFF + 16];   // two slice buffers | row metadata | ticket broadcast
     RowMeta* rowmeta = reinterpret_cast<RowMeta*>(smem + META_OFF);
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wr = wave >> 2, wc = wave & 3;            // wave row = ping-pong half (waves w and w + 4 share a SIMD), wave column
     const int G = pl.grid, ns = pl.ns;
     // workgroup ids are dealt round-robin to the 8 XCDs: an XCD owns a contiguous run of shares (n-fastest tile order: its L2
     // fetches an A panel once)
@@ -70,18 +74,19 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
     const RowMap bmap = {p.b_map.rpi, p.b_map.rps, p.b_map.off};
     const char* zero = reinterpret_cast<const char*>(zero_chunk_w);
 
-    // fragment read offsets (gemm_nt.hip): lane -> row (lane & 15) of a 16-row group, k-chunk 4 s + (lane >> 4)
+    // ---- fragment read offsets inside a slice buffer: lane -> row (lane & 15) of a 16-row group, k-chunk 4 s + (lane >> 4) ----
     const int frow = lane & 15, fswz = (frow >> 1) & 7;
     const int slot0 = ((lane >> 4) ^ fswz) << 4, slot1 = ((4 + (lane >> 4)) ^ fswz) << 4;
-    const int offA = (wm * WROWS + frow) * 128, offBn = A_BYTES + (wn * WCOLS + frow) * 128;
-    int offB[NJ];
+    const int offA = wr * HALF + frow * 128;                                            // + (sub * 64 + i * 16) * 128 + slot
+    const int offBn = (2 + (wc >> 1)) * HALF + ((wc & 1) * 64 + frow) * 128;            // + (sub * 32 + j * 16) * 128 + slot
+    int offB[NJ];                                                                       // k-major weight half: + s * 32 * ROWB
     if constexpr (BKM) {
-        typedef KMajor<BN> KG;
+        typedef KMajor<128> KG;
         const int li = lane & 15, g4 = lane >> 4;
         const int xr2 = KG::swz(8 * g4 + (li >> 2));
         const int rowoff = (8 * g4 + (li >> 2)) * KG::ROWB + (li & 1) * 8;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) offB[j] = A_BYTES + rowoff + ((((BN / 16) * wn + 2 * j + ((li & 3) >> 1)) ^ xr2) * 16);
+        for (int j = 0; j < NJ; ++j) offB[j] = (2 + (wc >> 1)) * HALF + rowoff + (((8 * (wc & 1) + 2 * j + ((li & 3) >> 1)) ^ xr2) * 16);
     }
 
     int u = lo, dp_tile = pl.sk_tiles + w;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
             n_any = range_has_kept(n0, BN, p.n_period, nmax);
         }
         // live slices are walked with a cursor (slice nk, nr = (nk * BK) % k_period kept incrementally): the test of the general
-        // kernel (range_has_kept: a modulo per call) costs ~100 scalar instructions per slice between the barrier and the MFMAs
+        // kernel (range_has_kept: a modulo per call) costs ~100 scalar instructions per slice
         const bool masked = p.keep_k != nullptr;
         const int period = p.k_period >= BK ? p.k_period : 0;        // periods below a slice: every slice holds kept columns
         const bool prefix = masked && p.k_period <= 0;               // plain prefix: slices below kmax
@@ -136,100 +141,113 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
             return ke;
         };
 
-        // ---- LDS-DMA source addressing: piece h of this wave = 8 rows of 128 B, lane -> (row, 16-byte slot) ----
-        const char* gA[AP];
-        const char* gB[BP];
-        {
-            const int ra = wave * (8 * AP) + (lane >> 3);
-            if (amap.rpi == 0 && m0 + BM <= p.M) {
-                const char* a0 = reinterpret_cast<const char*>(p.A) + (long long)(m0 + ra) * p.lda * 2;
-                const long long step = (long long)p.lda * 16;
+        // ---- LDS-DMA sources: half-tile x, piece h of this wave = its rows 16 wave + 8 h .. + 8; lane -> (row, 16-byte slot) ----
+        const char* gA[2][2];
+        const char* gB[2][2];
 #pragma unroll
-                for (int h = 0; h < AP; ++h) gA[h] = a0 + h * step + (((lane & 7) ^ (((ra + 8 * h) >> 1) & 7)) << 4);
-            } else {
+        for (int x = 0; x < 2; ++x)
 #pragma unroll
-                for (int h = 0; h < AP; ++h) {
-                    const int r = ra + h * 8;
-                    const int ma = min(m0 + r, p.M - 1);
-                    gA[h] = reinterpret_cast<const char*>(p.A) + map_row(amap, ma) * (long long)p.lda * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+            for (int h = 0; h < 2; ++h) {
+                const int r = 16 * wave + 8 * h + (lane >> 3);
+                const int ma = min(m0 + 128 * x + r, p.M - 1);
+                gA[x][h] = reinterpret_cast<const char*>(p.A) + map_row(amap, ma) * (long long)p.lda * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+                if constexpr (BKM) {
+                    typedef KMajor<128> KG;
+                    const int tk = (2 * wave + h) * KG::TPP + lane / KG::SLOTS;
+                    const int c = (lane % KG::SLOTS) ^ KG::swz(tk);
+                    // column chunks past the row's readable width (ldb >= roundup(N, 8)) come from the zero page: their products
+                    // only reach outputs that are not stored
+                    const bool bok = n0 + 128 * x + c * 8 + 8 <= p.ldb;
+                    gB[x][h] = bok ? reinterpret_cast<const char*>(p.B) + ((long long)tk * p.ldb + n0 + 128 * x + c * 8) * 2 : nullptr;
+                } else {
+                    const int nb = min(n0 + 128 * x + r, p.N - 1);
+                    gB[x][h] = reinterpret_cast<const char*>(p.B) + map_row(bmap, nb) * (long long)p.ldb * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
                 }
             }
-        }
-        if constexpr (BKM) {
-            typedef KMajor<BN> KG;
+        // stage one half-tile (X = 0, 1: A rows; 2, 3: B columns) of slice kt into slice buffer buf: two pieces per wave
+        auto stage = [&]<int X>(int kt, int buf) {
+            const long long kbytes = (long long)kt * (BK * 2);
+            char* dst = smem + buf * STAGE_BYTES + X * HALF + wave * 2048;
 #pragma unroll
-            for (int h = 0; h < BP; ++h) {
-                const int tk = (wave * BP + h) * KG::TPP + lane / KG::SLOTS;
-                const int c = (lane % KG::SLOTS) ^ KG::swz(tk);
-                // column chunks past the row's readable width (ldb >= roundup(N, 8)) come from the zero page: their products only
-                // reach outputs that are not stored
-                const bool bok = n0 + c * 8 + 8 <= p.ldb;
-                gB[h] = bok ? reinterpret_cast<const char*>(p.B) + ((long long)tk * p.ldb + n0 + c * 8) * 2 : nullptr;
+            for (int h = 0; h < 2; ++h) {
+                const char* src;
+                if constexpr (X < 2) src = gA[X][h] + kbytes;
+                else if constexpr (BKM) src = gB[X - 2][h] ? gB[X - 2][h] + (long long)kt * BK * p.ldb * 2 : zero;
+                else src = gB[X - 2][h] + kbytes;
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + h * 1024), 16, 0, 0);
             }
-        } else {
-            const int rb = wave * (8 * BP) + (lane >> 3);
-            if (bmap.rpi == 0 && n0 + BN <= p.N) {
-                const char* b0 = reinterpret_cast<const char*>(p.B) + (long long)(n0 + rb) * p.ldb * 2;
-                const long long step = (long long)p.ldb * 16;
-#pragma unroll
-                for (int h = 0; h < BP; ++h) gB[h] = b0 + h * step + (((lane & 7) ^ (((rb + 8 * h) >> 1) & 7)) << 4);
-            } else {
-#pragma unroll
-                for (int h = 0; h < BP; ++h) {
-                    const int r = rb + h * 8;
-                    const int nb = min(n0 + r, p.N - 1);
-                    gB[h] = reinterpret_cast<const char*>(p.B) + map_row(bmap, nb) * (long long)p.ldb * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
-                }
-            }
-        }
+        };
 
         f32x4 acc[MI][NJ];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bfv8 fa[4][2];            // A fragments of the current 64-row sub-block: [16-row group][k step]
+        bfv8 fb[4][2];            // B fragments of the wave's 64 columns: [16-column group][k step]
 
-        auto issue = [&](int kt, int buf) {
-            const long long kbytes = (long long)kt * (BK * 2);
-            char* dst = smem + buf * STAGE_BYTES;
+        // One phase = quadrant Q of the slice in buffer BUF: (Q 0) rows 0-63 x columns 0-31, (1) rows 0-63 x columns 32-63,
+        // (2) rows 64-127 x columns 32-63, (3) rows 64-127 x columns 0-31 -- only what changed is read: 12 / 4 / 8 / 0 fragments.
+        auto phase = [&]<int Q, int BUF, int STX, int STBUF>(const int st_kt, const bool st_on, const int wait_mode) {
+            constexpr int SA = Q >> 1, SB = (Q == 1 || Q == 2) ? 1 : 0;
+            const char* sb_ = smem + BUF * STAGE_BYTES;
+            if constexpr (Q == 0 || Q == 1) {
 #pragma unroll
-            for (int h = 0; h < AP; ++h)
-                __builtin_amdgcn_global_load_lds((glb_void*)(gA[h] + kbytes), (lds_void*)(dst + (wave * (8 * AP) + h * 8) * 128), 16, 0, 0);
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int h = 0; h < BP; ++h) {
-                const char* sb;
-                if constexpr (BKM) sb = gB[h] ? gB[h] + (long long)kt * BK * p.ldb * 2 : zero;
-                else sb = gB[h] + kbytes;
-                __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(dst + A_BYTES + (wave * (8 * BP) + h * 8) * 128), 16, 0, 0);
+                    for (int s = 0; s < 2; ++s) {
+                        if constexpr (BKM) fb[SB * 2 + j][s] = tr_frag<KMajor<128>::ROWB>(sb_ + offB[SB * 2 + j] + s * 32 * KMajor<128>::ROWB);
+                        else fb[SB * 2 + j][s] = *reinterpret_cast<const bfv8*>(sb_ + offBn + (SB * 32 + j * 16) * 128 + (s ? slot1 : slot0));
+                    }
             }
+            if constexpr (Q == 0 || Q == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        fa[i][s] = *reinterpret_cast<const bfv8*>(sb_ + offA + (SA * 64 + i * 16) * 128 + (s ? slot1 : slot0));
+            }
+            if (st_on) stage.template operator()<STX>(st_kt, STBUF);
+            // wait_mode 1: every piece but the two just issued has landed; 2: every piece
+            if (wait_mode == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (wait_mode == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[SA * 4 + i][SB * 2 + j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[SB * 2 + j][s], fa[i][s], acc[SA * 4 + i][SB * 2 + j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
         };
-        auto compute = [&](int buf) {
-            const char* sb_ = smem + buf * STAGE_BYTES;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int so = s == 0 ? slot0 : slot1;
-                bfv8 a[MI], b[NJ];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bfv8*>(sb_ + offA + i * 2048 + so);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    if constexpr (BKM) b[j] = tr_frag<KMajor<BN>::ROWB>(sb_ + offB[j] + s * 32 * KMajor<BN>::ROWB);
-                    else b[j] = *reinterpret_cast<const bfv8*>(sb_ + offBn + j * 2048 + so);
-                }
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-            }
+        // one slice (four phases) out of buffer BUF; stages the rest of slice c1 (its first B half went in a slice ago) into the
+        // other buffer and the first B half of slice c2 into this one (its B columns 0-127 were last read two phases earlier)
+        auto slice = [&]<int BUF>(const int c1, const int c2) {
+            phase.template operator()<0, BUF, 3, BUF ^ 1>(c1, c1 < ke, 0);
+            phase.template operator()<1, BUF, 0, BUF ^ 1>(c1, c1 < ke, 0);
+            phase.template operator()<2, BUF, 1, BUF ^ 1>(c1, c1 < ke, 0);
+            phase.template operator()<3, BUF, 2, BUF>(c2, c2 < ke, c2 < ke ? 1 : 2);
         };
 
-        // ---- K loop: ring of three slice buffers, two slices in flight behind the one being multiplied ----
+        // ---- prologue: slice c0 whole, first B half of c1; per-row epilogue metadata while they fly ----
         int c0 = take();
         int c1 = take();
-        if (c0 < ke) issue(c0, 0);
-        if (c1 < ke) issue(c1, 1);
-        if (t < BM) {          // per-row epilogue metadata (its loads drain behind the first two slices)
+        if (c0 < ke) {
+            stage.template operator()<2>(c0, 0);
+            stage.template operator()<3>(c0, 0);
+            stage.template operator()<0>(c0, 0);
+            stage.template operator()<1>(c0, 0);
+        }
+        if (c1 < ke) stage.template operator()<2>(c1, 1);
+        if (t < BM) {
             const int m = m0 + t;
             RowMeta rm;
             rm.keep = 1 << 30; rm.scale = 1.0f; rm.orow = -1; rm.mloc = 0;
@@ -242,23 +260,24 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
             }
             rowmeta[t] = rm;
         }
+        if (c1 < ke) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();        // the second wave row runs one barrier behind the first
+        __builtin_amdgcn_sched_barrier(0);
         while (c0 < ke) {
-#pragma unroll
-            for (int b = 0; b < STAGES; ++b) {
-                if (c0 >= ke) break;
-                // slice c0 has landed when at most the pieces of the younger slice c1 are outstanding
-                if (c1 < ke) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();         // ... for every wave, and every wave is done with the buffer re-filled next
-                const int c2 = take();
-                if (c2 < ke) issue(c2, (b + 2) % STAGES);
-                compute(b);
-                c0 = c1;
-                c1 = c2;
-            }
-            // (a segment whose live-slice count is not a multiple of three ends inside the ring: the next segment starts at
-            // buffer 0 again behind the workgroup barrier below)
+            int c2 = take();
+            slice.template operator()<0>(c1, c2);
+            c0 = c1;
+            c1 = c2;
+            if (c0 >= ke) break;
+            c2 = take();
+            slice.template operator()<1>(c1, c2);
+            c0 = c1;
+            c1 = c2;
         }
+        if (wr == 0) __builtin_amdgcn_s_barrier();        // (the barrier the second row is still owed)
         __syncthreads();
 
         // ---- a tile cut between workgroups: the last contributor to arrive sums the partial accumulators ----
@@ -283,23 +302,24 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
                     __hip_atomic_store(pl.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __syncthreads();
-                for (int wc = w_first; wc <= w_last; ++wc) {
-                    if (wc == w) continue;
-                    const int lo_c = (int)(U * wc / G);
-                    const float* src = pl.slabs + ((size_t)wc * 2 + (lo_c / ns == tile ? 0 : 1)) * SLAB_FLOATS + t * 4;
-                    f32x4 part[MI * NJ];
+                for (int wc_ = w_first; wc_ <= w_last; ++wc_) {
+                    if (wc_ == w) continue;
+                    const int lo_c = (int)(U * wc_ / G);
+                    const float* src = pl.slabs + ((size_t)wc_ * 2 + (lo_c / ns == tile ? 0 : 1)) * SLAB_FLOATS + t * 4;
 #pragma unroll
-                    for (int r = 0; r < MI * NJ; ++r) part[r] = *reinterpret_cast<const f32x4*>(src + r * (WTHR * 4));
+                    for (int hh = 0; hh < 2; ++hh) {
+                        f32x4 part[MI * NJ / 2];
 #pragma unroll
-                    for (int i = 0; i < MI; ++i)
+                        for (int r = 0; r < MI * NJ / 2; ++r) part[r] = *reinterpret_cast<const f32x4*>(src + (hh * (MI * NJ / 2) + r) * (WTHR * 4));
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) acc[i][j] += part[i * NJ + j];
+                        for (int r = 0; r < MI * NJ / 2; ++r) acc[(hh * (MI * NJ / 2) + r) / NJ][(hh * (MI * NJ / 2) + r) % NJ] += part[r];
+                    }
                 }
                 finish = true;
             }
         }
         if (finish)
-            epilogue<TO, EPI, true, MI, NJ, FEAT>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wm * WROWS, n0 + wn * WCOLS, lane);
+            epilogue<TO, EPI, true, MI, NJ, FEAT>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wr * WROWS, n0 + wc * WCOLS, lane);
         __syncthreads();
     }
 }
@@ -312,7 +332,7 @@ template <typename TO, int EPI, int FEAT, bool BKM = false> void wlaunch(const v
 
 // bytes of workspace the wide kernel wants for a chip of n_cu CUs (tickets + two slabs per workgroup)
 size_t vr_gemm_ntw_ws_bytes(int n_cu) {
-    return (size_t)4096 * 4 + (size_t)n_cu * 2 * vr_gemm_nt::SLAB_FLOATS * sizeof(float);
+    return (size_t)vr_gemm_nt::TICKET_BYTES + (size_t)n_cu * 2 * vr_gemm_nt::SLAB_FLOATS * sizeof(float);
 }
 
 // Called by vr_gemm_nt_launch for forms both kernels cover.  mode: 1 = use the wide kernel where the cost model prefers it,
@@ -339,27 +359,31 @@ bool vr_gemm_ntw_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu, int
     pl.tiles_n = (a.N + W_BN - 1) / W_BN;
     pl.ns = a.K / BK;
     const long long tiles = (long long)pl.tiles_m * pl.tiles_n;
-    const int G = n_cu;
     static const int knob_fix = std::getenv("VITRES_NTW_FIX") ? std::atoi(std::getenv("VITRES_NTW_FIX")) : 8;   // a cut tile ~ this many slices
-    static const int knob_sk = std::getenv("VITRES_NTW_SK") ? std::atoi(std::getenv("VITRES_NTW_SK")) : 1;      // 0: never share tiles
-    const size_t need = vr_gemm_ntw_ws_bytes(G);
-    const bool can_sk = knob_sk && a.ws && (size_t)a.ws_bytes >= need && tiles + G <= 4096;
+    static const int knob_sk = std::getenv("VITRES_NTW_SK") ? std::atoi(std::getenv("VITRES_NTW_SK")) : 1;      // 0: never share tiles; 2: always
+    const size_t need = vr_gemm_ntw_ws_bytes(n_cu);
+    const bool can_sk = knob_sk && a.ws && (size_t)a.ws_bytes >= need && tiles + n_cu <= TICKET_BYTES / 4;
+    const int G = n_cu;
     const long long rounds = tiles / G, rem = tiles % G;
     const long long dp_cost = (rounds + (rem ? 1 : 0)) * pl.ns;
     long long sk_tiles = 0, cost = dp_cost;
+    int grid = (int)(tiles < G ? tiles : G);
     if (can_sk && rem) {
         const long long skt = rounds ? rem + G : rem;               // two-tile form: every share holds at least one whole tile
-        const long long sk_cost = (rounds ? rounds - 1 : 0) * pl.ns + (skt * pl.ns + G - 1) / G + knob_fix;
-        if (sk_cost < dp_cost || knob_sk == 2) { sk_tiles = skt; cost = sk_cost; }
+        const long long units = skt * pl.ns;
+        const int g2 = (int)(units / 4 < G ? (units / 4 < 1 ? 1 : units / 4) : G);      // at least four slices per share
+        const long long sk_cost = (rounds ? rounds - 1 : 0) * pl.ns + (units + g2 - 1) / g2 + knob_fix;
+        if ((sk_cost < dp_cost || knob_sk == 2) && (g2 == G || !rounds)) { sk_tiles = skt; cost = sk_cost; grid = g2; }
     }
     if (mode == 1) {
-        // the 4-wave kernels keep the short-K, many-tile GEMMs (first stage: HBM-bound, four workgroups per CU hide the latency)
-        if (pl.ns < 8 || cost * G > 2 * tiles * pl.ns) return false;
+        // the 4-wave kernels keep the short-K GEMMs of the first stage (HBM-bound: four workgroups per CU hide the latency)
+        if (pl.ns < 8) return false;
     }
+    (void)cost;
     pl.sk_tiles = (int)sk_tiles;
-    pl.grid = (int)(sk_tiles ? G : (tiles < G ? tiles : G));
+    pl.grid = grid;
     pl.tickets = reinterpret_cast<int*>(a.ws);
-    pl.slabs = a.ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(a.ws) + 4096 * 4) : nullptr;
+    pl.slabs = a.ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(a.ws) + TICKET_BYTES) : nullptr;
 
     if (a.b_trans) {
         if (a.dact_u) {
