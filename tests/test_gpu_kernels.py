@@ -111,7 +111,7 @@ def test_gemm_wide_streamk(M, N, K_, rows_in, variant):
     to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
     kw_d = {k: to(v) for k, v in kw.items()}
     ad, bd = a.to(DEV), b.to(DEV)
-    t_ = 1e-4 if out.dtype == torch.float32 else 5e-3
+    t_ = 1e-4 if out.dtype == torch.float32 else 8e-3          # bf16 outputs: one ulp (2^-7 of the largest value) where a sum rounds the other way
     for rep in range(3):
         real = K.gemm(ad, bd, torch.full_like(out, float("nan")).to(DEV), sched=8, **kw_d)
         torch.cuda.synchronize()
@@ -137,7 +137,7 @@ def test_gemm_wide_streamk(M, N, K_, rows_in, variant):
         outs.append((o_w, o_n))
     torch.cuda.synchronize()
     for o_w, o_n in outs:
-        assert relerr(o_w, o_n) < (2e-5 if out.dtype == torch.float32 else 5e-3), (variant, relerr(o_w, o_n))
+        assert relerr(o_w, o_n) < (2e-5 if out.dtype == torch.float32 else 8e-3), (variant, relerr(o_w, o_n))
     ws = K._workspace(torch.device(DEV, torch.cuda.current_device()))
     assert int(ws[: 4096 * 4].view(torch.int32).abs().sum()) == 0           # every ticket is back at zero
 

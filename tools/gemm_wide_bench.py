@@ -65,10 +65,12 @@ STAGES = {
            (2176, 1024, 3072, "dgrad"), (2176, 3072, 1024, "dmul"), (2176, 1024, 2304, "dgrad"), (2176, 768, 1024, "dgrad")],
     "s1": [(32896, 768, 256, "fwd"), (32896, 768, 256, "gelu"), (32896, 256, 768, "res"), (32896, 256, 256, "res"),
            (32896, 256, 768, "dgrad"), (32896, 768, 256, "dmul")],
+    # 256 tiles of 256 x 256 (1024 of 128 x 128): one / four per CU exactly -- time = fixed cost per tile + slices x slope
+    "probe": [(8192, 2048, k, kind) for kind in ("fwd", "res", "gelu", "dgrad") for k in (128, 256, 512, 1024, 2048, 4096)],
     "small": [(4160, 1920, 640, "fwd"), (4160, 640, 1920, "res"), (1088, 3840, 1280, "gelu"), (1088, 1280, 3840, "res"),
               (16448, 960, 320, "gelu"), (16448, 320, 960, "res")],
 }
-ROWS = {8320: 65, 2176: 17, 32896: 257, 4160: 65, 1088: 17, 16448: 257}
+ROWS = {8320: 65, 2176: 17, 32896: 257, 4160: 65, 1088: 17, 16448: 257, 8192: 64}
 
 which = sys.argv[1:] or ["s2", "s3", "s1"]
 print("%-30s %9s %9s %9s   %s" % ("M N K kind", "4-wave us", "wide us", "auto us", "dense TF/s (4-wave / wide / auto)"))

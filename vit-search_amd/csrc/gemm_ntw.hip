@@ -2,26 +2,25 @@
 //
 // The Linears of the second and third ViT-Res stages (reference nets/supernet_blocks.py:37-52,102-119 at 65 / 17 tokens per
 // sample: M = 8320 / 2176 rows, K and N = 512 ... 3072).  gemm_nt.hip covers them with 128 x 128 (or 64 x 128) tiles, one slice
-// in flight per workgroup and several un-synchronised workgroups per CU.  Two things bound that form below either roof:
-// a 64 x 64 wave tile reads 0.5 KB of LDS per MFMA (the LDS pipe is as busy as the matrix pipe would be at its peak), and a
-// 128 x 128 tile moves 1 byte into LDS per 64 flop -- exactly the balance of a CU's load path.  This kernel:
+// in flight per workgroup and several un-synchronised workgroups per CU: at four workgroups on every CU that form reaches
+// ~1000 TFLOP/s, but these outputs are 130 - 540 such tiles on 256 CUs -- one or two per CU, each paying the full load latency
+// per slice (350 - 430 TFLOP/s dense).  This kernel is built to run ONE workgroup per CU at full speed and to cut the work
+// into exactly one share per CU:
 //
-//   * 256 x 256 tile per 512-thread workgroup, 8 waves as 2 (M) x 4 (N), each 128 x 64 = 8 x 4 v_mfma_f32_16x16x32_bf16
-//     (0.375 KB of LDS reads per MFMA, 128 flop per byte of LDS fill), 128 accumulator registers, one workgroup per CU;
-//   * the two wave rows are the two halves of a ping-pong: a K slice (64) is four phases per wave, each {fragment reads of one
-//     64 x 32 quadrant + two LDS-DMA pieces} | s_barrier | {16 MFMAs} | s_barrier, and the second wave row runs one barrier
-//     behind the first, so that on every SIMD one wave multiplies while its partner reads and stages;
-//   * two 64 KB slice buffers of four 16 KB half-tiles (A rows 0-127 / 128-255, B columns 0-127 / 128-255); every phase stages
-//     one half-tile of a later slice (8 waves x 2 pieces), three half-tiles stay in flight across the barriers and ONE counted
-//     s_waitcnt vmcnt per slice retires them (all LDS is one array: a second __shared__ object makes hipcc drain the DMA queue in
-//     front of every fragment read);
-//   * stream-K (optional, vr_gemm_args.ws): tiles that do not fill a round of the chip are cut into equal contiguous shares of
+//   * 256 x 128 tile per 512-thread workgroup, 8 waves as 4 (M) x 2 (N), each 64 x 64 = 4 x 4 v_mfma_f32_16x16x32_bf16;
+//   * the upper and lower four waves are the two halves of a ping-pong (waves w and w + 4 share a SIMD): a K slice (64) is two
+//     phases per wave, each {8 fragment reads of one k step + 3 LDS-DMA pieces} | s_barrier | {16 MFMAs} | s_barrier, and the
+//     second half runs one barrier behind the first -- on every SIMD one wave multiplies while its partner reads and stages;
+//   * a ring of three 48 KB slice buffers: the slice two ahead is staged while the current one is multiplied, and ONE counted
+//     s_waitcnt vmcnt per slice retires the slice in between (all LDS is one array: a second __shared__ object makes hipcc
+//     drain the DMA queue in front of every fragment read);
+//   * stream-K (vr_gemm_args.ws): tiles that do not fill a round of the chip are cut into equal contiguous shares of
 //     (tile, slice) units, one per workgroup.  A tile cut between workgroups is summed by the LAST of them to arrive: every
 //     contributor writes its fp32 accumulators (register layout, 16 B per lane: no transposition) write-through to its own
-//     slab, drains, takes a ticket; the holder of the last ticket acquires, adds the other slabs to its registers and runs the
-//     epilogue.  Nobody waits for anybody: no co-residency or dispatch order is assumed; tickets return to zero.
+//     128 KB slab, drains, takes a ticket; the holder of the last ticket acquires, adds the other slabs to its registers and
+//     runs the epilogue.  Nobody waits for anybody: no co-residency or dispatch order is assumed; tickets return to zero.
 //
-// LDS images (XOR-swizzled 128-B rows; k-major weight half + ds_read_b64_tr_b16 for b_trans) and the epilogue are those of
+// LDS images (XOR-swizzled 128-B rows; k-major weight slice + ds_read_b64_tr_b16 for b_trans) and the epilogue are those of
 // gemm_nt.hip (gemm_nt_parts.h).
 #include <cstdlib>
 
@@ -30,8 +29,8 @@
 namespace vr_gemm_nt {
 
 constexpr int WTHR = 512;
-constexpr int W_BM = 256, W_BN = 256;
-constexpr int SLAB_FLOATS = W_BM * W_BN;            // one workgroup's accumulators: 256 KB
+constexpr int W_BM = 256, W_BN = 128;
+constexpr int SLAB_FLOATS = W_BM * W_BN;            // one workgroup's accumulators: 128 KB
 constexpr int TICKET_BYTES = 4096 * 4;
 
 __device__ const uint4 zero_chunk_w[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -50,15 +49,16 @@ __device__ __forceinline__ void store_wt(float* p, const f32x4 v) {        // wr
 
 template <typename TO, int EPI, int FEAT, bool BKM>
 __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, const NtwPlan pl) {
-    constexpr int MI = 8, NJ = 4, BM = W_BM, BN = W_BN, WROWS = 128, WCOLS = 64;
-    constexpr int HALF = 128 * BK * 2;                  // a half-tile: 128 rows (or k-major: 64 k x 128 columns) = 16 KB = 16 pieces
-    constexpr int STAGE_BYTES = 4 * HALF;               // [A rows 0-127][A rows 128-255][B columns 0-127][B columns 128-255]
-    constexpr int META_OFF = 2 * STAGE_BYTES, FLAG_OFF = META_OFF + BM * (int)sizeof(RowMeta);
-    __shared__ __attribute__((aligned(1024))) char smem[FLAG_OFF + 16];   // two slice buffers | row metadata | ticket broadcast
+    constexpr int MI = 4, NJ = 4, BM = W_BM, BN = W_BN, WROWS = 64, WCOLS = 64;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, AP = 4, BP = 2;      // LDS-DMA pieces (1 KB) per wave and slice
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES, STAGES = 3;
+    constexpr int META_OFF = STAGES * STAGE_BYTES, FLAG_OFF = META_OFF + BM * (int)sizeof(RowMeta);
+    __shared__ __attribute__((aligned(1024))) char smem[FLAG_OFF + 16];   // ring of slice buffers | row metadata | ticket broadcast
     RowMeta* rowmeta = reinterpret_cast<RowMeta*>(smem + META_OFF);
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wr = wave >> 2, wc = wave & 3;            // wave row = ping-pong half (waves w and w + 4 share a SIMD), wave column
+    const int wr = wave >> 1, wc = wave & 1;            // wave row (rows 64 wr ..), wave column (columns 64 wc ..)
+    const int half = wave >> 2;                         // ping-pong half: waves w and w + 4 share a SIMD
     const int G = pl.grid, ns = pl.ns;
     // workgroup ids are dealt round-robin to the 8 XCDs: an XCD owns a contiguous run of shares (n-fastest tile order: its L2
     // fetches an A panel once)
@@ -77,16 +77,16 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
     // ---- fragment read offsets inside a slice buffer: lane -> row (lane & 15) of a 16-row group, k-chunk 4 s + (lane >> 4) ----
     const int frow = lane & 15, fswz = (frow >> 1) & 7;
     const int slot0 = ((lane >> 4) ^ fswz) << 4, slot1 = ((4 + (lane >> 4)) ^ fswz) << 4;
-    const int offA = wr * HALF + frow * 128;                                            // + (sub * 64 + i * 16) * 128 + slot
-    const int offBn = (2 + (wc >> 1)) * HALF + ((wc & 1) * 64 + frow) * 128;            // + (sub * 32 + j * 16) * 128 + slot
-    int offB[NJ];                                                                       // k-major weight half: + s * 32 * ROWB
+    const int offA = (wr * WROWS + frow) * 128;                                         // + i * 2048 + slot
+    const int offBn = A_BYTES + (wc * WCOLS + frow) * 128;                              // + j * 2048 + slot
+    int offB[NJ];                                                                       // k-major weight slice: + s * 32 * ROWB
     if constexpr (BKM) {
-        typedef KMajor<128> KG;
+        typedef KMajor<BN> KG;
         const int li = lane & 15, g4 = lane >> 4;
         const int xr2 = KG::swz(8 * g4 + (li >> 2));
         const int rowoff = (8 * g4 + (li >> 2)) * KG::ROWB + (li & 1) * 8;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) offB[j] = (2 + (wc >> 1)) * HALF + rowoff + (((8 * (wc & 1) + 2 * j + ((li & 3) >> 1)) ^ xr2) * 16);
+        for (int j = 0; j < NJ; ++j) offB[j] = A_BYTES + rowoff + ((((BN / 16) * wc + 2 * j + ((li & 3) >> 1)) ^ xr2) * 16);
     }
 
     int u = lo, dp_tile = pl.sk_tiles + w;
@@ -141,40 +141,47 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
             return ke;
         };
 
-        // ---- LDS-DMA sources: half-tile x, piece h of this wave = its rows 16 wave + 8 h .. + 8; lane -> (row, 16-byte slot) ----
-        const char* gA[2][2];
-        const char* gB[2][2];
+        // ---- LDS-DMA sources: piece h of this wave = 8 rows of 128 B, lane -> (row, 16-byte slot) ----
+        const char* gA[AP];
+        const char* gB[BP];
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int h = 0; h < AP; ++h) {
+            const int r = wave * (8 * AP) + 8 * h + (lane >> 3);
+            const int ma = min(m0 + r, p.M - 1);
+            gA[h] = reinterpret_cast<const char*>(p.A) + map_row(amap, ma) * (long long)p.lda * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+        }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = 16 * wave + 8 * h + (lane >> 3);
-                const int ma = min(m0 + 128 * x + r, p.M - 1);
-                gA[x][h] = reinterpret_cast<const char*>(p.A) + map_row(amap, ma) * (long long)p.lda * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
-                if constexpr (BKM) {
-                    typedef KMajor<128> KG;
-                    const int tk = (2 * wave + h) * KG::TPP + lane / KG::SLOTS;
-                    const int c = (lane % KG::SLOTS) ^ KG::swz(tk);
-                    // column chunks past the row's readable width (ldb >= roundup(N, 8)) come from the zero page: their products
-                    // only reach outputs that are not stored
-                    const bool bok = n0 + 128 * x + c * 8 + 8 <= p.ldb;
-                    gB[x][h] = bok ? reinterpret_cast<const char*>(p.B) + ((long long)tk * p.ldb + n0 + 128 * x + c * 8) * 2 : nullptr;
-                } else {
-                    const int nb = min(n0 + 128 * x + r, p.N - 1);
-                    gB[x][h] = reinterpret_cast<const char*>(p.B) + map_row(bmap, nb) * (long long)p.ldb * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
-                }
+        for (int h = 0; h < BP; ++h) {
+            if constexpr (BKM) {
+                typedef KMajor<BN> KG;
+                const int tk = (wave * BP + h) * KG::TPP + lane / KG::SLOTS;
+                const int c = (lane % KG::SLOTS) ^ KG::swz(tk);
+                // column chunks past the row's readable width (ldb >= roundup(N, 8)) come from the zero page: their products only
+                // reach outputs that are not stored
+                const bool bok = n0 + c * 8 + 8 <= p.ldb;
+                gB[h] = bok ? reinterpret_cast<const char*>(p.B) + ((long long)tk * p.ldb + n0 + c * 8) * 2 : nullptr;
+            } else {
+                const int r = wave * (8 * BP) + 8 * h + (lane >> 3);
+                const int nb = min(n0 + r, p.N - 1);
+                gB[h] = reinterpret_cast<const char*>(p.B) + map_row(bmap, nb) * (long long)p.ldb * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
             }
-        // stage one half-tile (X = 0, 1: A rows; 2, 3: B columns) of slice kt into slice buffer buf: two pieces per wave
-        auto stage = [&]<int X>(int kt, int buf) {
+        }
+        // stage this wave's pieces of slice kt into ring buffer buf: PART 0 = A pieces 0-2, 1 = A piece 3 + both B pieces, 2 = all
+        auto stage = [&]<int PART>(int kt, int buf) {
             const long long kbytes = (long long)kt * (BK * 2);
-            char* dst = smem + buf * STAGE_BYTES + X * HALF + wave * 2048;
+            char* dst = smem + buf * STAGE_BYTES;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const char* src;
-                if constexpr (X < 2) src = gA[X][h] + kbytes;
-                else if constexpr (BKM) src = gB[X - 2][h] ? gB[X - 2][h] + (long long)kt * BK * p.ldb * 2 : zero;
-                else src = gB[X - 2][h] + kbytes;
-                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + h * 1024), 16, 0, 0);
+            for (int h = 0; h < AP; ++h)
+                if (PART == 2 || (PART == 0) == (h < 3))
+                    __builtin_amdgcn_global_load_lds((glb_void*)(gA[h] + kbytes), (lds_void*)(dst + (wave * AP + h) * 1024), 16, 0, 0);
+            if constexpr (PART != 0) {
+#pragma unroll
+                for (int h = 0; h < BP; ++h) {
+                    const char* src;
+                    if constexpr (BKM) src = gB[h] ? gB[h] + (long long)kt * BK * p.ldb * 2 : zero;
+                    else src = gB[h] + kbytes;
+                    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + A_BYTES + (wave * BP + h) * 1024), 16, 0, 0);
+                }
             }
         };
 
@@ -183,69 +190,45 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bfv8 fa[4][2];            // A fragments of the current 64-row sub-block: [16-row group][k step]
-        bfv8 fb[4][2];            // B fragments of the wave's 64 columns: [16-column group][k step]
 
-        // One phase = quadrant Q of the slice in buffer BUF: (Q 0) rows 0-63 x columns 0-31, (1) rows 0-63 x columns 32-63,
-        // (2) rows 64-127 x columns 32-63, (3) rows 64-127 x columns 0-31 -- only what changed is read: 12 / 4 / 8 / 0 fragments.
-        auto phase = [&]<int Q, int BUF, int STX, int STBUF>(const int st_kt, const bool st_on, const int wait_mode) {
-            constexpr int SA = Q >> 1, SB = (Q == 1 || Q == 2) ? 1 : 0;
+        // One phase = k step S (32 of the slice's 64) out of ring buffer BUF, staging half of slice c2 into buffer (BUF + 2) % 3
+        // (last read a slice ago: every wave retired those reads in front of a barrier this wave has passed).
+        auto phase = [&]<int S, int BUF>(const int c2, const bool last_of_slice) {
             const char* sb_ = smem + BUF * STAGE_BYTES;
-            if constexpr (Q == 0 || Q == 1) {
+            const int so = S ? slot1 : slot0;
+            bfv8 fa[MI], fb[NJ];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const bfv8*>(sb_ + offA + i * 2048 + so);
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        if constexpr (BKM) fb[SB * 2 + j][s] = tr_frag<KMajor<128>::ROWB>(sb_ + offB[SB * 2 + j] + s * 32 * KMajor<128>::ROWB);
-                        else fb[SB * 2 + j][s] = *reinterpret_cast<const bfv8*>(sb_ + offBn + (SB * 32 + j * 16) * 128 + (s ? slot1 : slot0));
-                    }
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (BKM) fb[j] = tr_frag<KMajor<BN>::ROWB>(sb_ + offB[j] + S * 32 * KMajor<BN>::ROWB);
+                else fb[j] = *reinterpret_cast<const bfv8*>(sb_ + offBn + j * 2048 + so);
             }
-            if constexpr (Q == 0 || Q == 2) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-                        fa[i][s] = *reinterpret_cast<const bfv8*>(sb_ + offA + (SA * 64 + i * 16) * 128 + (s ? slot1 : slot0));
+            if (c2 < ke) stage.template operator()<S>(c2, (BUF + 2) % STAGES);
+            if (last_of_slice) {
+                // the next slice (staged a slice ago) has landed when at most the six pieces of slice c2 are outstanding
+                if (c2 < ke) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (st_on) stage.template operator()<STX>(st_kt, STBUF);
-            // wait_mode 1: every piece but the two just issued has landed; 2: every piece
-            if (wait_mode == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (wait_mode == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // fragment reads retired IN FRONT of the barrier (see above)
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[SA * 4 + i][SB * 2 + j] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[SB * 2 + j][s], fa[i][s], acc[SA * 4 + i][SB * 2 + j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
-        // one slice (four phases) out of buffer BUF; stages the rest of slice c1 (its first B half went in a slice ago) into the
-        // other buffer and the first B half of slice c2 into this one (its B columns 0-127 were last read two phases earlier)
-        auto slice = [&]<int BUF>(const int c1, const int c2) {
-            phase.template operator()<0, BUF, 3, BUF ^ 1>(c1, c1 < ke, 0);
-            phase.template operator()<1, BUF, 0, BUF ^ 1>(c1, c1 < ke, 0);
-            phase.template operator()<2, BUF, 1, BUF ^ 1>(c1, c1 < ke, 0);
-            phase.template operator()<3, BUF, 2, BUF>(c2, c2 < ke, c2 < ke ? 1 : 2);
-        };
 
-        // ---- prologue: slice c0 whole, first B half of c1; per-row epilogue metadata while they fly ----
+        // ---- prologue: slices c0 and c1 whole; per-row epilogue metadata while they fly ----
         int c0 = take();
         int c1 = take();
-        if (c0 < ke) {
-            stage.template operator()<2>(c0, 0);
-            stage.template operator()<3>(c0, 0);
-            stage.template operator()<0>(c0, 0);
-            stage.template operator()<1>(c0, 0);
-        }
+        if (c0 < ke) stage.template operator()<2>(c0, 0);
         if (c1 < ke) stage.template operator()<2>(c1, 1);
         if (t < BM) {
             const int m = m0 + t;
@@ -260,24 +243,27 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
             }
             rowmeta[t] = rm;
         }
-        if (c1 < ke) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (c1 < ke) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        if (wr == 1) __builtin_amdgcn_s_barrier();        // the second wave row runs one barrier behind the first
+        if (half == 1) __builtin_amdgcn_s_barrier();      // the second half runs one barrier behind the first
         __builtin_amdgcn_sched_barrier(0);
         while (c0 < ke) {
-            int c2 = take();
-            slice.template operator()<0>(c1, c2);
-            c0 = c1;
-            c1 = c2;
-            if (c0 >= ke) break;
-            c2 = take();
-            slice.template operator()<1>(c1, c2);
-            c0 = c1;
-            c1 = c2;
+#pragma unroll
+            for (int b = 0; b < STAGES; ++b) {
+                if (c0 >= ke) break;
+                const int c2 = take();
+                if (b == 0) { phase.template operator()<0, 0>(c2, false); phase.template operator()<1, 0>(c2, true); }
+                else if (b == 1) { phase.template operator()<0, 1>(c2, false); phase.template operator()<1, 1>(c2, true); }
+                else { phase.template operator()<0, 2>(c2, false); phase.template operator()<1, 2>(c2, true); }
+                c0 = c1;
+                c1 = c2;
+            }
+            // (a segment whose live-slice count is not a multiple of three ends inside the ring: the next segment starts at
+            // buffer 0 again behind the workgroup barrier below)
         }
-        if (wr == 0) __builtin_amdgcn_s_barrier();        // (the barrier the second row is still owed)
+        if (half == 0) __builtin_amdgcn_s_barrier();      // (the barrier the second half is still owed)
         __syncthreads();
 
         // ---- a tile cut between workgroups: the last contributor to arrive sums the partial accumulators ----
@@ -306,14 +292,11 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
                     if (wc_ == w) continue;
                     const int lo_c = (int)(U * wc_ / G);
                     const float* src = pl.slabs + ((size_t)wc_ * 2 + (lo_c / ns == tile ? 0 : 1)) * SLAB_FLOATS + t * 4;
+                    f32x4 part[MI * NJ];
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        f32x4 part[MI * NJ / 2];
+                    for (int r = 0; r < MI * NJ; ++r) part[r] = *reinterpret_cast<const f32x4*>(src + r * (WTHR * 4));
 #pragma unroll
-                        for (int r = 0; r < MI * NJ / 2; ++r) part[r] = *reinterpret_cast<const f32x4*>(src + (hh * (MI * NJ / 2) + r) * (WTHR * 4));
-#pragma unroll
-                        for (int r = 0; r < MI * NJ / 2; ++r) acc[(hh * (MI * NJ / 2) + r) / NJ][(hh * (MI * NJ / 2) + r) % NJ] += part[r];
-                    }
+                    for (int r = 0; r < MI * NJ; ++r) acc[r / NJ][r % NJ] += part[r];
                 }
                 finish = true;
             }
