@@ -67,19 +67,25 @@ STAGES = {
            (32896, 256, 768, "dgrad"), (32896, 768, 256, "dmul")],
     # 256 tiles of 256 x 256 (1024 of 128 x 128): one / four per CU exactly -- time = fixed cost per tile + slices x slope
     "probe": [(8192, 2048, k, kind) for kind in ("fwd", "res", "gelu", "dgrad") for k in (128, 256, 512, 1024, 2048, 4096)],
+    "skp": [(8320, 512, 1536, "res"), (8320, 512, 1536, "dgrad"), (2176, 1024, 3072, "res"), (2176, 1024, 2304, "dgrad"), (8320, 512, 512, "res")],
     "small": [(4160, 1920, 640, "fwd"), (4160, 640, 1920, "res"), (1088, 3840, 1280, "gelu"), (1088, 1280, 3840, "res"),
               (16448, 960, 320, "gelu"), (16448, 320, 960, "res")],
 }
 ROWS = {8320: 65, 2176: 17, 32896: 257, 4160: 65, 1088: 17, 16448: 257, 8192: 64}
 
-which = sys.argv[1:] or ["s2", "s3", "s1"]
-print("%-30s %9s %9s %9s   %s" % ("M N K kind", "4-wave us", "wide us", "auto us", "dense TF/s (4-wave / wide / auto)"))
-for st in which:
-    for M, N, Kd, kind in STAGES[st]:
-        x, w, out, kw = case(M, N, Kd, kind, ROWS[M])
-        ts = []
-        for sched in (16, 8, 0):
-            ts.append(timeit(lambda: K.gemm(x, w, out, sched=sched, **kw)))
-        fl = 2.0 * M * N * Kd
-        print("%-30s %9.1f %9.1f %9.1f   %6.0f / %6.0f / %6.0f" % ("%d %d %d %s" % (M, N, Kd, kind), ts[0] * 1e6, ts[1] * 1e6,
-                                                                 ts[2] * 1e6, fl / ts[0] / 1e12, fl / ts[1] / 1e12, fl / ts[2] / 1e12))
+def main():
+    which = sys.argv[1:] or ["s2", "s3", "s1"]
+    print("%-30s %9s %9s %9s   %s" % ("M N K kind", "4-wave us", "wide us", "auto us", "dense TF/s (4-wave / wide / auto)"))
+    for st in which:
+        for M, N, Kd, kind in STAGES[st]:
+            x, w, out, kw = case(M, N, Kd, kind, ROWS[M])
+            ts = []
+            for sched in (16, 8, 0):
+                ts.append(timeit(lambda: K.gemm(x, w, out, sched=sched, **kw)))
+            fl = 2.0 * M * N * Kd
+            print("%-30s %9.1f %9.1f %9.1f   %6.0f / %6.0f / %6.0f" % ("%d %d %d %s" % (M, N, Kd, kind), ts[0] * 1e6, ts[1] * 1e6,
+                                                                     ts[2] * 1e6, fl / ts[0] / 1e12, fl / ts[1] / 1e12, fl / ts[2] / 1e12))
+
+
+if __name__ == "__main__":
+    main()

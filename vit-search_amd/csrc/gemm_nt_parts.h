@@ -56,7 +56,10 @@ template <int ROWB> __device__ __forceinline__ bfv8 tr_frag(const char* p) {
 // residual, 3: bias + residual + DropPath scale, 4: decided per launch from the arguments (pos-embed, any other mix; the only
 // form of the non-FAST kernels).  As run-time uniform conditions the compiler if-converts them into a v_cndmask per element
 // and term (measured: 890 VALU instructions per tile and wave against 128 MFMAs at K = 256, VALU pipe busy 2x the matrix pipe).
-template <typename TO, int EPI, bool FAST, int MI, int NJ, int FEAT>
+// DEEP: the side operands of ALL rounds are requested up front (16 registers per round for the fp32 residual: only the 8-wave
+// kernel, which runs at two waves per SIMD, has them) instead of one round ahead -- a 256 x 128 tile's fp32 residual epilogue
+// took 5 us of exposed latency, four rounds in a row.
+template <typename TO, int EPI, bool FAST, int MI, int NJ, int FEAT, bool DEEP = false>
 __device__ __forceinline__ void epilogue(const vr_gemm_args& p, f32x4 (&acc)[MI][NJ], float* park, const RowMeta* meta0, const int nw0,
                                          const int lane) {
     constexpr int WCOLS = 16 * NJ;
@@ -98,27 +101,34 @@ __device__ __forceinline__ void epilogue(const vr_gemm_args& p, f32x4 (&acc)[MI]
     constexpr bool SIDE_D = EPI == EPI_DGELU || EPI == EPI_DMUL;
     constexpr bool SIDE_R = EPI == EPI_STORE && (FEAT == 2 || FEAT == 3);
     constexpr bool PREF = FAST && (SIDE_D || SIDE_R);
-    RowMeta rmn[NQ];
-    uint4 dn[NQ];
-    float4 rn[NQ][2];
+    constexpr int NSET = DEEP ? MI : 1;
+    RowMeta rmn[NSET][NQ];
+    uint4 dn[NSET][NQ];
+    float4 rn[NSET][NQ][2];
     auto prefetch = [&](int i) {
+        const int sidx = DEEP ? i : 0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            rmn[q] = meta[i * 16 + q * RPP];
-            const long long row = rmn[q].orow < 0 ? 0 : rmn[q].orow;
+            rmn[sidx][q] = meta[i * 16 + q * RPP];
+            const long long row = rmn[sidx][q].orow < 0 ? 0 : rmn[sidx][q].orow;
             if constexpr (SIDE_D)
-                dn[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.dact_u) + row * p.ldu + nc);
+                dn[sidx][q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.dact_u) + row * p.ldu + nc);
             if constexpr (SIDE_R) {
                 const float* r = p.resid + row * p.ldc + nc;
-                rn[q][0] = *reinterpret_cast<const float4*>(r);
-                rn[q][1] = *reinterpret_cast<const float4*>(r + 4);
+                rn[sidx][q][0] = *reinterpret_cast<const float4*>(r);
+                rn[sidx][q][1] = *reinterpret_cast<const float4*>(r + 4);
             }
         }
     };
-    if constexpr (SIDE_D && PREF) prefetch(0);
+    if constexpr (PREF && DEEP) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) prefetch(i);
+    } else if constexpr (SIDE_D && PREF) {
+        prefetch(0);
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        if constexpr (SIDE_R && PREF) prefetch(i);
+        if constexpr (SIDE_R && PREF && !DEEP) prefetch(i);
         RowMeta rm[NQ];
         long long oidx[NQ];
         float rv[NQ][CW], pv[NQ][CW];
@@ -127,12 +137,12 @@ __device__ __forceinline__ void epilogue(const vr_gemm_args& p, f32x4 (&acc)[MI]
         if constexpr (PREF) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                rm[q] = rmn[q];
-                dc[q] = dn[q];
-                rc[q][0] = rn[q][0];
-                rc[q][1] = rn[q][1];
+                rm[q] = rmn[DEEP ? i : 0][q];
+                dc[q] = dn[DEEP ? i : 0][q];
+                rc[q][0] = rn[DEEP ? i : 0][q][0];
+                rc[q][1] = rn[DEEP ? i : 0][q][1];
             }
-            if constexpr (SIDE_D) {
+            if constexpr (SIDE_D && !DEEP) {
                 if (i + 1 < MI) prefetch(i + 1);
             }
         }

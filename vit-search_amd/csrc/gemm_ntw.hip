@@ -41,11 +41,21 @@ struct NtwPlan {
     int grid;                      // workgroups
     float* slabs;                  // [grid][2][SLAB_FLOATS] partial accumulators
     int* tickets;                  // [sk_tiles], zero on entry and on exit
+    int dbg;                       // timing experiments (VITRES_NTW_DBG; 1 / 2 / 4 give wrong results): 1 no slab stores, 2 no slab reads,
+                                   // 4 plain stores + release fence, 8 record stamps
 };
 
 __device__ __forceinline__ void store_wt(float* p, const f32x4 v) {        // write-through (sc1) 16-byte store
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
+
+// VITRES_NTW_DBG & 8: workgroups < 64 record wall-clock stamps (100 MHz) of their first segments in the upper half of the ticket
+// array (tools/ntw_stamps.py prints them)
+#define NTW_STAMP(slot)                                                                                           \
+    do {                                                                                                          \
+        if ((pl.dbg & 8) && t == 0 && blockIdx.x < 64 && stamp_i < 16)                                            \
+            reinterpret_cast<long long*>(pl.tickets + 2048)[blockIdx.x * 16 + stamp_i++] = (long long)wall_clock64() * 16 + (slot); \
+    } while (0)
 
 template <typename TO, int EPI, int FEAT, bool BKM>
 __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, const NtwPlan pl) {
@@ -67,8 +77,8 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
         const int xq = G >> 3, xr = G & 7, x = w & 7;
         w = x * xq + min(x, xr) + (w >> 3);
     }
-    const long long U = (long long)pl.sk_tiles * ns;          // slice units of the shared tiles
-    const int lo = (int)(U * w / G), hi = (int)(U * (w + 1) / G);
+    const unsigned U = (unsigned)pl.sk_tiles * ns;            // slice units of the shared tiles (host: U * grid < 2^31)
+    const int lo = (int)(U * (unsigned)w / (unsigned)G), hi = (int)(U * (unsigned)(w + 1) / (unsigned)G);
     const int tiles = pl.tiles_m * pl.tiles_n;
     const RowMap amap = {p.a_map.rpi, p.a_map.rps, p.a_map.off};
     const RowMap bmap = {p.b_map.rpi, p.b_map.rps, p.b_map.off};
@@ -89,6 +99,8 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
         for (int j = 0; j < NJ; ++j) offB[j] = A_BYTES + rowoff + ((((BN / 16) * wc + 2 * j + ((li & 3) >> 1)) ^ xr2) * 16);
     }
 
+    int stamp_i = 0;
+    NTW_STAMP(0);
     int u = lo, dp_tile = pl.sk_tiles + w;
     while (true) {
         // ---- next segment: slices [kb, ke) of a tile ----
@@ -225,6 +237,7 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
             __builtin_amdgcn_sched_barrier(0);
         };
 
+        NTW_STAMP(1);
         // ---- prologue: slices c0 and c1 whole; per-row epilogue metadata while they fly ----
         int c0 = take();
         int c1 = take();
@@ -249,6 +262,7 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
         __builtin_amdgcn_s_barrier();
         if (half == 1) __builtin_amdgcn_s_barrier();      // the second half runs one barrier behind the first
         __builtin_amdgcn_sched_barrier(0);
+        NTW_STAMP(2);
         while (c0 < ke) {
 #pragma unroll
             for (int b = 0; b < STAGES; ++b) {
@@ -265,21 +279,37 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
         }
         if (half == 0) __builtin_amdgcn_s_barrier();      // (the barrier the second half is still owed)
         __syncthreads();
+        NTW_STAMP(3);
 
         // ---- a tile cut between workgroups: the last contributor to arrive sums the partial accumulators ----
         bool finish = kb == 0 && ke == ns;
         if (!finish) {
-            const long long u0 = (long long)tile * ns;
+            const unsigned u0 = (unsigned)tile * ns;
             const int w_first = (int)(((u0 + 1) * G - 1) / U), w_last = (int)(((u0 + ns) * G - 1) / U);
             float* mine = pl.slabs + ((size_t)w * 2 + (first_seg ? 0 : 1)) * SLAB_FLOATS + t * 4;
+            if (!(pl.dbg & 1)) {
+                if (pl.dbg & 4) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) store_wt(mine + (i * NJ + j) * (WTHR * 4), acc[i][j]);
+                        for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(mine + (i * NJ + j) * (WTHR * 4)) = acc[i][j];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) store_wt(mine + (i * NJ + j) * (WTHR * 4), acc[i][j]);
+                }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             int* flag = reinterpret_cast<int*>(smem + FLAG_OFF);
-            if (t == 0) *flag = __hip_atomic_fetch_add(pl.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0) {
+                if (pl.dbg & 4) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                *flag = __hip_atomic_fetch_add(pl.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             __syncthreads();
             const int ticket = *flag;
             if (ticket == w_last - w_first) {
@@ -289,8 +319,8 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
                 }
                 __syncthreads();
                 for (int wc_ = w_first; wc_ <= w_last; ++wc_) {
-                    if (wc_ == w) continue;
-                    const int lo_c = (int)(U * wc_ / G);
+                    if (wc_ == w || (pl.dbg & 2)) continue;
+                    const int lo_c = (int)(U * (unsigned)wc_ / (unsigned)G);
                     const float* src = pl.slabs + ((size_t)wc_ * 2 + (lo_c / ns == tile ? 0 : 1)) * SLAB_FLOATS + t * 4;
                     f32x4 part[MI * NJ];
 #pragma unroll
@@ -301,9 +331,11 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
                 finish = true;
             }
         }
+        NTW_STAMP(4);
         if (finish)
-            epilogue<TO, EPI, true, MI, NJ, FEAT>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wr * WROWS, n0 + wc * WCOLS, lane);
+            epilogue<TO, EPI, true, MI, NJ, FEAT, true>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wr * WROWS, n0 + wc * WCOLS, lane);
         __syncthreads();
+        NTW_STAMP(5);
     }
 }
 
@@ -345,7 +377,7 @@ bool vr_gemm_ntw_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu, int
     static const int knob_fix = std::getenv("VITRES_NTW_FIX") ? std::atoi(std::getenv("VITRES_NTW_FIX")) : 8;   // a cut tile ~ this many slices
     static const int knob_sk = std::getenv("VITRES_NTW_SK") ? std::atoi(std::getenv("VITRES_NTW_SK")) : 1;      // 0: never share tiles; 2: always
     const size_t need = vr_gemm_ntw_ws_bytes(n_cu);
-    const bool can_sk = knob_sk && a.ws && (size_t)a.ws_bytes >= need && tiles + n_cu <= TICKET_BYTES / 4;
+    const bool can_sk = knob_sk && a.ws && (size_t)a.ws_bytes >= need && tiles + n_cu <= 2048 && (tiles + n_cu) * pl.ns * (long long)n_cu < (1LL << 31);
     const int G = n_cu;
     const long long rounds = tiles / G, rem = tiles % G;
     const long long dp_cost = (rounds + (rem ? 1 : 0)) * pl.ns;
@@ -365,6 +397,8 @@ bool vr_gemm_ntw_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu, int
     (void)cost;
     pl.sk_tiles = (int)sk_tiles;
     pl.grid = grid;
+    static const int knob_dbg = std::getenv("VITRES_NTW_DBG") ? std::atoi(std::getenv("VITRES_NTW_DBG")) : 0;
+    pl.dbg = knob_dbg;
     pl.tickets = reinterpret_cast<int*>(a.ws);
     pl.slabs = a.ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(a.ws) + TICKET_BYTES) : nullptr;
 

@@ -275,6 +275,8 @@ class GraphedTrainStep:
         if cuts:
             self.split = cuts[0]
         self.graph = torch.cuda.CUDAGraph()
+        from . import kernels as K
+        K.ensure_workspaces(samples.device, roles=(0, 1))             # stream-K workspaces exist before anything is captured
         model._bwd_split = [c for c, _ in cuts] if cuts else None
         try:
             self._loss_buf = torch.zeros(1, dtype=torch.float32, device=samples.device)

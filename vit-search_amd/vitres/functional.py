@@ -99,12 +99,19 @@ SIDE_DEFER = _os.environ.get('VITRES_SIDE_DEFER', '1') != '0'
 _deferred = []           # [(event on the main stream, side stream, fn)]
 
 
+def _run_side(side, fn):
+    # (launches on a side stream overlap the main chain's: they get their own stream-K workspace -- kernels.ws_role)
+    sides = _side_streams.get(side.device, ())
+    role = 1 + (sides.index(side) if side in sides else 0)
+    with torch.cuda.stream(side), K.ws_role(role):
+        fn()
+
+
 def flush_side():
     while _deferred:
         ev, side, fn = _deferred.pop(0)
         side.wait_event(ev)
-        with torch.cuda.stream(side):
-            fn()
+        _run_side(side, fn)
 
 
 def on_side(fn, *keepalive, defer=True):
@@ -121,8 +128,7 @@ def on_side(fn, *keepalive, defer=True):
     else:
         flush_side()
         side.wait_stream(main)
-        with torch.cuda.stream(side):
-            fn()
+        _run_side(side, fn)
     _pending.extend(keepalive)
 
 
