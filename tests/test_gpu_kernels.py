@@ -25,6 +25,13 @@ def tol(dtype):
     return 2e-5 if dtype == torch.float32 else 1.2e-2
 
 
+def tol32(dtype):
+    """fp32 OUTPUT of a GEMM: with bf16 operands the emulation multiplies the same bf16-rounded values and accumulates in fp32
+    like the MFMAs do -- only the summation order differs.  (1.2e-2 is for bf16 OUTPUTS: one ulp of the largest value; at that
+    width a wrong fragment in one of 80 K slices would pass.)"""
+    return 2e-5 if dtype == torch.float32 else 1e-4
+
+
 def both(fn_name, cpu_args, cpu_kwargs=None, tensor_outs=()):
     """Run emu on CPU args and the real kernel on .cuda() copies; returns (real, ref)."""
     cpu_kwargs = cpu_kwargs or {}
@@ -62,7 +69,7 @@ def test_gemm_forward_epilogues(dtype, M, N, K_):
         kw_d = {k: to(v) for k, v in kw.items()}
         real = K.gemm(a.to(DEV), b.to(DEV), out.to(DEV), **kw_d)
         torch.cuda.synchronize()
-        assert relerr(real, ref) < tol(dtype), (variant, relerr(real, ref))
+        assert relerr(real, ref) < (tol32(dtype) if variant == "resid" else tol(dtype)), (variant, relerr(real, ref))
         if variant == "gelu":
             ref2 = torch.zeros(M, N, dtype=out_dtype)
             kw2 = dict(kw); kw2["out2"] = ref2
@@ -154,7 +161,7 @@ def test_gemm_rowmaps_and_pos(dtype):
     kw = dict(M=B * P, N=C, K=Kd, lda=Kd, ldb=Kd, ldc=C, bias=bias, pos=pos, keep_n=keep, rows_in=P, c_map=(P, N, 1))
     ref = E.gemm(a, w, out.clone(), **kw)
     real = K.gemm(a.to(DEV), w.to(DEV), out.to(DEV), **{k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
-    assert relerr(real, ref) < tol(dtype)
+    assert relerr(real, ref) < tol32(dtype)
     # a_map on the input rows (token 0 of every sample)
     y = rnd(B, N, C, seed=5).to(dtype)
     w2 = rnd(24, C, seed=6, scale=0.1).to(dtype)
@@ -162,7 +169,7 @@ def test_gemm_rowmaps_and_pos(dtype):
     kw = dict(M=B, N=24, K=C, lda=C, ldb=C, ldc=24, a_map=(1, N, 0))
     ref = E.gemm(y, w2, out.clone(), **kw)
     real = K.gemm(y.to(DEV), w2.to(DEV), out.to(DEV), **kw)
-    assert relerr(real, ref) < tol(dtype)
+    assert relerr(real, ref) < tol32(dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -197,7 +204,7 @@ def test_gemm_wgrad(dtype, T, No, Ki, split):
     bg_ref, bg = rnd(No, seed=4), rnd(No, seed=4).to(DEV)
     ref = E.gemm(dy, x, out.clone(), bias_grad=bg_ref, **kw)
     real = K.gemm(dy.to(DEV), x.to(DEV), out.to(DEV), bias_grad=bg, **kw)
-    t = 5e-5 if dtype == torch.float32 else 1.2e-2
+    t = 5e-5 if dtype == torch.float32 else 1e-4
     assert relerr(real, ref) < t, relerr(real, ref)
     assert relerr(bg, bg_ref) < 2e-4, relerr(bg, bg_ref)       # fused bias gradient (exact sums of the stored values)
 
@@ -212,14 +219,14 @@ def test_gemm_wgrad_rowmaps(dtype):
               a_map=(1, No_, 0), b_map=(1, Ni, 0))
     ref = E.gemm(gt, y, out.clone(), **kw)
     real = K.gemm(gt.to(DEV), y.to(DEV), out.to(DEV), **kw)
-    assert relerr(real, ref) < tol(dtype)
+    assert relerr(real, ref) < tol32(dtype)
     col = rnd(B * 4, 9 * C, seed=3).to(dtype)
     out = torch.zeros(Co, 9 * C)
     kw = dict(M=Co, N=9 * C, K=B * 4, lda=Co, ldb=9 * C, ldc=9 * C, a_trans=True, b_trans=True, atomic=True,
               split_k=2, a_map=(4, No_, 1))
     ref = E.gemm(gt, col, out.clone(), **kw)
     real = K.gemm(gt.to(DEV), col.to(DEV), out.to(DEV), **kw)
-    assert relerr(real, ref) < tol(dtype)
+    assert relerr(real, ref) < tol32(dtype)
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
@@ -330,6 +337,26 @@ def test_attention_fwd_bwd(dtype, N, H, D):
     dq = K.attn_bwd(qkv.to(DEV), o, d_o.to(DEV), lse, keep.to(DEV), B, N, H, D, scale)
     dqr = E.attn_bwd(qkv, orf, d_o, lser, keep, B, N, H, D, scale)
     assert relerr(dq, dqr) < (1e-4 if dtype == torch.float32 else 2.5e-2), relerr(dq, dqr)
+
+
+@pytest.mark.parametrize("N,H,D", [(17, 2, 64), (65, 3, 48), (257, 2, 32), (257, 3, 64)])
+def test_attention_propagates_non_finite_inputs(N, H, D):
+    """attn_mfma.hip is built with -fno-honor-nans (no v_max canonicalisation): a NaN / Inf in q, k or v of a diverged step must
+    still reach o, lse and the gradients -- train_one_epoch's only divergence guard is math.isfinite(loss) (engine.py:170-173)."""
+    B = 2
+    scale = D ** -0.5
+    keep = torch.tensor([H * D, H * D], dtype=torch.int32, device=DEV)
+    for bad, where in ((float("nan"), 0), (float("inf"), H * D), (float("nan"), 2 * H * D)):        # q, k, v of head 0
+        qkv = rnd(B, N, 3 * H * D, seed=1).to(torch.bfloat16).to(DEV)
+        qkv[1, N // 2, where + 3] = bad
+        o, lse = K.attn_fwd(qkv, keep, B, N, H, D, scale)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o[0].float()).all() and torch.isfinite(lse[0]).all()             # the other sample is untouched
+        assert not torch.isfinite(o[1, :, :D].float()).all(), (bad, where)
+        d_o = rnd(B, N, H * D, seed=2).to(torch.bfloat16).to(DEV)
+        dq = K.attn_bwd(qkv, o, d_o, lse, keep, B, N, H, D, scale)
+        assert not torch.isfinite(dq[1].float()).all(), (bad, where)
+        assert torch.isfinite(dq[0].float()).all()
 
 
 def test_softce():
@@ -537,7 +564,7 @@ def test_gemm_masked_work_skipping(dtype):
               keep_k=ak, k_period=HD, keep_n=ek)
     ref = E.gemm(dqkv, y, out.clone(), bias_grad=bg_ref, **kw)
     real = K.gemm(dqkv.to(DEV), y.to(DEV), out.to(DEV), bias_grad=bg, **{k: to(v) for k, v in kw.items()})
-    assert relerr(real, ref) < (5e-5 if dtype == torch.float32 else 1.2e-2)
+    assert relerr(real, ref) < (5e-5 if dtype == torch.float32 else 1e-4)
     assert relerr(bg, bg_ref) < 2e-4
     # residual epilogue with a fully masked sample (layer drop: keep 0) and prefix keep_k
     ok = torch.tensor([256, 0, 256, 64, 0, 160], dtype=torch.int32)
@@ -548,7 +575,7 @@ def test_gemm_masked_work_skipping(dtype):
     kw = dict(M=M, N=C, K=HD, lda=HD, ldb=HD, ldc=C, bias=rnd(C, seed=8), scale=scale, keep_n=ok, resid=resid, rows_in=Nt, keep_k=ak)
     ref = E.gemm(o, wp, torch.zeros(M, C), **kw)
     real = K.gemm(o.to(DEV), wp.to(DEV), torch.full((M, C), 7.0, device=DEV), **{k: to(v) for k, v in kw.items()})
-    assert relerr(real, ref) < tol(dtype)
+    assert relerr(real, ref) < tol32(dtype)
 
 
 @pytest.mark.parametrize("Cin,Cout", [(24, 24), (32, 32), (16, 24), (24, 8)])
@@ -829,7 +856,7 @@ def test_gemm_group_equals_the_launches_one_by_one(T, C, F, HD):
     torch.cuda.synchronize()
     for (dw_g, db_g), (dw_1, db_1, _), (_, _, dw_ref, kwr) in zip(outs_gpu, outs_one, calls_cpu):
         assert relerr(dw_g, dw_1) < 1e-5 and relerr(db_g, db_1) < 1e-5          # same kernel body, same split rule apart
-        assert relerr(dw_g, dw_ref) < 1.2e-2 and relerr(db_g, kwr["bias_grad"]) < 1.2e-2
+        assert relerr(dw_g, dw_ref) < 1e-4 and relerr(db_g, kwr["bias_grad"]) < 2e-4      # fp32 results of bf16 operands
 
 
 @pytest.mark.parametrize("M,C,F", [(257 * 4, 256, 768), (65 * 3, 128, 392)])

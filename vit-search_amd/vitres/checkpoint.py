@@ -1,5 +1,5 @@
 """Checkpoints in the reference's own layout (main.py:400-424,496-515): one dict
-    {'model', 'optimizer', 'lr_scheduler', 'epoch', 'args'[, 'model_ema']}
+    {'model', 'optimizer', 'lr_scheduler', 'epoch', 'args'[, 'model_ema'][, 'vitres_rng']}
 written with torch.save as `checkpoint.pth.tar` (+ `epoch@E_checkpoint.pth.tar` every tenth epoch), so that runs move between
 the reference and this stack in either direction.  'model' / 'model_ema' use the reference's state_dict keys;
 'optimizer' is torch.optim.AdamW's layout -- vitres.optim.FlatAdamW converts to and from its arena-shaped moments.
@@ -33,6 +33,10 @@ def checkpoint_dict(model, optimizer, lr_scheduler, epoch, args=None, model_ema=
            'lr_scheduler': lr_scheduler.state_dict() if lr_scheduler is not None else {}, 'epoch': epoch, 'args': args}
     if model_ema is not None:
         out['model_ema'] = _cpu(model_ema if isinstance(model_ema, dict) else model_ema.state_dict())
+    if hasattr(model, 'drop_path_rng_state'):
+        # one key beyond the reference's layout (its loaders index by name and ignore it): the DropPath draws of this stack come
+        # from a private CPU generator, so a resumed run continues the same noise stream
+        out['vitres_rng'] = {'drop_path': model.drop_path_rng_state()}
     return out
 
 
@@ -61,6 +65,8 @@ def resume(path_or_dict, model, optimizer=None, lr_scheduler=None, eval_mode=Fal
         if lr_scheduler is not None:
             lr_scheduler.load_state_dict(ck['lr_scheduler'])
         start = ck['epoch'] + 1
+        if 'vitres_rng' in ck and hasattr(model, 'set_drop_path_rng_state'):
+            model.set_drop_path_rng_state(ck['vitres_rng']['drop_path'])
         if 'model_ema' in ck:
             if load_ema is not None:
                 load_ema(ck['model_ema'])

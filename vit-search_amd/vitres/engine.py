@@ -215,8 +215,9 @@ class GraphedTrainStep:
     """forward + loss + backward of one iteration captured ONCE into a hipGraph and replayed every step
     (the step issues ~600 kernel launches; replay removes their host cost).  What changes between iterations goes
     through static device buffers: the batch, the soft targets, and the int32 keep rows of every ChannelDrop, which
-    are still sampled on the host with the reference's RNG protocol before each replay.  DropPath noise comes from
-    torch's graph-safe device generator.  The gradient exchange and the optimizer stay outside the graph."""
+    are still sampled on the host with the reference's RNG protocol before each replay, and the DropPath scale vectors, drawn
+    from the model's private CPU generator (model.drop_path_generator(): seeded from torch.initial_seed() + rank, saved and
+    restored with the checkpoint's RNG bundle).  The gradient exchange and the optimizer stay outside the graph."""
 
     def __init__(self, model, criterion, samples, targets, patch_targets=None, patch_output_type=None, warmup=2,
                  split_for_sync=False, optimizer=None):
@@ -380,6 +381,7 @@ class GraphedTrainStep:
             if self.pt is not None:
                 self.pt.copy_(patch_targets, non_blocking=True)
         self.graph.replay()
+        self.model._stem_fold = None                               # (stem.drop_fold: the replay moved BatchNorm's running statistics)
         for k, g in enumerate(self.more_graphs):
             if self._sync is not None:                            # the arena range of the part just replayed is final: exchange it now
                 self._works.append(self._sync.all_reduce_range(*self.ranges[k]))

@@ -65,9 +65,12 @@ def flush_ln_grads():
 
 
 def reset_ln_grads():
-    """Drop slots left behind by a backward that raised; returns True if there were any (their rows need re-zeroing)."""
+    """Drop slots left behind by a backward that raised; returns True if there were any (their rows need re-zeroing).  The
+    weight-gradient calls collected for a block that was never flushed go with them: launched by the next backward they
+    would add a dead step's gradients and keep its tensors alive."""
     dirty = bool(_ln_pending)
     _ln_pending.clear()
+    del _block_wgrads[:]
     return dirty
 
 

@@ -80,13 +80,13 @@ class ChannelDrop(nn.Module):
             return np.array([channels], dtype=np.int64)
         if self.table is None:
             self._build_table(batch, channels)
-            self._table_np = self.table.numpy()
+        tab = self.table.numpy()           # zero-copy view (the table may also have been built by sample_keep)
         perm = torch.randperm(self.table.shape[0]).numpy()
         if self.single_arch:
-            return self._table_np[perm[0:1]]
+            return tab[perm[0:1]]
         assert batch % self.example_per_arch == 0, \
             'In forward(), batch size is not divisible by sub-batch size (examples per arch).'
-        return self._table_np[perm[:batch // self.example_per_arch]]
+        return tab[perm[:batch // self.example_per_arch]]
 
     def forward(self, x):
         raise RuntimeError('ChannelDrop has no standalone device op in the HIP path: its multiply is fused into the '

@@ -291,6 +291,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         vitres.optim.FlatAdamW maintains the bf16 weight shadow: re-casts it right away (forwards then skip their own cast,
         also inside a captured hipGraph)."""
         a = self._arena
+        self._stem_fold = None             # BatchNorm-folded evaluation stem (stem.drop_fold)
         if a is not None:
             a["shadow_ver"] = None
         if a is not None and a.get("shadow_ok") and a["flat"].is_cuda:
@@ -516,12 +517,29 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             if plan.order is not None:
                 noise = noise[:, np.asarray(plan.order)]
         else:
-            gen = getattr(self, "_dp_gen", None)
-            if gen is None:
-                gen = self._dp_gen = torch.Generator(device="cpu")
-                gen.manual_seed((torch.initial_seed() * 2654435761 + 97) % (2 ** 63))
-            noise = torch.rand(plan.n_dp, B, generator=gen).numpy()
+            noise = torch.rand(plan.n_dp, B, generator=self.drop_path_generator()).numpy()
         return (np.floor(kp + noise.astype(np.float32)) / kp).astype(np.float32)
+
+    def drop_path_generator(self, seed=None):
+        """The private CPU generator the DropPath draws come from (the reference draws them on the device, nets/drop.py:23 --
+        never from the CPU generator the ChannelDrops consume).  Seeded on first use from torch.initial_seed() and the
+        data-parallel rank, so that ranks draw different noise also when `arch_sample='single'` re-seeds the global generator
+        identically everywhere; `seed` re-seeds it explicitly.  Its state is part of vitres.checkpoint's RNG bundle
+        (drop_path_rng_state / set_drop_path_rng_state): a resumed run continues the same noise stream."""
+        gen = getattr(self, "_dp_gen", None)
+        if gen is None or seed is not None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+            base = torch.initial_seed() if seed is None else int(seed)
+            gen = self._dp_gen = torch.Generator(device="cpu")
+            gen.manual_seed(((base + rank) * 2654435761 + 97) % (2 ** 63))
+        return gen
+
+    def drop_path_rng_state(self):
+        return self.drop_path_generator().get_state()
+
+    def set_drop_path_rng_state(self, state):
+        self.drop_path_generator().set_state(state)
 
     def _order_tensors(self, order, device):
         cache = getattr(self, "_order_cache", None)
@@ -821,6 +839,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             a["gcur"].zero_()
         a["gzeroed"] = False
         Fn.join_side()                     # transposed weight shadows (issued beside the forward)
+        del Fn._block_wgrads[:]            # (weight gradients a dead backward collected and never launched)
         if Fn.LN_COPIES > 1:
             self._ln_parts()
             if Fn.reset_ln_grads():        # a backward died between a LayerNorm kernel and flush_ln_grads()

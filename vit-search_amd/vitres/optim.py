@@ -71,6 +71,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if g is None or p0.grad is None or p0.grad.data_ptr() != g.data_ptr() + 4 * a["offsets"][0][0]:
             raise RuntimeError("FlatAdamW needs the gradients in the model's flat arena (one backward since zero_grad)")
         self._step += 1
+        self.model._stem_fold = None           # parameters change through raw pointers: no Tensor._version moves (stem.drop_fold)
         arr = self._group_structs(self._step)
         st = self._flat_state
         shadow = a["shadow"] if self.model.compute_dtype == torch.bfloat16 else None
@@ -99,6 +100,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if getattr(self, "_hp_dev", None) is None or self._hp_dev.device != dev:
             self._hp_dev = torch.zeros(MAX_GROUPS * 8, dtype=torch.float32, device=dev)
         self._step += 1
+        self.model._stem_fold = None           # parameters change through raw pointers: no Tensor._version moves (stem.drop_fold)
         arr = self._group_structs(self._step)
         vals = []
         for gi in range(len(self.param_groups)):
@@ -123,6 +125,7 @@ class FlatAdamW(torch.optim.Optimizer):
             raise ValueError("range must be non-empty and aligned to 8 elements")
         st = self._flat_state
         shadow = a["shadow"] if self.model.compute_dtype == torch.bfloat16 else None
+        self.model._stem_fold = None           # (stem.drop_fold)
 
         def at(t, esz):
             return None if t is None else t.data_ptr() + lo * esz

@@ -77,8 +77,17 @@ DIRECT_CONV1 = __import__("os").environ.get("VITRES_STEM_DIRECT_CONV1", "1") != 
 Z_BF16 = __import__("os").environ.get("VITRES_STEM_Z_BF16", "0") != "0"
 
 
+def drop_fold(model):
+    """Forget the BatchNorm-folded evaluation weights (anything that may have changed a stem parameter or running statistic calls
+    this: a training-mode forward of the stem, a replay of a captured training step, an optimizer step, invalidate_shadow)."""
+    model._stem_fold = None
+
+
 def _folded_params(model):
-    """bf16 [(w1', t1), (w2', t2), (w3', t3)] with BatchNorm folded in; cached until a parameter / buffer of the stem changes."""
+    """bf16 [(w1', t1), (w2', t2), (w3', t3)] with BatchNorm folded in.  Cached between evaluation forwards; the cache is dropped
+    by drop_fold() -- Tensor._version alone is NOT a valid key: FlatAdamW updates the parameters through raw pointers and a
+    replayed hipGraph updates the running statistics without touching either version counter (both are still compared, for
+    in-place edits through torch)."""
     pe = model.patch_embed
     convs = (pe.conv1, pe.conv2, pe.conv3)
     ver = tuple(t._version for c in convs for t in (c.conv.weight, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var))
@@ -142,6 +151,8 @@ def embed_conv_fwd(model, x, p, cfg, keep, save):
     T = cfg.get("tokens", 1)
     N = P + T
     tr = model.training
+    if tr:
+        drop_fold(model)                   # this forward moves the running statistics
 
     zdt = dt if (Z_BF16 and dt == torch.bfloat16) else torch.float32
 
