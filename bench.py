@@ -217,6 +217,8 @@ def main():
                     "next one; 0/1: one graph, one all-reduce; -1: 3 when --gpus > 1 (only ~24 MB of the 279 MB are exchanged after the "
                     "backward has finished, against ~116 MB with 2 graphs; +0.2 ms of graph boundaries measured on one GPU; not yet timed "
                     "over RCCL -- no multi-GPU box was available)")
+    ap.add_argument("--wire", default="f32", choices=["f32", "bf16"], help="dtype of the gradients on the wire (N > 1): bf16 halves "
+                    "the bytes of the exchange (engine.GradSync(wire_dtype=torch.bfloat16)); the default is the reference's fp32")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -261,7 +263,7 @@ def main():
     B = args.batch or w["batch"]
     torch.manual_seed(0 + rank)                                    # reference: seed + rank (main.py:261-267)
     model, nd = build_model(args.workload, dtype, device)
-    sync = engine.GradSync(model)
+    sync = engine.GradSync(model, wire_dtype=torch.bfloat16 if args.wire == "bf16" else torch.float32)
     x, t, pt = synthetic_batch(B, device, 1000 + rank)
     model.train()
     if w["space"]:
@@ -357,8 +359,8 @@ def main():
         exposed = None
         if graphed is not None and getattr(graphed, "exposed", None):
             exposed = round(sum(a.elapsed_time(b) for a, b in graphed.exposed) / len(graphed.exposed), 3)
-        exchange = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "allreduce_bytes_per_step": 4 * n_arena,
-                    "dtype": "f32", "ranges": (len(graphed.ranges) if graphed is not None and graphed.ranges else 1),
+        exchange = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "allreduce_bytes_per_step": (2 if args.wire == "bf16" else 4) * n_arena,
+                    "dtype": args.wire, "ranges": (len(graphed.ranges) if graphed is not None and graphed.ranges else 1),
                     "exposed_ms_per_step": exposed,
                     "note": "exposed = GPU time between the end of the last backward graph and the end of the last all-reduce "
                             "(rank 0, HIP events on the compute stream)"}

@@ -860,9 +860,33 @@ def f18_droppath_fullsize_c4():
         del m
 
 
+def f19_flops():
+    """ComputationEstimator(return_mac=False): FLOP counts (multiply-adds x 2, biases, softmax / LayerNorm / GELU / residual
+    terms, compute_flop_mac.py:53-194) of the five shipped network_defs with and without the distillation token, of the
+    micro candidates at 56 px, and of the README's patch-16 ViT-T example."""
+    import io
+    import contextlib
+    out = {}
+    nets = {"ref_tiny": recipe.REF_TINY_DEF, "sr_tiny": recipe.SR_TINY_DEF, "sr_small": recipe.SR_SMALL_DEF,
+            "sr_tiny_mh": recipe.SR_TINY_MH_DEF, "sr_small_mh": recipe.SR_SMALL_MH_DEF}
+    with contextlib.redirect_stdout(io.StringIO()):
+        for name, nd in nets.items():
+            for distill in (False, True):
+                est = R.flop.ComputationEstimator(distill=distill, input_resolution=224, patch_size=14, return_mac=False)
+                out["%s.flops%s" % (name, "_distill" if distill else "")] = est(nd)
+        for i, nd in enumerate(recipe.MICRO_CANDIDATES):
+            est = R.flop.ComputationEstimator(distill=False, input_resolution=56, patch_size=14, return_mac=False)
+            out["micro_cand%d.flops" % i] = est(nd)
+        vit_t = ((0, 192),) + ((1, (192, 3, 64), (192, 768), 1),) * 12 + ((2, 192, 1000),)
+        for mac in (True, False):
+            est = R.flop.ComputationEstimator(distill=True, input_resolution=224, patch_size=16, return_mac=mac)
+            out["vit_t_p16." + ("macs" if mac else "flops")] = est(vit_t)
+    save("f19_flops", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15", "f16", "f17", "f18"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14", "f15", "f16", "f17", "f18", "f19"]
     table = dict(f1=f1_micro, f2=f2_masked_ln, f3=f3_channel_drop, f4=f4_fullsize, f5=f5_subnet,
-                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init, f13=f13_evolver, f14=f14_distill_token, f15=f15_distillation_engine, f16=f16_vit16, f17=f17_ra_sampler, f18=f18_droppath_fullsize_c4)
+                 f6=f6_schema_and_macs, f7=f7_rewiring, f8=f8_engine, f9=f9_patch_avg, f10=f10_token_mix, f11=f11_pos_embed_interp, f12=f12_init, f13=f13_evolver, f14=f14_distill_token, f15=f15_distillation_engine, f16=f16_vit16, f17=f17_ra_sampler, f18=f18_droppath_fullsize_c4, f19=f19_flops)
     for w in which:
         table[w]()

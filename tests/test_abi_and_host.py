@@ -27,6 +27,23 @@ def test_library_exports_every_declared_symbol():
     assert lib.vr_version() >= 1000
 
 
+def test_flop_mode_of_the_estimator_matches_reference():
+    """ComputationEstimator(return_mac=False) (compute_flop_mac.py:53-194, 227-307) -- fixture F19: exact integers."""
+    g = np.load(os.path.join(G, "f19_flops.npz"))
+    nets = {"ref_tiny": recipe.REF_TINY_DEF, "sr_tiny": recipe.SR_TINY_DEF, "sr_small": recipe.SR_SMALL_DEF,
+            "sr_tiny_mh": recipe.SR_TINY_MH_DEF, "sr_small_mh": recipe.SR_SMALL_MH_DEF}
+    for name, nd in nets.items():
+        for distill in (False, True):
+            est = ComputationEstimator(distill=distill, input_resolution=224, patch_size=14, return_mac=False)
+            assert est(nd) == int(g["%s.flops%s" % (name, "_distill" if distill else "")]), (name, distill)
+    for i, nd in enumerate(recipe.MICRO_CANDIDATES):
+        assert ComputationEstimator(False, 56, 14, return_mac=False)(nd) == int(g["micro_cand%d.flops" % i])
+    vit_t = ((0, 192),) + ((1, (192, 3, 64), (192, 768), 1),) * 12 + ((2, 192, 1000),)
+    assert ComputationEstimator(True, 224, 16)(vit_t) == int(g["vit_t_p16.macs"]) == 1261003776       # the reference's own print
+    assert ComputationEstimator(True, 224, 16, return_mac=False)(vit_t) == int(g["vit_t_p16.flops"])
+    assert "return_mac=False" in repr(ComputationEstimator(True, 224, 16, return_mac=False))
+
+
 def test_search_spaces_and_macs_match_reference():
     g = np.load(os.path.join(G, "f6_schema_macs.npz"))
     est = ComputationEstimator(distill=False, input_resolution=224, patch_size=14)

@@ -88,6 +88,28 @@ def _worker(rank, world, port, out_dir):
     sync.finish(works)
     g_split3 = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
     model.zero_grad(set_to_none=True)
+    # the same three-part exchange with bf16 on the wire (GradSync(wire_dtype=torch.bfloat16)): half the bytes per link
+    sync16 = engine.GradSync(model, wire_dtype=torch.bfloat16)
+    torch.random.set_rng_state(rng)
+    cls, pat = model(x, patch_output_type="seq")
+    model._bwd_split = [c for c, _ in cuts]
+    (crit(cls, t) + crit(pat, pt)).backward()
+    model._bwd_split = None
+    works, end = [], model._arena["gcur"].numel()
+    for _, st in cuts:
+        works.append(sync16.all_reduce_range(st, end))
+        end = st
+        model.resume_backward()
+    works.append(sync16.all_reduce_range(0, end))
+    sync16.finish(works)
+    g_bf16 = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    model.zero_grad(set_to_none=True)
+    torch.random.set_rng_state(rng)
+    cls, pat = model(x, patch_output_type="seq")
+    (crit(cls, t) + crit(pat, pt)).backward()
+    sync16.all_reduce_grads()                                       # ... and as one blocking call
+    g_bf16_one = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    model.zero_grad(set_to_none=True)
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
     torch.random.set_rng_state(rng)
     engine.train_step(model, crit, opt, x, t, pt, "seq", epoch=31, train_iter=0, arch_sample="multi", grad_sync=sync)
@@ -102,7 +124,7 @@ def _worker(rank, world, port, out_dir):
                       loss_scaler=Scaler())
     p2 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
     torch.save({"p0": p0, "p1": p1, "p2": p2, "g_local": g_local, "g_sync": g_sync, "keeps": keeps, "g_split": g_split,
-                "g_split3": g_split3}, os.path.join(out_dir, "r%d.pt" % rank))
+                "g_split3": g_split3, "g_bf16": g_bf16, "g_bf16_one": g_bf16_one}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -124,6 +146,15 @@ def test_two_rank_gradient_exchange(tmp_path):
     assert float((r0["g_split"] - r0["g_sync"]).abs().max() / r0["g_sync"].abs().max()) < 1e-6
     assert torch.equal(r0["g_split3"], r1["g_split3"]) and torch.equal(r0["g_split3"], r0["g_split"])
     assert torch.equal(r0["p2"], r1["p2"]) and not torch.equal(r0["p2"], r0["p1"])      # loss_scaler + grad_sync: replicas stay equal
+    # bf16 on the wire: both ranks hold the same values; against the fp32 exchange every element is within three bf16 roundings
+    # (unit roundoff u = 2^-8: each rank's value, then their sum -- at most u (|a| + |b| + |a + b|) / 2 <= 2 u mean(|a|, |b|) on the
+    # averaged gradient), and within 2^-8 in the L2 norm
+    assert torch.equal(r0["g_bf16"], r1["g_bf16"]) and torch.equal(r0["g_bf16"], r0["g_bf16_one"])
+    ref16 = r0["g_split3"]
+    scale = 0.5 * (r0["g_local"].abs() + r1["g_local"].abs())
+    assert float(((r0["g_bf16"] - ref16).abs() - 2 * 2.0 ** -8 * scale).max()) <= 1e-9
+    assert float((r0["g_bf16"] - ref16).norm() / ref16.norm()) < 2.0 ** -8
+    assert not torch.equal(r0["g_bf16"], ref16)
 
 
 def _buffer_worker(rank, world, port, out_dir):

@@ -57,9 +57,19 @@ class GradSync:
     (reference DDP constructor, main.py:367) and, every step, the flat gradient arena is all-reduced
     (sum) and scaled by 1/world -- one RCCL call over xGMI instead of DDP's 25 MB buckets."""
 
-    def __init__(self, model):
+    def __init__(self, model, wire_dtype=torch.float32):
+        """wire_dtype=torch.bfloat16: the gradients cross xGMI as bf16 -- half the bytes of the exchange the ring pays per link
+        (279 MB of fp32 per step for sr_tiny).  Every range is rounded to bf16 into a persistent wire buffer,
+        all-reduced there (RCCL sums bf16 in bf16: each of the world - 1 additions rounds once more) and written back to the fp32
+        arena by finish(); AdamW's moments and the master weights stay fp32.  Error of an averaged gradient element against the
+        fp32 exchange: at most world bf16 roundings (unit roundoff 2^-8) of the operands' mean magnitude; tests/test_dist_gloo.py
+        pins it at world 2: every element within 2 * 2^-8 * mean(|g_rank|), the whole arena within 2^-8 in the L2 norm.
+        The default stays fp32 -- the reference's DDP reduces fp32 gradients (main.py:366-367)."""
         self.model = model
         self.world = world_size()
+        self.wire_dtype = wire_dtype
+        self._wire = None
+        self._ranges = []
 
     def broadcast_parameters(self):
         if self.world == 1:
@@ -101,7 +111,26 @@ class GradSync:
         on one rank).  RCCL runs it on the process group's stream after everything queued so far on the current one."""
         if self.world == 1 or hi <= lo:
             return None
-        return dist.all_reduce(self.model._arena["gcur"][lo:hi], async_op=True)
+        g = self.model._arena["gcur"]
+        if self.wire_dtype == torch.float32:
+            return dist.all_reduce(g[lo:hi], async_op=True)
+        wire = self._wire_buffer(g)
+        self._to_wire(g[lo:hi], wire[lo:hi])
+        self._ranges.append((lo, hi))
+        return dist.all_reduce(wire[lo:hi], async_op=True)
+
+    def _wire_buffer(self, g):
+        if self._wire is None or self._wire.numel() != g.numel() or self._wire.device != g.device:
+            self._wire = torch.empty(g.numel(), dtype=self.wire_dtype, device=g.device)
+        return self._wire
+
+    @staticmethod
+    def _to_wire(src, dst):
+        if src.is_cuda and dst.dtype == torch.bfloat16:
+            from . import kernels as K
+            K.cast_bf16(src, dst)              # vr_cast_f32_bf16: round-to-nearest-even, 16-byte accesses
+        else:
+            dst.copy_(src)
 
     def finish(self, works, average=True):
         """Wait for all_reduce_range handles and apply the 1/world averaging (average=False leaves the SUM: an optimizer
@@ -111,8 +140,16 @@ class GradSync:
         for w in works:
             if w is not None:
                 w.wait()
+        g = self.model._arena["gcur"]
+        if self._ranges:                       # bf16 wire: summed ranges back into the fp32 arena (averaging folded in)
+            for lo, hi in self._ranges:
+                g[lo:hi].copy_(self._wire[lo:hi])
+                if average:
+                    g[lo:hi].mul_(1.0 / self.world)
+            self._ranges = []
+            return
         if average:
-            self.model._arena["gcur"].mul_(1.0 / self.world)
+            g.mul_(1.0 / self.world)
 
     def all_reduce_grads(self, average=True):
         if self.world == 1:
@@ -121,6 +158,8 @@ class GradSync:
         g = a.get("gcur") if a is not None else None
         p0 = a["params"][0] if a is not None else None
         if g is not None and p0.grad is not None and p0.grad.data_ptr() == g.data_ptr() + 4 * a["offsets"][0][0]:
+            if self.wire_dtype != torch.float32:
+                return self.finish([self.all_reduce_range(0, g.numel())], average=average)
             dist.all_reduce(g)                                    # .grad tensors are views of the flat arena
             if average:
                 g.mul_(1.0 / self.world)
