@@ -215,8 +215,8 @@ def test_c5_sr_small_candidates_on_resident_supernet_match_sliced_subnets():
     sup = sup.to(DEV).eval()
     est = ComputationEstimator(distill=False, input_resolution=224, patch_size=14)
     np.random.seed(3)
-    cands = [gen_utils.gen_random_network_def(sp.network_def, sp.num_channels_to_keep, 2.9e9, est) for _ in range(3)]
-    assert all(0.975 * 2.9e9 <= est(c) <= 2.9e9 for c in cands)
+    cands = [gen_utils.gen_random_network_def(sp.network_def, sp.num_channels_to_keep, 2.9e9, est) for _ in range(8)]
+    assert all(0.975 * 2.9e9 <= est(c) <= 2.9e9 for c in cands) and len({str(c) for c in cands}) == 8
     assert any(any(e[0] == 1 and not e[3] for e in c) for c in cands) or True          # (removed blocks occur in most draws)
     x, _, _, labels = recipe.inputs(31, 4, 224, 1000, 16)
     for ci, nd in enumerate(cands):
@@ -234,4 +234,4 @@ def test_c5_sr_small_candidates_on_resident_supernet_match_sliced_subnets():
                 got = sup(x.to(DEV), plan=evo_eval.plan_for_subnet(sup, nd, 4))
             assert rel(got, want) < tol, (ci, dt, rel(got, want))
     scores = evo_eval.score_population(sup, cands, [(x.to(DEV), labels.to(DEV))])
-    assert len(scores) == 3 and all(0.0 <= s_ <= 100.0 for s_ in scores)
+    assert len(scores) == 8 and all(0.0 <= s_ <= 100.0 for s_ in scores)

@@ -132,7 +132,15 @@ def _launch_gemm_ln(args, ln, a, M, N, K, rows_in, keep_k, keep_n, k_period, ext
     e0.record()
     _lib.check(_lib.lib().vr_gemm_ln(ctypes.byref(args), ctypes.byref(ln), _stream()), "vr_gemm_ln")
     e1.record()
-    PROFILE.append((("bf16", 0, 0, 2), flops, 2.0 * M * N * K, float((M * K + N * K) * 2 + extra_bytes), e0, e1))
+    # algorithmic bytes from the KEPT widths, like _gemm_work: sample b reads rows x kept K of A; the weights once for the widest
+    # sample; the row-wide side tensors (residual stream, LayerNorm output ...) in full
+    if keep_k is not None and rows_in > 0:
+        kk = torch.clamp(keep_k.detach().to("cpu", torch.float64), max=k_period) * (K // k_period) if k_period else \
+            torch.clamp(keep_k.detach().to("cpu", torch.float64), max=K)
+        a_bytes, k_w = float((rows_in * kk).sum()) * 2, float(kk.max())
+    else:
+        a_bytes, k_w = float(M) * K * 2, float(K)
+    PROFILE.append((("bf16", 0, 0, 2), flops, 2.0 * M * N * K, a_bytes + N * k_w * 2 + extra_bytes, e0, e1))
     if PROFILE_DESC is not None:
         PROFILE_DESC.append("ln%d M%d N%d K%d" % (ln.mode, M, N, K))
 
