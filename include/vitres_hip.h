@@ -88,7 +88,10 @@ typedef struct vr_gemm_args {
                             saved-derivative form of the same pair: forward (no dact_u) C = gelu'(u), C2 = gelu(u); data gradient
                             (dact_u given) multiplies by dact_u as it is -- no transcendental in the backward epilogue;
                             3 relu, single store: C = max(u, 0) (no C2 / dact_u) */
-    int32_t atomic;      /* 1: atomicAdd fp32 */
+    int32_t atomic;      /* 1: atomicAdd into fp32 C; 2 (weight-gradient form, bf16 operands, 8-element aligned leading dimensions):
+                            C and bias_grad are OVERWRITTEN by plain stores -- every output tile is computed by one workgroup over
+                            the whole token range (split_k <= 1), fully masked tiles write zeros, the destination need not be
+                            zero-filled; VR_EUNSUPPORTED where only the atomic kernels cover the form */
     int32_t split_k;     /* >= 1 */
     int32_t rows_in;     /* rows per sample of the M index (0: single sample); wgrad: tokens per sample of the K index */
     int32_t n_period;    /* > 0: column n is kept iff (n % n_period) < keep_n[s] (per-head prefixes of the qkv layout) */
@@ -337,6 +340,19 @@ int vr_sr_col2im(const void* dcol, void* dy, int32_t B, int32_t g, int32_t C, in
 int vr_sr_resid(const float* x, float* out, int32_t B, int32_t g, int32_t Cin, int32_t Cout, int32_t num_tokens, vr_stream_t stream);
 int vr_sr_resid_bwd(const float* dout, float* dx, int32_t B, int32_t g, int32_t Cin, int32_t Cout,
                     int32_t accumulate, int32_t num_tokens, vr_stream_t stream);
+
+/*
+ * Zero-fill ranges [lo[i], lo[i] + count[i]) (elements) of one fp32 buffer in one launch: optimizer.zero_grad() of the flat
+ * gradient arena (reference engine.py:175) minus the spans whose weight gradients are written in store form (vr_gemm atomic == 2).
+ */
+#define VR_MAX_ZERO_RANGES 24
+typedef struct vr_range_list {
+    int64_t lo[VR_MAX_ZERO_RANGES];
+    int64_t count[VR_MAX_ZERO_RANGES];
+    int32_t n;
+    int32_t reserved;
+} vr_range_list;
+int vr_zero_ranges(float* base, const vr_range_list* ranges, vr_stream_t stream);
 
 /* x[m, c] = 0 for c >= keep[sample(m)]  (ChannelDrop.forward `x * mask`, nets/channel_drop.py:82) */
 int vr_mask_rows(float* x, const int32_t* keep, int32_t M, int32_t C, int32_t rows_per_sample, vr_stream_t stream);

@@ -37,7 +37,10 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
         Bm = B2[_rows(K, b_map if a_trans else None)][:, :N].float().t()
     v = Am @ Bm.t()
     if bias_grad is not None:
-        bias_grad += Am.sum(dim=1)
+        if atomic == 2:                     # store form of the weight gradient: C and the bias gradient are overwritten
+            bias_grad.copy_(Am.sum(dim=1))
+        else:
+            bias_grad += Am.sum(dim=1)
     if atomic and a_trans:                  # wgrad form: rows_in / keep_* describe the contraction tokens (hints only)
         rows_in, keep_n, scale = 0, None, None
     m_idx = torch.arange(M)
@@ -79,6 +82,9 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
     v = torch.where(nmask, v, torch.zeros_like(v))
     if scale is not None:
         v = v * scale[sample].view(M, 1)
+    if atomic == 2:
+        C2d[orow, :N] = v
+        return out
     if atomic:
         C2d[orow, :N] += v
         return out
@@ -427,7 +433,13 @@ def patch_fold(col, B, gh, gw, P, C):
 
 
 ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "gemm_group", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "ln_grad_reduce", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "softce_train", "colsum", "scale_mask_cast",
-       "batchsum", "conv3x3", "conv1_direct", "conv1_direct_supported", "conv3x3_bias_relu", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows"]
+       "batchsum", "conv3x3", "conv1_direct", "conv1_direct_supported", "conv3x3_bias_relu", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows", "zero_ranges"]
+
+
+def zero_ranges(buf, ranges):
+    for lo, hi in ranges:
+        buf[int(lo):int(hi)] = 0
+    return buf
 
 
 def install(monkeypatch):

@@ -68,7 +68,8 @@ def test_checkpoint_dict_layout_resume_and_eval_with_ema(tmp_path):
     path = checkpoint.save_checkpoint(str(tmp_path), m, opt, sched, epoch=9, args={"lr": 1e-3}, model_ema=ema)
     assert os.path.basename(path) == "checkpoint.pth.tar" and os.path.exists(os.path.join(tmp_path, "epoch@9_checkpoint.pth.tar"))
     ck = torch.load(path, map_location="cpu", weights_only=False)
-    assert set(ck) == {"model", "optimizer", "lr_scheduler", "epoch", "args", "model_ema"} and ck["epoch"] == 9
+    # the reference's six keys (main.py:506-512) + this stack's DropPath generator state (the reference's loaders index by name)
+    assert set(ck) == {"model", "optimizer", "lr_scheduler", "epoch", "args", "model_ema", "vitres_rng"} and ck["epoch"] == 9
     assert list(ck["model"].keys()) == list(m.state_dict().keys())
     assert set(ck["optimizer"]) == {"state", "param_groups"}
     torch.manual_seed(3)
@@ -77,6 +78,9 @@ def test_checkpoint_dict_layout_resume_and_eval_with_ema(tmp_path):
     got = {}
     start = checkpoint.resume(path, m2, opt2, None, load_ema=got.update)
     assert start == 10 and opt2._step == 3 and recipe.checksum(m2.state_dict()) == recipe.checksum(m.state_dict())
+    assert torch.equal(m2.drop_path_rng_state(), m.drop_path_rng_state())        # a resumed run continues the same noise stream
+    m.drop_path_generator(seed=123)
+    assert not torch.equal(m2.drop_path_rng_state(), m.drop_path_rng_state())
     assert torch.equal(opt2._flat_state["v"], opt._flat_state["v"]) and set(got) == set(ema)
     m3 = micro()
     assert checkpoint.resume(path, m3, eval_mode=True) is None                   # --eval: EMA weights, no optimizer

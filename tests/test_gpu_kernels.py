@@ -209,6 +209,45 @@ def test_gemm_wgrad(dtype, T, No, Ki, split):
     assert relerr(bg, bg_ref) < 2e-4, relerr(bg, bg_ref)       # fused bias gradient (exact sums of the stored values)
 
 
+@pytest.mark.parametrize("T,No,Ki,rps", [(2176, 3072, 1024, 17), (17 * 8, 768, 1024, 17), (65 * 6, 200, 328, 65)])
+def test_gemm_wgrad_store_form(T, No, Ki, rps):
+    """atomic == 2: dW and the bias gradient are OVERWRITTEN (one workgroup per tile over all tokens, plain stores): the
+    destination starts as NaN; tiles with no kept row / column for any sample must come back as exact zeros; alone and as
+    members of a vr_gemm_group launch beside an atomic-form problem."""
+    B = T // rps
+    dy, x = rnd(T, No, seed=1).to(torch.bfloat16), rnd(T, Ki, seed=2).to(torch.bfloat16)
+    kr = torch.tensor([max(No // 2 - 8 * (i % 3), 8) for i in range(B)], dtype=torch.int32)       # upper row tiles fully masked
+    kc = torch.tensor([max(Ki - 128 - 16 * (i % 2), 8) for i in range(B)], dtype=torch.int32)     # last column tile fully masked
+    dy = dy * (torch.arange(No)[None, :] < kr.long().repeat_interleave(rps)[:, None])
+    x = x * (torch.arange(Ki)[None, :] < kc.long().repeat_interleave(rps)[:, None])
+    kw = dict(M=No, N=Ki, K=T, lda=No, ldb=Ki, ldc=Ki, a_trans=True, b_trans=True, atomic=2, split_k=1, rows_in=rps)
+    ref, bg_ref = torch.full((No, Ki), float("nan")), torch.full((No,), float("nan"))
+    E.gemm(dy, x, ref, bias_grad=bg_ref, keep_k=kr, keep_n=kc, **kw)
+    out, bg = torch.full((No, Ki), float("nan"), device=DEV), torch.full((No,), float("nan"), device=DEV)
+    K.gemm(dy.to(DEV), x.to(DEV), out, bias_grad=bg, keep_k=kr.to(DEV), keep_n=kc.to(DEV), **kw)
+    assert torch.isfinite(out).all() and torch.isfinite(bg).all()
+    assert relerr(out, ref) < 1e-4 and relerr(bg, bg_ref) < 2e-4
+    assert float(out[int(kr.max()):].abs().max()) == 0.0 and float(out[:, int(kc.max()):].abs().max()) == 0.0
+    # grouped: [store, atomic, store]
+    outs = [torch.full((No, Ki), float("nan"), device=DEV), torch.zeros(No, Ki, device=DEV), torch.full((No, Ki), float("nan"), device=DEV)]
+    bgs = [torch.full((No,), float("nan"), device=DEV), torch.zeros(No, device=DEV), torch.full((No,), float("nan"), device=DEV)]
+    calls = []
+    for i in range(3):
+        kwi = dict(kw, atomic=(True if i == 1 else 2), split_k=(0 if i == 1 else 1), keep_k=kr.to(DEV), keep_n=kc.to(DEV), bias_grad=bgs[i])
+        calls.append((dy.to(DEV), x.to(DEV), outs[i], kwi))
+    K.gemm_group(calls)
+    torch.cuda.synchronize()
+    for o_, b_ in zip(outs, bgs):
+        assert relerr(o_, ref) < 1e-4 and relerr(b_, bg_ref) < 2e-4
+    # the ranges kernel that clears what the store form does not write
+    buf = torch.full((1000003,), 3.0, device=DEV)
+    K.zero_ranges(buf, [(0, 5), (7, 7), (13, 100001), (500002, 1000003)])
+    want = torch.full((1000003,), 3.0)
+    for lo, hi in ((0, 5), (13, 100001), (500002, 1000003)):
+        want[lo:hi] = 0
+    assert torch.equal(buf.cpu(), want)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_wgrad_rowmaps(dtype):
     B, No_, Ni, Co, C = 6, 5, 17, 64, 32

@@ -761,7 +761,11 @@ int launch(const vr_gemm_args& a, hipStream_t stream) {
 static int gemm_validate(vr_gemm_args& a) {
     if (!a.A || !a.B || !a.C) return VR_EINVAL;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return VR_EINVAL;
+    if (a.atomic < 0 || a.atomic > 2) return VR_EINVAL;
     if (a.split_k < 0 || (!a.atomic && a.split_k == 0)) a.split_k = 1;   // 0 with atomic = choose automatically
+    if (a.atomic == 2) {                                                  // store form of the weight gradient: one workgroup per tile
+        if (!(a.a_trans && a.b_trans) || a.split_k > 1) return VR_EINVAL;
+    }
     if (a.split_k > 1 && !a.atomic) return VR_EINVAL;
     if (a.atomic && a.out_dtype != VR_F32) return VR_EINVAL;
     if (a.bias_grad && !(a.a_trans && a.atomic)) return VR_EINVAL;
@@ -810,6 +814,7 @@ extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
         VR_CHECK_LAUNCH();
         return VR_OK;
     }
+    if (a.atomic == 2) return VR_EUNSUPPORTED;       // the store form exists on the bf16 LDS-DMA weight-gradient kernel only
     if (a.in_dtype == VR_BF16) return launch<bf16_t>(a, (hipStream_t)stream);
     return launch<float>(a, (hipStream_t)stream);
 }

@@ -1,4 +1,5 @@
 // bf16 weight-gradient GEMM:  C[M,N] += A[T,M]^T * B[T,N]   (fp32 atomics, split over the tokens T)
+//                         or  C[M,N]  = A[T,M]^T * B[T,N]   (atomic == 2: one workgroup per output tile, plain stores)
 //
 // Weight gradient of every nn.Linear on the ViT-Res hot path (autograd of F.linear, reference
 // nets/supernet_blocks.py:41,110): A = dY [tokens, out], B = X [tokens, in], both as the forward/backward kernels left
@@ -102,7 +103,10 @@ __device__ __forceinline__ void tn_body(const vr_gemm_args& p, const int bid) {
         const int nmax = max_keep(p.keep_n, s_lo, s_hi, 1 << 30);
         if (!range_has_kept(n0, TW, p.n_period, nmax) || !range_has_kept(m0, TW, p.k_period, kmax)) ntiles = 0;
     }
-    if (ntiles == 0) return;
+    // atomic == 2 (store form, split_k == 1): the tile's one workgroup OVERWRITES the gradient -- no zero-filled destination, no
+    // read-modify-write; a fully masked tile must then write its zeros instead of leaving
+    const bool store = p.atomic == 2;
+    if (ntiles == 0 && !store) return;
 
     // ---- LDS-DMA source addressing: piece h of this wave = slice tokens (wave*PPW + h)*TPP .. ; lane -> (token, slot) ----
     const char* gA[PPW];
@@ -199,7 +203,7 @@ __device__ __forceinline__ void tn_body(const vr_gemm_args& p, const int bid) {
             __syncthreads();
         }
     } else {
-        issue(0, 0);
+        if (ntiles > 0) issue(0, 0);
         if (ntiles > 1) issue(1, 1);
         int buf = 0;
         for (int kt = 0; kt < ntiles; ++kt) {
@@ -226,9 +230,15 @@ __device__ __forceinline__ void tn_body(const vr_gemm_args& p, const int bid) {
 #pragma unroll
             for (int j = 0; j < F; ++j) {
                 const int n = n0 + wn * (TW / 2) + 16 * j + li;
-                if (n < p.N) atomicAdd(crow + n, acc[i][j][r]);
+                if (n < p.N) {
+                    if (store) crow[n] = acc[i][j][r];
+                    else atomicAdd(crow + n, acc[i][j][r]);
+                }
             }
-            if (want_bg && li == 0) atomicAdd(p.bias_grad + m, accb[i][r]);
+            if (want_bg && li == 0) {
+                if (store) p.bias_grad[m] = accb[i][r];
+                else atomicAdd(p.bias_grad + m, accb[i][r]);
+            }
         }
 }
 
@@ -303,7 +313,7 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
         g.a[i] = args[i];
         const long long slices = (args[i].K + BT - 1) / BT;
         const long long tiles = (long long)((args[i].M + 127) / 128) * ((args[i].N + 127) / 128);
-        long long split = (slices + spw - 1) / spw;
+        long long split = args[i].atomic == 2 ? 1 : (slices + spw - 1) / spw;       // store form: one workgroup per tile
         g.a[i].split_k = (int)(split < 1 ? 1 : split);
         g.first[i] = next;
         next += (int)((tiles * g.a[i].split_k + 7) / 8 * 8);
@@ -319,6 +329,7 @@ bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_tn;
     if (!tn_covers(a0)) return false;
     vr_gemm_args a = a0;
+    if (a.atomic == 2) a.split_k = 1;
     static const int knob_s = std::getenv("VITRES_TN_S") ? std::atoi(std::getenv("VITRES_TN_S")) : 32;
     static const int knob_tw = std::getenv("VITRES_TN_TW") ? std::atoi(std::getenv("VITRES_TN_TW")) : 0;
     const long long slices = (a.K + BT - 1) / BT;

@@ -643,3 +643,39 @@ extern "C" int vr_sr_resid_bwd(const float* dout, float* dx, int32_t B, int32_t 
     VR_CHECK_LAUNCH();
     return VR_OK;
 }
+
+// ---- vr_zero_ranges: zero-fill up to VR_MAX_ZERO_RANGES ranges of one fp32 buffer in ONE launch ----
+// The gradient arena is accumulated into by atomics (weight gradients split over tokens, LayerNorm partial rows ...) and must
+// start at zero -- except the spans whose weight gradients are written in store form (vr_gemm atomic == 2): the ranges in
+// between are what this kernel clears (reference: optimizer.zero_grad(), engine.py:175).
+namespace {
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* base, const vr_range_list r) {
+    const long long lo = r.lo[blockIdx.y], n = r.count[blockIdx.y];
+    float* p = base + lo;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // head up to the first 16-byte boundary, float4 body, scalar tail
+    const long long head = min(n, (long long)((4 - ((reinterpret_cast<uintptr_t>(p) >> 2) & 3)) & 3));
+    if (i < head) p[i] = 0.f;
+    float4* p4 = reinterpret_cast<float4*>(p + head);
+    const long long n4 = (n - head) >> 2;
+    for (long long k = i; k < n4; k += stride) p4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long tail0 = head + (n4 << 2);
+    if (tail0 + i < n && i < 4) p[tail0 + i] = 0.f;
+}
+}  // namespace
+
+extern "C" int vr_zero_ranges(float* base, const vr_range_list* ranges, vr_stream_t stream) {
+    if (!base || !ranges || ranges->n <= 0 || ranges->n > VR_MAX_ZERO_RANGES) return VR_EINVAL;
+    long long most = 0;
+    for (int i = 0; i < ranges->n; ++i) {
+        if (ranges->lo[i] < 0 || ranges->count[i] < 0) return VR_EINVAL;
+        most = ranges->count[i] > most ? ranges->count[i] : most;
+    }
+    if (most == 0) return VR_OK;
+    long long bx = (most / 4 + 255) / 256;
+    bx = bx < 1 ? 1 : (bx > 2048 ? 2048 : bx);
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)bx, (unsigned)ranges->n), dim3(256), 0, (hipStream_t)stream, base, *ranges);
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}

@@ -40,6 +40,13 @@ class LnEpilogue(ctypes.Structure):
                 ("gt_out", c_void_p), ("gt_scale", c_void_p), ("gt_keep", c_void_p), ("grad_copies", c_int32)]
 
 
+MAX_ZERO_RANGES = 24
+
+
+class ZeroRanges(ctypes.Structure):
+    _fields_ = [("lo", c_int64 * MAX_ZERO_RANGES), ("count", c_int64 * MAX_ZERO_RANGES), ("n", c_int32), ("reserved", c_int32)]
+
+
 class LnGradSlot(ctypes.Structure):
     _fields_ = [("part_w", c_void_p), ("part_b", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("C", c_int32),
                 ("reserved", c_int32)]
@@ -82,6 +89,7 @@ SYMBOLS = {
     "vr_sr_resid": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
     "vr_sr_resid_bwd": [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p],
     "vr_mask_rows": [c_void_p, c_void_p] + [c_int32] * 3 + [c_void_p],
+    "vr_zero_ranges": [c_void_p, ctypes.POINTER(ZeroRanges), c_void_p],
     "vr_im2col3x3": [c_void_p, c_void_p] + [c_int32] * 8 + [c_void_p],
     "vr_col2im3x3": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
     "vr_bn_stats": [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p],

@@ -191,13 +191,28 @@ def linear_dgrad(dy, W, dx, M, N_in, K_out, lddy, lddx, **kw):
         K.gemm(dy, W.w_c, dx, M=M, N=N_in, K=K_out, lda=lddy, ldb=W.ld, ldc=lddx, b_trans=True, **kw)
 
 
+# VITRES_WGRAD_STORE=1: the weight gradients of the transformer-block Linears whose token count fits one workgroup's walk
+# (<= WGRAD_STORE_MAXT tokens: the 17-token stage at B = 128, 2176 tokens = 34 slices) are written in STORE form (vr_gemm
+# atomic == 2): one workgroup per 128 x 128 tile over all tokens, plain stores -- no fp32 read-modify-write (stage 3 paid 82 MB of
+# atomics per block for 41 MB of gradients) and no zero fill of those spans of the gradient arena (the model skips them:
+# vit_sr_supernet._zero_grad_arena).  Stage 3 has 144 ... 192 tiles per Linear, i.e. the chip is full without a token split.
+WGRAD_STORE = _os.environ.get('VITRES_WGRAD_STORE', '1') != '0'
+WGRAD_STORE_MAXT = int(_os.environ.get('VITRES_WGRAD_STORE_MAXT', '3072'))
+
+
+def wgrad_store_ok(tokens, dtype, is_cuda):
+    """The ONE rule both the block backward and the arena zero-fill apply (they must agree: a store-form span is not cleared)."""
+    return WGRAD_STORE and is_cuda and dtype == torch.bfloat16 and tokens <= WGRAD_STORE_MAXT
+
+
 def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None, db=None, keep_rows=None,
-                 keep_cols=None, row_period=0, tokens_per_sample=0, sched=0, collect=None):
+                 keep_cols=None, row_period=0, tokens_per_sample=0, sched=0, collect=None, store=False):
     """dw[N_out, K_in] += dy[M, N_out]^T @ x[M, K_in]  (fp32 atomics, split over tokens; db[N_out] += colsum(dy)).
     keep_rows / keep_cols: per-sample kept prefix of dy's / x's channels -> fully masked tiles are skipped.
-    collect: a list -> the call is appended to it instead of being launched (K.gemm_group launches the list as one kernel)."""
+    collect: a list -> the call is appended to it instead of being launched (K.gemm_group launches the list as one kernel).
+    store: dw and db are OVERWRITTEN (one workgroup per tile over all tokens, plain stores) -- see WGRAD_STORE."""
     kw = dict(M=N_out, N=K_in, K=M, lda=lddy, ldb=ldx, ldc=ldw or K_in, a_trans=True, b_trans=True,
-              atomic=True, split_k=0, a_map=a_map, b_map=b_map, bias_grad=db,
+              atomic=(2 if store else True), split_k=(1 if store else 0), a_map=a_map, b_map=b_map, bias_grad=db,
               keep_k=keep_rows, keep_n=keep_cols, k_period=row_period, rows_in=tokens_per_sample, sched=sched)
     if collect is not None:
         collect.append((dy, x, dw, kw))
@@ -284,7 +299,7 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
 
     def wgrad_proj():
         linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"], keep_rows=out_keep, keep_cols=attn_keep,
-                     tokens_per_sample=N, sched=sch, collect=grp)
+                     tokens_per_sample=N, sched=sch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
     if grp is not None:
         wgrad_proj()
         if WGRAD_EARLY:
@@ -301,7 +316,8 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
 
     def wgrad_qkv():
         linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C, db=grads["qkv.b"], keep_rows=attn_keep,
-                     keep_cols=embed_keep, row_period=HD, tokens_per_sample=N, sched=sch, collect=grp)
+                     keep_cols=embed_keep, row_period=HD, tokens_per_sample=N, sched=sch, collect=grp,
+                     store=wgrad_store_ok(M, dt, g.is_cuda))
     if grp is not None:
         wgrad_qkv()
         if not WGRAD_EARLY:
@@ -371,7 +387,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
 
     def wgrad_fc2():
         linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"], keep_rows=out_keep, keep_cols=mlp_keep,
-                     tokens_per_sample=N, sched=sch, collect=grp)
+                     tokens_per_sample=N, sched=sch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
     if ov and grp is None:
         on_side(wgrad_fc2, gt)
     else:
@@ -382,7 +398,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
 
     def wgrad_fc1():
         linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"], keep_rows=mlp_keep, keep_cols=embed_keep,
-                     tokens_per_sample=N, sched=sch, collect=grp)
+                     tokens_per_sample=N, sched=sch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
     if ov and grp is None:
         on_side(wgrad_fc1, du)
     else:

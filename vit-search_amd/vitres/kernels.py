@@ -270,6 +270,19 @@ def _gemm_work(a, out, M, N, K, a_trans, rows_in, keep_k, keep_n, k_period, n_pe
     return flops, float((rows_in * kk).sum() * esz + float(kk.max()) * float(kn.max()) * esz + M * N * osz + side)
 
 
+def zero_ranges(buf, ranges):
+    """buf[lo:hi] = 0 for every (lo, hi) of `ranges` (fp32 buffer; one launch per 24 ranges) -- vr_zero_ranges."""
+    ranges = [(int(lo), int(hi)) for lo, hi in ranges if hi > lo]
+    for i in range(0, len(ranges), _lib.MAX_ZERO_RANGES):
+        chunk = ranges[i:i + _lib.MAX_ZERO_RANGES]
+        zr = _lib.ZeroRanges()
+        zr.n = len(chunk)
+        for j, (lo, hi) in enumerate(chunk):
+            zr.lo[j], zr.count[j] = lo, hi - lo
+        _lib.check(_lib.lib().vr_zero_ranges(_p(buf), ctypes.byref(zr), _stream()), "vr_zero_ranges")
+    return buf
+
+
 def cast_bf16(src, dst):
     _lib.check(_lib.lib().vr_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "vr_cast_f32_bf16")
     return dst

@@ -379,6 +379,40 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             w_t = a["shadow_t"][off_t:off_t + m.weight.shape[1] * ld_t].view(m.weight.shape[1], ld_t)
         return Fn.Weights(m.weight, m.bias.detach() if m.bias is not None else None, w, w.shape[1], w_t, ld_t)
 
+    def _zero_grad_arena(self, buf, B):
+        """optimizer.zero_grad() of the flat gradient arena (reference engine.py:175) minus the spans the backward OVERWRITES:
+        the weight and bias gradients of the transformer-block Linears whose weight gradient runs in store form
+        (functional.wgrad_store_ok -- the same rule, from the same token count B x N of the block)."""
+        a = self._arena
+        key = (B, self.compute_dtype, buf.is_cuda, Fn.WGRAD_STORE, Fn.WGRAD_STORE_MAXT)
+        cached = a.get("zero_ranges")
+        if cached is None or cached[0] != key:
+            spans = []
+            grid = self.img_size // self.patch_size
+            for blk in self.blocks:
+                if isinstance(blk, Block):
+                    if Fn.wgrad_store_ok(B * (self.num_tokens + grid * grid), self.compute_dtype, buf.is_cuda):
+                        for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+                            for p_ in (lin.weight, lin.bias):
+                                if p_ is not None:
+                                    spans.append(a["offsets"][a["index"][id(p_)]])
+                elif isinstance(blk, SpatialReductionPatchEmbedding):
+                    grid //= 2
+            ranges, cur = [], 0
+            for off, n in sorted(spans):
+                if off > cur:
+                    ranges.append((cur, off))
+                cur = max(cur, off + n)
+            if cur < buf.numel():
+                ranges.append((cur, buf.numel()))
+            cached = a["zero_ranges"] = (key, ranges, sum(n for _, n in spans))
+        if buf.is_cuda:
+            K.zero_ranges(buf, cached[1])
+        else:
+            for lo, hi in cached[1]:
+                buf[lo:hi].zero_()
+        return cached[2]
+
     def _gview(self, p):
         a = self._arena
         off, n = a["offsets"][a["index"][id(p)]]
@@ -760,7 +794,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                         if isinstance(blk_, SpatialReductionPatchEmbedding):
                             side_params[id(blk_)] = self._layer_params(blk_)
                     if fresh:
-                        a["gflat"].zero_()
+                        self._zero_grad_arena(a["gflat"], x.shape[0])
                 Fn.on_side(side_prep)                  # enqueued (and side_params filled) by the flush_side() after the first branch
                 a["gzeroed"] = fresh
             else:
@@ -836,7 +870,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         # autograd's accumulation adds a separate buffer
         a["gcur"] = a["gflat"] if fresh else torch.zeros_like(a["flat"])
         if fresh and not a.pop("gzeroed", False):      # (the forward may have zeroed it on the side stream already)
-            a["gcur"].zero_()
+            self._zero_grad_arena(a["gcur"], plan.batch)
         a["gzeroed"] = False
         Fn.join_side()                     # transposed weight shadows (issued beside the forward)
         del Fn._block_wgrads[:]            # (weight gradients a dead backward collected and never launched)
