@@ -198,8 +198,16 @@ def run_evo_eval(args, rank, world, device):
         K.PROFILE = None
         if n:
             gbps, ach = by / sec / 1e9, fl / sec / 1e12
+            traffic, traffic_note = None, None
+            tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_evo_traffic.json")
+            if os.path.exists(tfile):
+                tj = json.load(open(tfile))
+                for fam, tv in tj["kernels"].items():
+                    if fam.startswith("vr_gemm_nt::nt_kernel"):
+                        traffic = round(tv["read_bytes_per_launch"] + tv["write_bytes_per_launch"], 1)
+                        traffic_note = "HBM-side bytes per launch (read + write) from profiles/r03_evo_traffic.json: %s" % tj["source"]
             roof = {"bound": "hbm", "kernel": "vr_gemm_nt::nt_kernel (forward)", "achieved": round(gbps, 1), "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "launches_per_step": n // args.profile_steps, "avg_launch_us": round(sec / n * 1e6, 2),
                     "flops_per_launch": fl / n, "algorithmic_bytes_per_launch": by / n,
                     "mfma_check": {"achieved_TFLOPs_kept": round(ach, 2), "peak_TFLOPs": MFMA_PEAK["bf16"],

@@ -19,6 +19,13 @@ VITRES_OVERLAP=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY
 db=$(find $out -name '*.db' | head -1)
 python $root/tools/rocpd_mfma.py $db > $root/gpurun_out/${tag}_f_mfma_busy_pmc.txt 2>&1
 rm -rf $out
+# (e) C5: HBM traffic of the candidate-scoring forward
+$root/tools/traffic_run.sh ${tag}_evo --workload evo_eval_sr_small
+# (g) per-shape table of every GEMM launch, kernels alone (single stream)
+cd $root
+VITRES_OVERLAP=0 python bench.py --no-cpu-baseline --launch-table gpurun_out/${tag}_launch_table.txt > /dev/null 2>&1
+# (h) the gate-meeting path: the same step on the exact-fp32 kernels
+python bench.py --dtype f32 --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${tag}_bench_c3_sr_tiny_f32.json
 # bench lines of the other configurations
 cd $root
 python bench.py > gpurun_out/${tag}_bench_c3_sr_tiny.json 2> gpurun_out/${tag}_bench_c3.err
@@ -26,7 +33,7 @@ python bench.py --workload ref_tiny --no-cpu-baseline 2>/dev/null | grep '^{' > 
 python bench.py --workload sr_tiny_mh_supernet --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${tag}_bench_c3p_sr_tiny_mh.json
 python bench.py --workload sr_small_supernet --no-cpu-baseline 2>/dev/null | grep '^{' > gpurun_out/${tag}_bench_c4_sr_small.json
 python bench.py --workload evo_eval_sr_small --steps 64 --warmup 8 2>/dev/null | grep '^{' > gpurun_out/${tag}_bench_c5_evo_eval.json
-for f in c3_sr_tiny c2_ref_tiny c3p_sr_tiny_mh c4_sr_small c5_evo_eval; do python -c "
+for f in c3_sr_tiny c3_sr_tiny_f32 c2_ref_tiny c3p_sr_tiny_mh c4_sr_small c5_evo_eval; do python -c "
 import json,sys
 l=[x for x in open('gpurun_out/${tag}_bench_$f.json') if x.startswith('{')]
 d=json.loads(l[-1]); print('$f', d['value'], d['ms_per_step'], (d.get('roofline') or {}).get('frac'))"; done

@@ -301,6 +301,12 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
     // one slice count per workgroup for the whole group: ~knob_fill workgroups per CU in total (2 measured best inside the
     // step: 8.52 ms against 8.61 at 4 and 8.76 at 6 -- fewer workgroups, fewer fp32 atomics), never finer than 8 slices
     // (each workgroup pays |tile| x 4 B of atomics) nor coarser than the single-launch rule (VITRES_TN_S)
+    // store-form members (atomic == 2) run one workgroup per tile over all tokens: no token split to fill the chip with, so a group
+    // of them uses 64 x 64 tiles (VITRES_TN_STORE_TW) -- four times the workgroups at the same output traffic
+    bool all_store = true;
+    for (int i = 0; i < count; ++i) all_store = all_store && args[i].atomic == 2;
+    static const int knob_stw = std::getenv("VITRES_TN_STORE_TW") ? std::atoi(std::getenv("VITRES_TN_STORE_TW")) : 64;
+    const int TWv = (all_store && knob_stw == 64) ? 64 : 128;
     long long work = 0;
     for (int i = 0; i < count; ++i)
         work += (long long)((args[i].M + 127) / 128) * ((args[i].N + 127) / 128) * ((args[i].K + BT - 1) / BT);
@@ -312,14 +318,15 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
     for (int i = 0; i < count; ++i) {
         g.a[i] = args[i];
         const long long slices = (args[i].K + BT - 1) / BT;
-        const long long tiles = (long long)((args[i].M + 127) / 128) * ((args[i].N + 127) / 128);
+        const long long tiles = (long long)((args[i].M + TWv - 1) / TWv) * ((args[i].N + TWv - 1) / TWv);
         long long split = args[i].atomic == 2 ? 1 : (slices + spw - 1) / spw;       // store form: one workgroup per tile
         g.a[i].split_k = (int)(split < 1 ? 1 : split);
         g.first[i] = next;
         next += (int)((tiles * g.a[i].split_k + 7) / 8 * 8);
     }
     for (int i = count; i <= MAXG; ++i) g.first[i] = next;
-    hipLaunchKernelGGL((tn_group_kernel<false, 128>), dim3((unsigned)next), dim3(NTHR), 0, stream, g);
+    if (TWv == 64) hipLaunchKernelGGL((tn_group_kernel<false, 64>), dim3((unsigned)next), dim3(NTHR), 0, stream, g);
+    else hipLaunchKernelGGL((tn_group_kernel<false, 128>), dim3((unsigned)next), dim3(NTHR), 0, stream, g);
     return true;
 }
 

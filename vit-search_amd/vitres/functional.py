@@ -191,12 +191,14 @@ def linear_dgrad(dy, W, dx, M, N_in, K_out, lddy, lddx, **kw):
         K.gemm(dy, W.w_c, dx, M=M, N=N_in, K=K_out, lda=lddy, ldb=W.ld, ldc=lddx, b_trans=True, **kw)
 
 
-# VITRES_WGRAD_STORE=1: the weight gradients of the transformer-block Linears whose token count fits one workgroup's walk
-# (<= WGRAD_STORE_MAXT tokens: the 17-token stage at B = 128, 2176 tokens = 34 slices) are written in STORE form (vr_gemm
-# atomic == 2): one workgroup per 128 x 128 tile over all tokens, plain stores -- no fp32 read-modify-write (stage 3 paid 82 MB of
-# atomics per block for 41 MB of gradients) and no zero fill of those spans of the gradient arena (the model skips them:
-# vit_sr_supernet._zero_grad_arena).  Stage 3 has 144 ... 192 tiles per Linear, i.e. the chip is full without a token split.
-WGRAD_STORE = _os.environ.get('VITRES_WGRAD_STORE', '1') != '0'
+# VITRES_WGRAD_STORE=1 (opt-in): the weight gradients of the transformer-block Linears whose token count fits one workgroup's
+# walk (<= WGRAD_STORE_MAXT tokens: the 17-token stage at B = 128, 2176 tokens = 34 slices) are written in STORE form (vr_gemm
+# atomic == 2): one workgroup per tile over all tokens, plain stores -- no fp32 read-modify-write (stage 3 pays 82 MB of atomics
+# per block for 41 MB of gradients) and no zero fill of those spans of the gradient arena (vit_sr_supernet._zero_grad_arena skips
+# them).  Measured round 3 inside the sr_tiny step: 7.85 -> 8.1 ms with 128 x 128 AND with 64 x 64 tiles -- without the token
+# split a group is 576 workgroups walking 34 slices each behind a single slice buffer, and what the atomics cost is less than
+# what the second workgroup per tile hid; 12.4 ms with the 65-token stage included.  Parity-tested; default off.
+WGRAD_STORE = _os.environ.get('VITRES_WGRAD_STORE', '0') != '0'
 WGRAD_STORE_MAXT = int(_os.environ.get('VITRES_WGRAD_STORE_MAXT', '3072'))
 
 
