@@ -104,6 +104,11 @@ typedef struct vr_gemm_args {
     vr_rowmap a_map;     /* remap of A's token rows (M index if a_trans==0, K index if a_trans==1) */
     vr_rowmap b_map;     /* remap of B's token rows (only meaningful when b_trans==1 && a_trans==1) */
     vr_rowmap c_map;     /* remap of output rows */
+    int32_t m_groups;    /* > 1: the token index (M rows; wgrad: K tokens) consists of this many equal, contiguous groups of samples
+                            with different keep_k / keep_n each -- the architecture groups of the supernet's multi-arch step
+                            (engine.py:119-165, channel_drop.py:101-105).  Pure scheduling hint: the kernels interleave the groups'
+                            row tiles (wgrad: token splits) in their XCD-contiguous workgroup order, so that no XCD is dealt only
+                            the sparsest (or only the densest) architecture; 0 / 1: one group */
     void* ws;            /* optional workspace of the stream-K forward / data-gradient kernel (gemm_ntw.hip): output tiles that do
                             not fill a round of the chip are shared slice-wise between workgroups, which exchange fp32 partial
                             accumulators through it.  >= vr_gemm_ws_bytes() bytes, 16-byte aligned, ZERO before its first use (the

@@ -209,6 +209,44 @@ def test_gemm_wgrad(dtype, T, No, Ki, split):
     assert relerr(bg, bg_ref) < 2e-4, relerr(bg, bg_ref)       # fused bias gradient (exact sums of the stored values)
 
 
+@pytest.mark.parametrize("groups", [2, 3, 5])
+def test_gemm_group_interleaved_tile_order_changes_nothing(groups):
+    """vr_gemm_args.m_groups is a pure scheduling hint (row tiles / token splits of the architecture groups interleaved in the
+    XCD-contiguous workgroup order): forward, data-gradient, LayerNorm-fused and weight-gradient results are those of the plain
+    order -- bit for bit where no atomics are involved -- for tile counts that do and do not divide by the group count."""
+    for M, N, K_, rows_in in ((65 * 30, 512, 384, 65), (257 * 12, 256, 768, 257), (17 * 45, 1024, 512, 17)):
+        for variant in ("fwd", "res", "dgrad"):
+            a, b, out, kw = _wide_case(M, N, K_, variant, rows_in, seed=7)
+            to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+            kw_d = {k: to(v) for k, v in kw.items()}
+            res = []
+            for g_ in (1, groups):
+                K.M_GROUPS[0] = g_
+                try:
+                    res.append(K.gemm(a.to(DEV), b.to(DEV), torch.full_like(out, float("nan")).to(DEV), sched=16, **kw_d).clone())
+                    if g_ > 1:
+                        res.append(K.gemm(a.to(DEV), b.to(DEV), torch.full_like(out, float("nan")).to(DEV), sched=8, **kw_d).clone())
+                finally:
+                    K.M_GROUPS[0] = 1
+            assert torch.equal(res[0], res[1]), (M, N, K_, variant)
+            assert relerr(res[2], res[0]) < (2e-5 if out.dtype == torch.float32 else 8e-3)      # (8-wave kernel: another summation order)
+        # weight gradient: token splits interleaved
+        T = M
+        dy, x = rnd(T, N, seed=3).to(torch.bfloat16).to(DEV), rnd(T, K_, seed=4).to(torch.bfloat16).to(DEV)
+        keep = torch.full((T // rows_in,), N, dtype=torch.int32, device=DEV)
+        outs = []
+        for g_ in (1, groups):
+            K.M_GROUPS[0] = g_
+            try:
+                o = torch.zeros(N, K_, device=DEV)
+                K.gemm(dy, x, o, M=N, N=K_, K=T, lda=N, ldb=K_, ldc=K_, a_trans=True, b_trans=True, atomic=True, split_k=0,
+                       rows_in=rows_in, keep_k=keep)
+                outs.append(o)
+            finally:
+                K.M_GROUPS[0] = 1
+        assert relerr(outs[1], outs[0]) < 1e-5
+
+
 @pytest.mark.parametrize("T,No,Ki,rps", [(2176, 3072, 1024, 17), (17 * 8, 768, 1024, 17), (65 * 6, 200, 328, 65)])
 def test_gemm_wgrad_store_form(T, No, Ki, rps):
     """atomic == 2: dW and the bias gradient are OVERWRITTEN (one workgroup per tile over all tokens, plain stores): the

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         const int xq = total >> 3, xr = total & 7, x = tile & 7;
         tile = x * xq + min(x, xr) + (tile >> 3);
     }
-    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    const int tn = tile % tiles_n, tm = interleave_groups(tile / tiles_n, tiles_m, p.m_groups);
     const int m0 = tm * BM, n0 = tn * BN;
     const RowMap amap = {p.a_map.rpi, p.a_map.rps, p.a_map.off};
     const RowMap bmap = {p.b_map.rpi, p.b_map.rps, p.b_map.off};

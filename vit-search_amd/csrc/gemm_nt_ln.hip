@@ -66,6 +66,7 @@ __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, con
         const int xq = tiles_m >> 3, xr = tiles_m & 7, x = tile & 7;
         tile = x * xq + min(x, xr) + (tile >> 3);
     }
+    tile = interleave_groups(tile, tiles_m, p.m_groups);      // every architecture group of a multi-arch batch on every XCD
     const int m0 = tile * BM;
     const RowMap amap = {p.a_map.rpi, p.a_map.rps, p.a_map.off};
 

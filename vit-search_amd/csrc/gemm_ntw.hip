@@ -120,7 +120,7 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
         } else {
             break;
         }
-        const int tn = tile % pl.tiles_n, tm = tile / pl.tiles_n;
+        const int tn = tile % pl.tiles_n, tm = interleave_groups(tile / pl.tiles_n, pl.tiles_m, p.m_groups);
         const int m0 = tm * BM, n0 = tn * BN;
 
         // ---- masked-work skipping (rules of the general kernel; the keep arrays are read with scalar loads) ----

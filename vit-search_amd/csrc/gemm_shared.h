@@ -19,6 +19,27 @@ __device__ __forceinline__ int max_keep(const int* keep, int s_lo, int s_hi, int
     return mk;
 }
 
+// Position p of the workgroup order -> index in [0, n) such that consecutive positions walk the G equal index groups
+// round-robin (group g = [g n / G, (g + 1) n / G)): the XCD-contiguous runs of the tile order then hold every architecture
+// group of a multi-arch batch in equal parts (vr_gemm_args.m_groups).  A bijection for every n, G.
+__device__ __forceinline__ int interleave_groups(int p, int n, int G) {
+    if (G <= 1 || n < 2 * G) return p;
+    const int t = n / G;                                   // every group has t or t + 1 members
+    if (p < t * G) {
+        const int g = p % G, r = p / G;
+        return (int)((long long)g * n / G) + r;
+    }
+    int k = p - t * G;                                     // the groups' (t + 1)-th members, in group order
+    for (int g = 0; g < G; ++g) {
+        const int s0 = (int)((long long)g * n / G), s1 = (int)((long long)(g + 1) * n / G);
+        if (s1 - s0 > t) {
+            if (k == 0) return s0 + t;
+            --k;
+        }
+    }
+    return p;
+}
+
 // Epilogue flavours (compile-time, keeps every instantiation small enough to unroll fully):
 //   EPI_STORE : (+bias)(+pos) -> keep mask -> scale -> (+resid) -> store TO
 //   EPI_GELU  : (+bias) -> C = u, C2 = gelu(u) masked by keep            (Mlp.fc1)

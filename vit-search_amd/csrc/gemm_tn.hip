@@ -89,7 +89,7 @@ __device__ __forceinline__ void tn_body(const vr_gemm_args& p, const int bid) {
         tile = x * xq + min(x, xr) + (tile >> 3);
     }
     const int tn = tile % tiles_n, rest = tile / tiles_n;
-    const int tm = rest % tiles_m, z = rest / tiles_m;
+    const int tm = rest % tiles_m, z = interleave_groups(rest / tiles_m, p.split_k, p.m_groups);   // (token splits of every architecture group on every XCD)
     const int m0 = tm * TW, n0 = tn * TW;
     const int kper = ((p.K + p.split_k - 1) / p.split_k + BT - 1) / BT * BT;
     const int kbeg = z * kper, kend = min(p.K, kbeg + kper);

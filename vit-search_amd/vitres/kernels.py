@@ -81,6 +81,14 @@ def ensure_workspaces(dev, roles=(0, 1)):
         _workspace(torch.device(dev), r)
 
 
+# Architecture groups of the batch being processed (vr_gemm_args.m_groups): the model sets it from its plan at the start of a
+# forward / backward (G = B / example_per_arch contiguous groups of samples in the arch-grouped execution order, each with its own
+# keep rows); every GEMM that carries keep arrays passes it on, so that the kernels deal every group to every XCD.
+# VITRES_GROUP_INTERLEAVE=0 keeps the plain tile order (measurement).
+M_GROUPS = [1]
+_GROUP_INTERLEAVE = __import__("os").environ.get("VITRES_GROUP_INTERLEAVE", "1") != "0"
+
+
 def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
                scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
                a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0, ws="auto"):
@@ -93,6 +101,7 @@ def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=Fals
     args.bias, args.pos, args.scale, args.keep_n = _p(bias), _p(pos), _p(scale), _p(keep_n)
     args.resid, args.dact_u, args.bias_grad, args.keep_k = _p(resid), _p(dact_u), _p(bias_grad), _p(keep_k)
     args.n_period, args.k_period, args.sched = n_period, k_period, sched
+    args.m_groups = M_GROUPS[0] if (_GROUP_INTERLEAVE and (keep_k is not None or keep_n is not None) and rows_in > 0) else 0
     args.M, args.N, args.K = M, N, K
     args.lda, args.ldb, args.ldc, args.ldu = lda, ldb, ldc, ldu
     args.a_trans, args.b_trans = int(a_trans), int(b_trans)

@@ -95,12 +95,13 @@ class SpatialReductionPatchEmbedding(nn.Module):
 
 class _Plan:
     """Host-side description of one forward: which keep vector / drop-path scale each layer uses."""
-    __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch", "n_dp", "order", "dp_noise", "host", "embed_col",
+    __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch", "n_dp", "order", "dp_noise", "host", "embed_col", "groups",
                  "keeps_host", "scales_host", "embed_map", "want_tape")
 
     def __init__(self):
         self.rows, self.layers, self.keep_dev, self.head, self.scales, self.batch, self.n_dp = [], [], None, None, None, 0, 0
         self.order = None
+        self.groups = 1          # architecture groups of the batch (contiguous in the arch-grouped order): vr_gemm_args.m_groups
         self.dp_noise = None     # test hook: the uniform draws of drop_path (nets/drop.py:23), [n_dp, B] in the CALLER's sample order
         self.host = None         # (int32 [n_rows, B] keeps, float32 [n_dp, B] DropPath scales) on the host, internal row order
         self.keeps_host = self.scales_host = None
@@ -518,6 +519,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             G = B // epa
             if 1 < G < B:
                 plan.order = [j * G + g for g in range(G) for j in range(epa)]
+                plan.groups = G
 
         def expand(gs, who):             # [len(gs), B]: entry b of a group vector g is g[b % len(g)]
             if not gs:
@@ -768,6 +770,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 a["shadow_ver"] = ver
         B = x.shape[0]
         tape = [] if save else None
+        K.M_GROUPS[0] = plan.groups              # every GEMM of this forward deals the architecture groups to every XCD
         side_params = {}
         ecfg = {"dtype": self.compute_dtype, "patch": self.patch_size, "patches": self.patch_embed.num_patches,
                 "dim": self.embed_dim, "tokens": self.num_tokens}
@@ -862,6 +865,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
     # ---- backward ----------------------------------------------------------------------------------
     def _run_backward(self, tape, plan, dcls, dpat, ready=False):
         a = self._arena
+        K.M_GROUPS[0] = plan.groups
         params = a["params"]
         fresh = all(p.grad is None for p in params)
         if a["gflat"] is None:
@@ -900,6 +904,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         st = self._bwd_state
         if st is None:
             raise RuntimeError("no split backward is pending")
+        K.M_GROUPS[0] = st["plan"].groups
         self._bwd_loop(st, st["stops"].pop(0))
         if st["i"] >= len(st["rtape"]):
             self._bwd_state = None
