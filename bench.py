@@ -187,6 +187,8 @@ def run_evo_eval(args, rank, world, device):
     if args.profile_steps > 0:
         K.PROFILE = []
         for i in range(args.profile_steps):
+            torch.cuda.synchronize()
+            torch.cuda._sleep(int(0.04 * 2.0e9))         # (see the training workloads: the step is queued before the GPU starts it)
             step(args.warmup + i)
         torch.cuda.synchronize()
         sec = fl = by = dense = 0.0
@@ -408,6 +410,11 @@ def main():
         K.PROFILE = []
         K.PROFILE_DESC = [] if args.launch_table else None
         for i in range(args.profile_steps):
+            # eager launches are host-bound (~10 us of Python per kernel): with an idle GPU every event pair would also time the
+            # host's gap between recording the event and launching the kernel.  The GPU is parked behind a 40 ms spin first, so that
+            # the whole step is queued when it starts and the pairs bracket GPU time only (kernel + its launch boundary).
+            torch.cuda.synchronize()
+            torch.cuda._sleep(int(0.04 * 2.0e9))
             eager_step(10_000 + i, exchange=False)      # rank 0 only, after the timed region: no collectives here
         torch.cuda.synchronize()
         if args.launch_table:                            # dev aid: per-shape table of the GEMM launches (time, TF/s, GB/s)
@@ -494,9 +501,9 @@ def main():
         peak, ach, gbps = MFMA_PEAK[dom_dt], fl / sec / 1e12, by / sec / 1e9
         roof.update({
                 "note": "FLOPs and bytes = kept (un-masked) sub-problems only; HIP events (recorded on the stream each kernel is launched "
-                        "on) around every vr_gemm launch of %d extra eager steps after the timed region (eager launches: a few per "
-                        "cent slower than the same kernels inside the replayed graph -- profiles/r03_a_kernel_stats.txt has the "
-                        "graph's averages)" % args.profile_steps,
+                        "on) around every vr_gemm launch of %d extra eager steps after the timed region, each queued behind a 40 ms GPU spin so that "
+                        "the pairs time the GPU, not the host's launch gaps (profiles/r03_a_kernel_stats.txt has the replayed graph's "
+                        "averages)" % args.profile_steps,
                 "all_gemm_ms_per_step": round(gemm_sec * 1e3, 3),
                 "all_gemm_kinds": {k: {
                     "tflops_kept": round(v[1] / v[0] / 1e12, 2), "tflops_dense_equiv": round(v[4] / v[0] / 1e12, 2),

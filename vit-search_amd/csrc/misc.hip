@@ -659,7 +659,15 @@ __global__ __launch_bounds__(256) void zero_ranges_kernel(float* base, const vr_
     if (i < head) p[i] = 0.f;
     float4* p4 = reinterpret_cast<float4*>(p + head);
     const long long n4 = (n - head) >> 2;
-    for (long long k = i; k < n4; k += stride) p4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    long long k = i;
+    for (; k + 3 * stride < n4; k += 4 * stride) {             // four 16-byte stores in flight per thread
+        p4[k] = z;
+        p4[k + stride] = z;
+        p4[k + 2 * stride] = z;
+        p4[k + 3 * stride] = z;
+    }
+    for (; k < n4; k += stride) p4[k] = z;
     const long long tail0 = head + (n4 << 2);
     if (tail0 + i < n && i < 4) p[tail0 + i] = 0.f;
 }
@@ -673,8 +681,8 @@ extern "C" int vr_zero_ranges(float* base, const vr_range_list* ranges, vr_strea
         most = ranges->count[i] > most ? ranges->count[i] : most;
     }
     if (most == 0) return VR_OK;
-    long long bx = (most / 4 + 255) / 256;
-    bx = bx < 1 ? 1 : (bx > 2048 ? 2048 : bx);
+    long long bx = (most / 16 + 255) / 256;
+    bx = bx < 1 ? 1 : (bx > 4096 ? 4096 : bx);
     hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)bx, (unsigned)ranges->n), dim3(256), 0, (hipStream_t)stream, base, *ranges);
     VR_CHECK_LAUNCH();
     return VR_OK;
