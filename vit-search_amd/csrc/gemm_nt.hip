@@ -39,6 +39,15 @@ __device__ const uint4 zero_chunk[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}
 // STAGES = 1: one slice buffer, the CU's other workgroups hide the load latency.  STAGES = 3: ring of three buffers with two
 // slices in flight (counted s_waitcnt vmcnt, raw s_barrier: __syncthreads would drain the LDS-DMA queue) for grids that leave a
 // CU one or two workgroups -- long-K GEMMs of the last stage, where a lone workgroup paid ~1 us per slice.
+// sched bit 32 (measurement aid, with vr_gemm_args.ws): workgroups 0..63 record wall-clock stamps (100 MHz) -- slot 0 entry,
+// 3 K loop done, 5 epilogue done -- in the upper half of the workspace's ticket array (tools/ntw_stamps.py prints them)
+#define NT_STAMP(slot)                                                                                   \
+    do {                                                                                                 \
+        if ((p.sched & 32) && p.ws && threadIdx.x == 0 && blockIdx.x < 64)                               \
+            reinterpret_cast<long long*>(reinterpret_cast<int*>(p.ws) + 2048)[blockIdx.x * 16 + (slot == 0 ? 0 : slot == 3 ? 1 : 2)] = \
+                (long long)wall_clock64() * 16 + (slot);                                                 \
+    } while (0)
+
 template <typename TO, int EPI, bool FAST, int MI, int NJ, int STAGES, int FEAT, bool BKM = false>
 __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm_args p) {
     constexpr int BM = 32 * MI, WROWS = 16 * MI;      // tile rows, rows per wave
@@ -49,6 +58,7 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE_BYTES];   // ring of [A slice][B slice]; epilogue: 4 x 4 KB
     __shared__ RowMeta rowmeta[BM];
     const int t = threadIdx.x, lane = t & 63;
+    NT_STAMP(0);
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
@@ -292,8 +302,10 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         __syncthreads();
     }
 
+    NT_STAMP(3);
     epilogue<TO, EPI, FAST, MI, NJ, FEAT>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wm * WROWS, n0 + wn * WCOLS,
                                          lane);
+    NT_STAMP(5);
 }
 
 template <typename TO, int EPI, int MI, int NJ, int STAGES, int FEAT> void launch3(const vr_gemm_args& a, hipStream_t stream, bool fast) {

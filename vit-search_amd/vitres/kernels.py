@@ -89,7 +89,6 @@ def ensure_workspaces(dev, roles=(0, 1)):
 # keep rows); every GEMM that carries keep arrays passes it on, so that the kernels deal every group to every XCD.
 # VITRES_GROUP_INTERLEAVE=0 keeps the plain tile order (measurement).
 M_GROUPS = [1]
-_GROUP_INTERLEAVE = __import__("os").environ.get("VITRES_GROUP_INTERLEAVE", "1") != "0"
 
 
 def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
@@ -97,7 +96,7 @@ def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=Fals
                a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0, ws="auto"):
     args = GemmArgs()
     if isinstance(ws, str):         # "auto": the role's workspace, when the 8-wave stream-K kernel can be chosen at all (opt-in)
-        ws = _workspace(a.device) if ((_WIDE_ON or (sched & 8)) and not a_trans and a.dtype == torch.bfloat16 and a.is_cuda and
+        ws = _workspace(a.device) if ((_WIDE_ON or (sched & (8 | 32))) and not a_trans and a.dtype == torch.bfloat16 and a.is_cuda and
                                       M >= 256 and K >= 128) else None
     if ws is not None:
         args.ws, args.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
