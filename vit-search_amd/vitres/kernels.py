@@ -89,6 +89,7 @@ def ensure_workspaces(dev, roles=(0, 1)):
 # keep rows); every GEMM that carries keep arrays passes it on, so that the kernels deal every group to every XCD.
 # VITRES_GROUP_INTERLEAVE=0 keeps the plain tile order (measurement).
 M_GROUPS = [1]
+_GROUP_INTERLEAVE = __import__("os").environ.get("VITRES_GROUP_INTERLEAVE", "1") != "0"
 
 
 def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
