@@ -27,6 +27,28 @@ def test_library_exports_every_declared_symbol():
     assert lib.vr_version() >= 1000
 
 
+def test_gemm_argument_marshalling_runs_without_a_gpu(monkeypatch):
+    """vitres.kernels._gemm_args fills the ctypes struct of include/vitres_hip.h (the emulation used by the CPU host tests
+    replaces K.gemm wholesale, so this is the only CPU coverage of the marshalling code: pointers are faked, nothing is launched)."""
+    from vitres import kernels as K
+    monkeypatch.setattr(K, "_p", lambda t: None if t is None else 0x1000)
+    a, b, out = torch.zeros(8, 16, dtype=torch.bfloat16), torch.zeros(4, 16, dtype=torch.bfloat16), torch.zeros(8, 4)
+    keep = torch.tensor([16, 8], dtype=torch.int32)
+    K.M_GROUPS[0] = 2
+    try:
+        args = K._gemm_args(a, b, out, M=8, N=4, K=16, lda=16, ldb=16, ldc=4, keep_k=keep, rows_in=4, sched=16, atomic=2, ws=None)
+    finally:
+        K.M_GROUPS[0] = 1
+    assert (args.M, args.N, args.K, args.atomic, args.m_groups, args.sched, args.in_dtype, args.out_dtype) == (8, 4, 16, 2, 2, 16, 1, 0)
+    assert args.ws is None and args.ws_bytes == 0
+    assert ctypes_sizeof_gemm_args() % 8 == 0
+
+
+def ctypes_sizeof_gemm_args():
+    import ctypes
+    return ctypes.sizeof(_lib.GemmArgs)
+
+
 def test_flop_mode_of_the_estimator_matches_reference():
     """ComputationEstimator(return_mac=False) (compute_flop_mac.py:53-194, 227-307) -- fixture F19: exact integers."""
     g = np.load(os.path.join(G, "f19_flops.npz"))
