@@ -303,6 +303,8 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     }
 
     NT_STAMP(3);
+    // (DEPTH = 2 for the fp32-residual forms -- the next round's residual requested once this round's accumulators are parked --
+    // measured round 3: +10..17 registers, 4 - 12 spilled at the 128 / 96 caps, residual GEMMs 29.0 -> 30.1 / 19.3 -> 21.0 us: no)
     epilogue<TO, EPI, FAST, MI, NJ, FEAT>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wm * WROWS, n0 + wn * WCOLS,
                                          lane);
     NT_STAMP(5);

@@ -56,10 +56,12 @@ template <int ROWB> __device__ __forceinline__ bfv8 tr_frag(const char* p) {
 // residual, 3: bias + residual + DropPath scale, 4: decided per launch from the arguments (pos-embed, any other mix; the only
 // form of the non-FAST kernels).  As run-time uniform conditions the compiler if-converts them into a v_cndmask per element
 // and term (measured: 890 VALU instructions per tile and wave against 128 MFMAs at K = 256, VALU pipe busy 2x the matrix pipe).
-// DEEP: the side operands of ALL rounds are requested up front (16 registers per round for the fp32 residual: only the 8-wave
-// kernel, which runs at two waves per SIMD, has them) instead of one round ahead -- a 256 x 128 tile's fp32 residual epilogue
-// took 5 us of exposed latency, four rounds in a row.
-template <typename TO, int EPI, bool FAST, int MI, int NJ, int FEAT, bool DEEP = false>
+// DEPTH: rounds of side operands in flight.  The fp32 residual costs 16 registers per round; with ONE round in flight (the load
+// at the top of its own round) every round exposes a whole HBM latency: stamps put the residual epilogue of a 128 x 128 tile at
+// 8 us against 2.5 us for a plain bf16 tile -- 16 KB in flight per workgroup, i.e. latency-bound by registers.  DEPTH = 2: the
+// next round's residual is requested as soon as this round's accumulators are parked (their registers are free then: no
+// higher peak), a round's worth of work ahead of its use; DEPTH = MI (the 8-wave kernel, two waves per SIMD): everything up front.
+template <typename TO, int EPI, bool FAST, int MI, int NJ, int FEAT, int DEPTH = 1>
 __device__ __forceinline__ void epilogue(const vr_gemm_args& p, f32x4 (&acc)[MI][NJ], float* park, const RowMeta* meta0, const int nw0,
                                          const int lane) {
     constexpr int WCOLS = 16 * NJ;
@@ -101,12 +103,13 @@ __device__ __forceinline__ void epilogue(const vr_gemm_args& p, f32x4 (&acc)[MI]
     constexpr bool SIDE_D = EPI == EPI_DGELU || EPI == EPI_DMUL;
     constexpr bool SIDE_R = EPI == EPI_STORE && (FEAT == 2 || FEAT == 3);
     constexpr bool PREF = FAST && (SIDE_D || SIDE_R);
-    constexpr int NSET = DEEP ? MI : 1;
+    constexpr bool DEEP = DEPTH >= MI;
+    constexpr int NSET = DEEP ? MI : (DEPTH > 1 ? DEPTH : 1);
     RowMeta rmn[NSET][NQ];
     uint4 dn[NSET][NQ];
     float4 rn[NSET][NQ][2];
     auto prefetch = [&](int i) {
-        const int sidx = DEEP ? i : 0;
+        const int sidx = i % NSET;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             rmn[sidx][q] = meta[i * 16 + q * RPP];
@@ -123,12 +126,14 @@ __device__ __forceinline__ void epilogue(const vr_gemm_args& p, f32x4 (&acc)[MI]
     if constexpr (PREF && DEEP) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) prefetch(i);
+    } else if constexpr (PREF && DEPTH > 1) {
+        prefetch(0);
     } else if constexpr (SIDE_D && PREF) {
         prefetch(0);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        if constexpr (SIDE_R && PREF && !DEEP) prefetch(i);
+        if constexpr (SIDE_R && PREF && !DEEP && DEPTH <= 1) prefetch(i);
         RowMeta rm[NQ];
         long long oidx[NQ];
         float rv[NQ][CW], pv[NQ][CW];
@@ -137,12 +142,12 @@ __device__ __forceinline__ void epilogue(const vr_gemm_args& p, f32x4 (&acc)[MI]
         if constexpr (PREF) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                rm[q] = rmn[DEEP ? i : 0][q];
-                dc[q] = dn[DEEP ? i : 0][q];
-                rc[q][0] = rn[DEEP ? i : 0][q][0];
-                rc[q][1] = rn[DEEP ? i : 0][q][1];
+                rm[q] = rmn[i % NSET][q];
+                dc[q] = dn[i % NSET][q];
+                rc[q][0] = rn[i % NSET][q][0];
+                rc[q][1] = rn[i % NSET][q][1];
             }
-            if constexpr (SIDE_D && !DEEP) {
+            if constexpr (SIDE_D && !DEEP && DEPTH <= 1) {
                 if (i + 1 < MI) prefetch(i + 1);
             }
         }
@@ -153,6 +158,9 @@ __device__ __forceinline__ void epilogue(const vr_gemm_args& p, f32x4 (&acc)[MI]
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if constexpr (PREF && !DEEP && DEPTH > 1) {                // this round's accumulators are parked: their registers take
+            if (i + 1 < MI) prefetch(i + 1);                       // the next round's side operands (other slot than rc's source)
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if constexpr (PREF) {

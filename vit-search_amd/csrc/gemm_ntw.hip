@@ -333,7 +333,7 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
         }
         NTW_STAMP(4);
         if (finish)
-            epilogue<TO, EPI, true, MI, NJ, FEAT, true>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wr * WROWS, n0 + wc * WCOLS, lane);
+            epilogue<TO, EPI, true, MI, NJ, FEAT, MI>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wr * WROWS, n0 + wc * WCOLS, lane);
         __syncthreads();
         NTW_STAMP(5);
     }
