@@ -41,6 +41,15 @@ def test_bench_launcher_two_ranks_sharing_one_gpu_over_gloo():
     assert ex["backend"] == "gloo" and ex["ranks_seen"] == 2 and ex["ranges"] >= 2 and ex["exposed_ms_per_step"] is not None
 
 
+def test_bench_launcher_two_ranks_bf16_wire_over_gloo():
+    """`bench.py --gpus 2 --wire bf16`: the gradient ranges cross the wire as bf16 (half the bytes of the fp32 exchange)."""
+    f32 = _run({"VITRES_DIST_BACKEND": "gloo"}, "--workload", "ref_tiny", "--batch", "8", "--profile-steps", "0")
+    b16 = _run({"VITRES_DIST_BACKEND": "gloo"}, "--workload", "ref_tiny", "--batch", "8", "--profile-steps", "0", "--wire", "bf16")
+    e32, e16 = f32["config"]["exchange"], b16["config"]["exchange"]
+    assert e32["dtype"] == "f32" and e16["dtype"] == "bf16" and 2 * e16["allreduce_bytes_per_step"] == e32["allreduce_bytes_per_step"]
+    assert abs(b16["config"]["final_loss"] - f32["config"]["final_loss"]) < 5e-2 * abs(f32["config"]["final_loss"])
+
+
 def _exchange(backend):
     """Two ranks of tests/exchange_worker.py under torch.distributed.run (127.0.0.1 rendezvous)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VITRES_DIST_BACKEND=backend)
