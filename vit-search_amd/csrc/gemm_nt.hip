@@ -85,13 +85,8 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         const int nmax = max_keep(p.keep_n, s_lo, s_hi, 1 << 30);
         n_any = range_has_kept(n0, BN, p.n_period, nmax);
     }
-    auto slice_live = [&](int kt) -> bool {
-        return n_any && (p.keep_k == nullptr || range_has_kept(kt * BK, BK, p.k_period, kmax));
-    };
-    auto next_live = [&](int kt) -> int {
-        while (kt < ntiles && !slice_live(kt)) ++kt;
-        return kt;
-    };
+    LiveSlices live;                 // cursor over the slices with kept k (gemm_shared.h)
+    live.init(p.keep_k, p.k_period, 0, ntiles, kmax, n_any);
 
     // ---- LDS-DMA source addressing: piece h of this wave = tile rows wave*32 + 8h .. +8, lane -> (row, slot) ----
     // Interior tiles of un-mapped operands (every block Linear) take the affine path: one row address per operand, pieces 8 rows
@@ -238,7 +233,7 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     };
 
     if constexpr (STAGES == 1) {
-        int kt = next_live(0);
+        int kt = live.take();
         if (kt < ntiles) issue(kt, 0);
         fill_rowmeta();
         if (kt >= ntiles) __syncthreads();
@@ -247,7 +242,7 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
             __syncthreads();
             compute(0);
             __syncthreads();
-            kt = next_live(kt + 1);
+            kt = live.take();
             if (kt < ntiles) issue(kt, 0);
         }
     } else if constexpr (STAGES == 2 || STAGES == 4) {
@@ -256,11 +251,9 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         // rows, 8 - 32 workgroups on the whole chip, paid one full load latency per 64-wide slice), in LDS that no other
         // workgroup would have used
         int cs[STAGES];
-        int nxt = 0;
 #pragma unroll
         for (int q = 0; q < STAGES; ++q) {
-            cs[q] = nxt < ntiles ? next_live(nxt) : ntiles;
-            nxt = cs[q] < ntiles ? cs[q] + 1 : ntiles;
+            cs[q] = live.take();
             if (cs[q] < ntiles) issue(cs[q], q);
         }
         fill_rowmeta();
@@ -274,15 +267,14 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < STAGES; ++q) {
-                cs[q] = nxt < ntiles ? next_live(nxt) : ntiles;
-                nxt = cs[q] < ntiles ? cs[q] + 1 : ntiles;
+                cs[q] = live.take();
                 if (cs[q] < ntiles) issue(cs[q], q);
             }
         }
     } else {
         fill_rowmeta();              // its global loads complete (the compiler waits for them) before any LDS-DMA is issued
-        int c0 = next_live(0);
-        int c1 = c0 < ntiles ? next_live(c0 + 1) : ntiles;
+        int c0 = live.take();
+        int c1 = live.take();
         if (c0 < ntiles) issue(c0, 0);
         if (c1 < ntiles) issue(c1, 1);
         int buf = 0;
@@ -291,7 +283,7 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
             if (c1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();         // every wave has also finished reading the buffer re-filled next
-            const int c2 = c1 < ntiles ? next_live(c1 + 1) : ntiles;
+            const int c2 = live.take();
             const int nb = buf == 0 ? 2 : buf - 1;      // (buf + 2) % 3
             if (c2 < ntiles) issue(c2, nb);
             compute(buf);

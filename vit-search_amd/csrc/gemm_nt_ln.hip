@@ -80,13 +80,8 @@ __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, con
         kmax = max_keep(p.keep_k, s_lo, s_hi, 1 << 30);
         n_any = max_keep(p.keep_n, s_lo, s_hi, 1 << 30) > 0;
     }
-    auto slice_live = [&](int kt) -> bool {
-        return n_any && (p.keep_k == nullptr || range_has_kept(kt * BK, BK, p.k_period, kmax));
-    };
-    auto next_live = [&](int kt) -> int {
-        while (kt < ntiles && !slice_live(kt)) ++kt;
-        return kt;
-    };
+    LiveSlices live;                 // cursor over the slices with kept k (gemm_shared.h)
+    live.init(p.keep_k, p.k_period, 0, ntiles, kmax, n_any);
 
     // ---- LDS-DMA source addressing: piece = 8 tile rows, lane -> (row, slot); slot p of row r holds k-chunk p ^ ((r >> 1) & 7) ----
     const char* gA[AP];
@@ -180,7 +175,7 @@ __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, con
         }
     };
 
-    int kt = next_live(0);
+    int kt = live.take();
     if (kt < ntiles) issue(kt);
     if (t < BM) {                          // per-row metadata of the row loop; its loads overlap the first slice
         const int m = m0 + t;
@@ -208,7 +203,7 @@ __global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, con
         __syncthreads();
         compute();
         __syncthreads();
-        kt = next_live(kt + 1);
+        kt = live.take();
         if (kt < ntiles) issue(kt);
     }
 

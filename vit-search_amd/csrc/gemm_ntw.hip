@@ -133,25 +133,9 @@ __global__ __launch_bounds__(WTHR, 2) void ntw_kernel(const vr_gemm_args p, cons
             const int nmax = max_keep(p.keep_n, s_lo, s_hi, 1 << 30);
             n_any = range_has_kept(n0, BN, p.n_period, nmax);
         }
-        // live slices are walked with a cursor (slice nk, nr = (nk * BK) % k_period kept incrementally): the test of the general
-        // kernel (range_has_kept: a modulo per call) costs ~100 scalar instructions per slice
-        const bool masked = p.keep_k != nullptr;
-        const int period = p.k_period >= BK ? p.k_period : 0;        // periods below a slice: every slice holds kept columns
-        const bool prefix = masked && p.k_period <= 0;               // plain prefix: slices below kmax
-        int nk = (n_any && kmax > 0) ? kb : ke;
-        int nr = period > 0 ? (kb * BK) % period : kb * BK;
-        auto take = [&]() -> int {                                   // next live slice in [nk, ke) (ke: none); moves the cursor past it
-            while (nk < ke) {
-                const bool lv = !masked || (period > 0 ? (nr < kmax || nr + BK > period) : (!prefix || nr < kmax));
-                const int cur = nk;
-                ++nk;
-                nr += BK;
-                if (period > 0 && nr >= period) nr -= period;
-                if (lv) return cur;
-                if (prefix) { nk = ke; break; }                      // beyond a prefix nothing is kept
-            }
-            return ke;
-        };
+        LiveSlices live;             // cursor over the slices with kept k (gemm_shared.h)
+        live.init(p.keep_k, p.k_period, kb, ke, kmax, n_any);
+        auto take = [&]() -> int { return live.take(); };
 
         // ---- LDS-DMA sources: piece h of this wave = 8 rows of 128 B, lane -> (row, 16-byte slot) ----
         const char* gA[AP];

@@ -19,6 +19,36 @@ __device__ __forceinline__ int max_keep(const int* keep, int s_lo, int s_hi, int
     return mk;
 }
 
+// Cursor over the K slices (64 wide) of [kb, ke) that hold a kept k for any sample of a tile: take() returns the next live slice
+// (ke: none) and moves past it.  The same slices as range_has_kept(kt * 64, 64, k_period, kmax) -- but that test is a modulo per
+// call, ~100 scalar instructions per slice on the critical path between a slice's last MFMA and the next slice's loads (PMC, round
+// 3: 6.7 SALU instructions per MFMA in the forward / dgrad kernel); here (kt * 64) % k_period is carried along.
+struct LiveSlices {
+    int nk, ke, nr, period, kmax;
+    bool masked, prefix;
+    __device__ __forceinline__ void init(const int* keep_k, int k_period, int kb, int ke_, int kmax_, bool any) {
+        masked = keep_k != nullptr;
+        period = k_period >= 64 ? k_period : 0;        // periods below a slice: every slice holds kept columns
+        prefix = masked && k_period <= 0;              // plain prefix: the slices below kmax
+        kmax = kmax_;
+        ke = ke_;
+        nk = (any && (!masked || kmax_ > 0)) ? kb : ke_;
+        nr = period > 0 ? (kb * 64) % period : kb * 64;
+    }
+    __device__ __forceinline__ int take() {
+        while (nk < ke) {
+            const bool lv = !masked || (period > 0 ? (nr < kmax || nr + 64 > period) : (!prefix || nr < kmax));
+            const int cur = nk;
+            ++nk;
+            nr += 64;
+            if (period > 0 && nr >= period) nr -= period;
+            if (lv) return cur;
+            if (prefix) { nk = ke; break; }            // beyond a prefix nothing is kept
+        }
+        return ke;
+    }
+};
+
 // Position p of the workgroup order -> index in [0, n) such that consecutive positions walk the G equal index groups
 // round-robin (group g = [g n / G, (g + 1) n / G)): the XCD-contiguous runs of the tile order then hold every architecture
 // group of a multi-arch batch in equal parts (vr_gemm_args.m_groups).  A bijection for every n, G.
