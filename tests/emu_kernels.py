@@ -433,13 +433,26 @@ def patch_fold(col, B, gh, gw, P, C):
 
 
 ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "gemm_group", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "ln_grad_reduce", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "softce_train", "colsum", "scale_mask_cast",
-       "batchsum", "conv3x3", "conv1_direct", "conv1_direct_supported", "conv3x3_bias_relu", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows", "zero_ranges"]
+       "batchsum", "conv3x3", "conv1_direct", "conv1_direct_supported", "conv3x3_bias_relu", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows", "zero_ranges", "zero_", "relayout"]
 
 
 def zero_ranges(buf, ranges):
     for lo, hi in ranges:
         buf[int(lo):int(hi)] = 0
     return buf
+
+
+def zero_(t):
+    return t.zero_()
+
+
+def relayout(src, dst, A, B, C, dst_ld=None):
+    dst_ld = B * C if dst_ld is None else dst_ld
+    v = src.reshape(-1)[:A * B * C].view(A, B, C).permute(0, 2, 1).reshape(A, B * C)
+    d = dst.reshape(-1)
+    idx = (torch.arange(A)[:, None] * dst_ld + torch.arange(B * C)[None, :]).reshape(-1)
+    d[idx] = v.reshape(-1).to(dst.dtype)
+    return dst
 
 
 def install(monkeypatch):

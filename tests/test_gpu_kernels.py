@@ -436,6 +436,26 @@ def test_attention_propagates_non_finite_inputs(N, H, D):
         assert torch.isfinite(dq[0].float()).all()
 
 
+def test_relayout_and_zero():
+    """vr_relayout (the [out, in, taps] <-> [out, (taps, in)] copies around the convolution-shaped weights, row copies into padded
+    rows) and zero_ against torch."""
+    for sd, dd in ((torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)):
+        w = rnd(20, 7, 9, seed=1).to(sd)
+        out = torch.full((20, 9 * 7), 5.0, dtype=dd, device=DEV)
+        K.relayout(w.to(DEV), out, 20, 7, 9)
+        assert torch.equal(out.cpu(), w.permute(0, 2, 1).reshape(20, 63).to(dd))
+    w = rnd(256, 588, seed=2)
+    out = torch.full((256, 592), 3.0, dtype=torch.bfloat16, device=DEV)
+    K.relayout(w.to(DEV), out, 256, 1, 588, 592)
+    assert torch.equal(out[:, :588].cpu(), w.to(torch.bfloat16)) and float((out[:, 588:].float() - 3.0).abs().max()) == 0.0
+    g = rnd(24, 49, 8, seed=3)                                                   # gradient [C, (kh, kw), m] -> [C, m, kh, kw]
+    back = torch.empty(24, 8, 7, 7, device=DEV)
+    K.relayout(g.to(DEV), back, 24, 49, 8)
+    assert torch.equal(back.cpu(), g.view(24, 7, 7, 8).permute(0, 3, 1, 2))
+    for t in (torch.full((3, 1001), 2.0, device=DEV), torch.full((1000,), 2.0, dtype=torch.bfloat16, device=DEV), torch.ones(1, device=DEV)):
+        assert float(K.zero_(t).float().abs().max()) == 0.0
+
+
 def test_softce():
     for R, Kc in ((8, 10), (128 * 16, 1000)):
         x = rnd(R, Kc, seed=1) * 3

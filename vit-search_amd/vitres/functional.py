@@ -555,7 +555,9 @@ def head_bwd(dcls, dpat, saved, p, grads, cfg, keep, next_cast=None, ready=False
     # every token row is written by a head's data gradient when the class head and the per-patch head are both active (and one
     # class token): no zero fill then
     covered = dcls is not None and dpat is not None and "dst" not in p and ym is None and T_ == 1
-    dy = (torch.empty if covered else torch.zeros)((B, N, C), dtype=dt, device=x.device)
+    dy = torch.empty((B, N, C), dtype=dt, device=x.device)
+    if not covered:
+        K.zero_(dy)
     ldp = (nc + 7) // 8 * 8                                                 # logits-gradient rows zero-padded to 16 B
 
     def padded(d2):                                                         # tiny [rows, classes] tensors: torch glue

@@ -296,6 +296,28 @@ def zero_ranges(buf, ranges):
     return buf
 
 
+def zero_(t):
+    """t[...] = 0 for a contiguous fp32 / bf16 tensor (vr_zero_ranges on its storage viewed as fp32 words)."""
+    if t.numel() == 0:
+        return t
+    nbytes = t.numel() * t.element_size()
+    if not t.is_contiguous() or nbytes % 4 or t.data_ptr() % 4:
+        raise ValueError("zero_: contiguous, 4-byte sized and aligned tensors only")
+    zr = _lib.ZeroRanges()
+    zr.n, zr.lo[0], zr.count[0] = 1, 0, nbytes // 4
+    _lib.check(_lib.lib().vr_zero_ranges(_p(t), ctypes.byref(zr), _stream()), "vr_zero_ranges")
+    return t
+
+
+def relayout(src, dst, A, B, C, dst_ld=None):
+    """dst[a, c, b] = src[a, b, c] (flat: dst[a * dst_ld + c * B + b] = src[(a * B + b) * C + c]); fp32 / bf16 either side --
+    vr_relayout.  Pad columns (dst_ld > B * C) keep their contents."""
+    dst_ld = B * C if dst_ld is None else dst_ld
+    assert src.is_contiguous() and src.numel() >= A * B * C and dst.numel() >= (A - 1) * dst_ld + B * C
+    _lib.check(_lib.lib().vr_relayout(_p(src), _p(dst), A, B, C, dst_ld, _dt(src), _dt(dst), _stream()), "vr_relayout")
+    return dst
+
+
 def cast_bf16(src, dst):
     _lib.check(_lib.lib().vr_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "vr_cast_f32_bf16")
     return dst

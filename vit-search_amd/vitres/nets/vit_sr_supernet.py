@@ -694,7 +694,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         with torch.no_grad():
             cls, pat, tape = self._run_forward(x, plan, with_patch, True)
             loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=x.device)
-            loss.zero_()
+            K.zero_(loss)
             dt = self.compute_dtype
             dcls = K.softce_train(cls, targets.float(), smap, 1, loss, dt)
             dpat = None
@@ -717,7 +717,9 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         if isinstance(blk, SpatialReductionPatchEmbedding):
             w = blk.patch_reduce.weight
             # [co, ci, 3, 3] -> [co, (kh, kw, ci)] from the compute-dtype shadow of the weight: one strided copy, no cast pass
-            wperm = self._wc(w).view(w.shape).permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+            wsrc = self._wc(w)
+            wperm = torch.empty((w.shape[0], 9 * w.shape[1]), dtype=wsrc.dtype, device=wsrc.device)
+            K.relayout(wsrc, wperm, w.shape[0], w.shape[1], 9)              # (vr_relayout: no torch permute / copy kernels)
             # (transposed copy for the data gradient only in the round-1 layout: the LDS-DMA kernel reads wperm itself, b_trans)
             wperm_t = wperm.t().contiguous() if self.compute_dtype == torch.bfloat16 and wperm.shape[0] % 8 == 0 and \
                 self._arena.get("wt_mode") == "all" else None
@@ -748,7 +750,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 wc = self._arena.get("embed_wc")            # persistent: the pad columns stay zero, one cast-copy per forward
                 if wc is None or wc.shape != (w.shape[0], ld) or wc.device != w.device:
                     wc = self._arena["embed_wc"] = torch.zeros((w.shape[0], ld), dtype=torch.bfloat16, device=w.device)
-                wc[:, :k].copy_(w.detach().view(w.shape[0], k))
+                K.relayout(w.detach(), wc, w.shape[0], 1, k, ld)             # fp32 [out, 588] -> bf16 [out, 592], pads stay zero
             return {"proj": Fn.Weights(w, pe.proj.bias.detach(), wc, ld), "pos": self.pos_embed.detach(),
                     "tokens": self.tokens.detach()}
         from .. import stem
@@ -996,11 +998,11 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 _, blk, p, cfg, (ek, nk), sv = entry
                 co, ci = blk.patch_reduce.weight.shape[0], blk.patch_reduce.weight.shape[1]
                 nt = self.num_tokens
-                ztmp = torch.zeros(co * 9 * ci + (nt + blk.num_patches) * co, dtype=torch.float32, device=dev)   # one fill
+                ztmp = K.zero_(torch.empty(co * 9 * ci + (nt + blk.num_patches) * co, dtype=torch.float32, device=dev))   # one fill
                 wtmp = ztmp[:co * 9 * ci].view(co, 9 * ci)
                 ptmp = ztmp[co * 9 * ci:].view(nt + blk.num_patches, co)
                 def finish(blk=blk, wtmp=wtmp, ptmp=ptmp, co=co, ci=ci, nt=nt):     # runs on the stream of the weight gradients
-                    gv(blk.patch_reduce.weight).copy_(wtmp.view(co, 3, 3, ci).permute(0, 3, 1, 2))
+                    K.relayout(wtmp, gv(blk.patch_reduce.weight), co, 9, ci)         # [co, (kh, kw), ci] -> [co, ci, kh, kw]
                     gv(blk.pos_embed).copy_(ptmp[nt:].unsqueeze(0))
                 grads = {"nw": gv(blk.norm.weight), "nb": gv(blk.norm.bias), "token.w": gv(blk.token_transform.weight),
                          "token.b": gv(blk.token_transform.bias), "reduce.b": gv(blk.patch_reduce.bias),

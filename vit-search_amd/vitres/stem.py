@@ -16,11 +16,11 @@ def _perm_weight(conv, dt, ld=None):
     """[out, in, kh, kw] -> [out, (kh, kw, in)] zero-padded to ld columns, compute dtype."""
     w = conv.weight.detach()
     o, k = w.shape[0], w.shape[1] * w.shape[2] * w.shape[3]
-    wp = w.permute(0, 2, 3, 1).reshape(o, k)
     ld = ld or k
-    out = torch.zeros((o, ld), dtype=dt, device=w.device)
-    out[:, :k] = wp
-    return out
+    out = torch.empty((o, ld), dtype=dt, device=w.device)
+    if ld != k:
+        K.zero_(out)
+    return K.relayout(w, out, o, w.shape[1], w.shape[2] * w.shape[3], ld)
 
 
 def embed_params(model):
@@ -44,7 +44,7 @@ def _bn_affine(z, bn, training):
     """Folded BatchNorm: returns (scale, shift, mean, rstd) fp32 [C]; updates running stats in training."""
     C = z.shape[1]
     if training:
-        sq = torch.zeros((2, C), dtype=torch.float32, device=z.device)
+        sq = K.zero_(torch.empty((2, C), dtype=torch.float32, device=z.device))
         K.bn_stats(z, sq[0], sq[1])
         n = z.shape[0]
         mean = sq[0] / n
@@ -210,12 +210,12 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
         gt = K.scale_mask_cast(gx, None, keep, N, dt)
     # conv_proj
     ov = Fn._overlap(gx) and Fn.STEM_SIDE
-    wtmp = torch.zeros((C, ldk), dtype=torch.float32, device=dev)
+    wtmp = K.zero_(torch.empty((C, ldk), dtype=torch.float32, device=dev))
 
     def wgrad_proj():
         Fn.linear_wgrad(gt, colp, wtmp, B * P, C, ldk, C, ldk, a_map=(P, N, T), db=gv(pe.conv_proj.bias),
                         sched=1 if ov else 0)
-        gv(pe.conv_proj.weight).copy_(wtmp.view(C, ps, ps, m).permute(0, 3, 1, 2))
+        K.relayout(wtmp, gv(pe.conv_proj.weight), C, ps * ps, m)          # [C, (kh, kw), m] -> [C, m, kh, kw]
         K.batchsum(gx, gv(model.pos_embed))
     # weight gradients run beside the data-gradient chain (functional.on_side); joined at the end of this function
     Fn.on_side(wgrad_proj, gt, wtmp) if ov else wgrad_proj()
@@ -224,11 +224,11 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
     da3 = K.patch_fold(dcolp, B, g, g, ps, m)                      # d(relu(bn3) + a1)
 
     def conv_bwd(da, z, bn, col, w, conv_mod, ld, need_dx, wt=None):
-        sg = torch.zeros((2, m), dtype=torch.float32, device=dev)
+        sg = K.zero_(torch.empty((2, m), dtype=torch.float32, device=dev))
         dz = K.bn_bwd(da, z, bn[0], bn[1], bn[2], bn[3], sg[0], sg[1], tr)
         gv(conv_mod.bn.weight).copy_(sg[1])
         gv(conv_mod.bn.bias).copy_(sg[0])
-        wg = torch.zeros((m, ld), dtype=torch.float32, device=dev)
+        wg = K.zero_(torch.empty((m, ld), dtype=torch.float32, device=dev))
         cin = conv_mod.conv.weight.shape[1]
         direct_w = wt is not None and K.conv3x3_wgrad_supported(dz, cin, m)
         if wt is not None and not direct_w:     # forward ran the direct convolution and saved the activation, not its im2col
