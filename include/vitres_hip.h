@@ -360,13 +360,13 @@ typedef struct vr_range_list {
 int vr_zero_ranges(float* base, const vr_range_list* ranges, vr_stream_t stream);
 
 /*
- * dst[a * dst_ld + c * B + b] = src[(a * B + b) * C + c]  (dtype codes as everywhere; pad columns of dst untouched).
+ * dst[a * dst_ld + c * B + b] = src[a * src_ld + b * C + c]  (dtype codes as everywhere; pad columns of dst untouched).
  * Replaces the `.permute(0, 2, 3, 1).reshape(...)` / `.permute(0, 3, 1, 2)` copies between the reference's convolution weights
  * [out, in, kh, kw] (nets/patch_conv.py:26-27, vit_sr_supernet.py:96-97) and the [out, (kh, kw, in)] form their GEMMs read, and the
  * row copy of the timm PatchEmbed weight into 16-byte-aligned rows (B = 1).
  */
-int vr_relayout(const void* src, void* dst, int32_t A, int32_t B, int32_t C, int64_t dst_ld, int32_t src_dtype, int32_t dst_dtype,
-                vr_stream_t stream);
+int vr_relayout(const void* src, void* dst, int32_t A, int32_t B, int32_t C, int64_t src_ld, int64_t dst_ld, int32_t src_dtype,
+                int32_t dst_dtype, vr_stream_t stream);
 
 /* x[m, c] = 0 for c >= keep[sample(m)]  (ChannelDrop.forward `x * mask`, nets/channel_drop.py:82) */
 int vr_mask_rows(float* x, const int32_t* keep, int32_t M, int32_t C, int32_t rows_per_sample, vr_stream_t stream);

@@ -446,12 +446,13 @@ def zero_(t):
     return t.zero_()
 
 
-def relayout(src, dst, A, B, C, dst_ld=None):
+def relayout(src, dst, A, B, C, dst_ld=None, src_ld=None):
     dst_ld = B * C if dst_ld is None else dst_ld
-    v = src.reshape(-1)[:A * B * C].view(A, B, C).permute(0, 2, 1).reshape(A, B * C)
-    d = dst.reshape(-1)
-    idx = (torch.arange(A)[:, None] * dst_ld + torch.arange(B * C)[None, :]).reshape(-1)
-    d[idx] = v.reshape(-1).to(dst.dtype)
+    src_ld = B * C if src_ld is None else src_ld
+    sidx = (torch.arange(A)[:, None] * src_ld + torch.arange(B * C)[None, :]).reshape(-1)
+    v = src.reshape(-1)[sidx].view(A, B, C).permute(0, 2, 1).reshape(A, B * C)
+    didx = (torch.arange(A)[:, None] * dst_ld + torch.arange(B * C)[None, :]).reshape(-1)
+    dst.reshape(-1)[didx] = v.reshape(-1).to(dst.dtype)
     return dst
 
 

@@ -446,8 +446,12 @@ def test_relayout_and_zero():
         assert torch.equal(out.cpu(), w.permute(0, 2, 1).reshape(20, 63).to(dd))
     w = rnd(256, 588, seed=2)
     out = torch.full((256, 592), 3.0, dtype=torch.bfloat16, device=DEV)
-    K.relayout(w.to(DEV), out, 256, 1, 588, 592)
+    K.relayout(w.to(DEV), out, 256, 1, 588, dst_ld=592)
     assert torch.equal(out[:, :588].cpu(), w.to(torch.bfloat16)) and float((out[:, 588:].float() - 3.0).abs().max()) == 0.0
+    wp = rnd(256, 592, seed=4)                                                   # padded rows -> dense rows (src_ld)
+    dense = torch.empty(256, 588, device=DEV)
+    K.relayout(wp.to(DEV), dense, 256, 1, 588, src_ld=592)
+    assert torch.equal(dense.cpu(), wp[:, :588])
     g = rnd(24, 49, 8, seed=3)                                                   # gradient [C, (kh, kw), m] -> [C, m, kh, kw]
     back = torch.empty(24, 8, 7, 7, device=DEV)
     K.relayout(g.to(DEV), back, 24, 49, 8)

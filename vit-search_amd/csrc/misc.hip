@@ -688,38 +688,39 @@ extern "C" int vr_zero_ranges(float* base, const vr_range_list* ranges, vr_strea
     return VR_OK;
 }
 
-// ---- vr_relayout: dst[a * dst_ld + c * B + b] = src[(a * B + b) * C + c]  (fp32 / bf16 in, fp32 / bf16 out) ----
+// ---- vr_relayout: dst[a * dst_ld + c * B + b] = src[a * src_ld + b * C + c]  (fp32 / bf16 in, fp32 / bf16 out) ----
 // The small re-layouts around the convolution-shaped weights: [out][in][taps] -> [out][(taps, in)] for the GEMM form of the 3x3 /
 // 7x7 convolutions (nets/patch_conv.py:56-58, vit_sr_supernet.py:140) and back for their gradients; with B = 1 a row copy into
 // 16-byte-aligned rows (the timm PatchEmbed weight, k = 588 -> ld = 592).  Pad columns of dst are not touched.
 namespace {
 template <typename TS, typename TD>
-__global__ __launch_bounds__(256) void relayout_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int A, int B, int C, long long dst_ld) {
+__global__ __launch_bounds__(256) void relayout_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int A, int B, int C, long long src_ld,
+                                                       long long dst_ld) {
     const long long total = (long long)A * B * C;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int b = (int)(i % B);                      // destination order: consecutive threads write consecutive elements
         const long long r = i / B;
         const int c = (int)(r % C);
         const int a = (int)(r / C);
-        Elem<TD>::st(dst + a * dst_ld + (long long)c * B + b, Elem<TS>::ld(src + ((long long)a * B + b) * C + c));
+        Elem<TD>::st(dst + a * dst_ld + (long long)c * B + b, Elem<TS>::ld(src + a * src_ld + (long long)b * C + c));
     }
 }
 }  // namespace
 
-extern "C" int vr_relayout(const void* src, void* dst, int32_t A, int32_t B, int32_t C, int64_t dst_ld, int32_t src_dtype,
+extern "C" int vr_relayout(const void* src, void* dst, int32_t A, int32_t B, int32_t C, int64_t src_ld, int64_t dst_ld, int32_t src_dtype,
                            int32_t dst_dtype, vr_stream_t stream) {
-    if (!src || !dst || A <= 0 || B <= 0 || C <= 0 || dst_ld < (int64_t)B * C) return VR_EINVAL;
+    if (!src || !dst || A <= 0 || B <= 0 || C <= 0 || dst_ld < (int64_t)B * C || src_ld < (int64_t)B * C) return VR_EINVAL;
     const long long total = (long long)A * B * C;
     const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
     if (src_dtype == VR_F32 && dst_dtype == VR_F32)
-        hipLaunchKernelGGL((relayout_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, A, B, C, dst_ld);
+        hipLaunchKernelGGL((relayout_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, A, B, C, src_ld, dst_ld);
     else if (src_dtype == VR_F32 && dst_dtype == VR_BF16)
-        hipLaunchKernelGGL((relayout_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, A, B, C, dst_ld);
+        hipLaunchKernelGGL((relayout_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, A, B, C, src_ld, dst_ld);
     else if (src_dtype == VR_BF16 && dst_dtype == VR_BF16)
-        hipLaunchKernelGGL((relayout_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, A, B, C, dst_ld);
+        hipLaunchKernelGGL((relayout_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, A, B, C, src_ld, dst_ld);
     else if (src_dtype == VR_BF16 && dst_dtype == VR_F32)
-        hipLaunchKernelGGL((relayout_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, A, B, C, dst_ld);
+        hipLaunchKernelGGL((relayout_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, A, B, C, src_ld, dst_ld);
     else
         return VR_EUNSUPPORTED;
     VR_CHECK_LAUNCH();

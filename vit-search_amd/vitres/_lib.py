@@ -90,7 +90,7 @@ SYMBOLS = {
     "vr_sr_resid_bwd": [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p],
     "vr_mask_rows": [c_void_p, c_void_p] + [c_int32] * 3 + [c_void_p],
     "vr_zero_ranges": [c_void_p, ctypes.POINTER(ZeroRanges), c_void_p],
-    "vr_relayout": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_int32, c_void_p],
+    "vr_relayout": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int64, c_int32, c_int32, c_void_p],
     "vr_im2col3x3": [c_void_p, c_void_p] + [c_int32] * 8 + [c_void_p],
     "vr_col2im3x3": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
     "vr_bn_stats": [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p],

@@ -309,12 +309,12 @@ def zero_(t):
     return t
 
 
-def relayout(src, dst, A, B, C, dst_ld=None):
-    """dst[a, c, b] = src[a, b, c] (flat: dst[a * dst_ld + c * B + b] = src[(a * B + b) * C + c]); fp32 / bf16 either side --
+def relayout(src, dst, A, B, C, dst_ld=None, src_ld=None):
+    """dst[a, c, b] = src[a, b, c] (flat: dst[a * dst_ld + c * B + b] = src[a * src_ld + b * C + c]); fp32 / bf16 either side --
     vr_relayout.  Pad columns (dst_ld > B * C) keep their contents."""
     dst_ld = B * C if dst_ld is None else dst_ld
-    assert src.is_contiguous() and src.numel() >= A * B * C and dst.numel() >= (A - 1) * dst_ld + B * C
-    _lib.check(_lib.lib().vr_relayout(_p(src), _p(dst), A, B, C, dst_ld, _dt(src), _dt(dst), _stream()), "vr_relayout")
+    src_ld = B * C if src_ld is None else src_ld
+    _lib.check(_lib.lib().vr_relayout(_p(src), _p(dst), A, B, C, src_ld, dst_ld, _dt(src), _dt(dst), _stream()), "vr_relayout")
     return dst
 
 

@@ -750,7 +750,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 wc = self._arena.get("embed_wc")            # persistent: the pad columns stay zero, one cast-copy per forward
                 if wc is None or wc.shape != (w.shape[0], ld) or wc.device != w.device:
                     wc = self._arena["embed_wc"] = torch.zeros((w.shape[0], ld), dtype=torch.bfloat16, device=w.device)
-                K.relayout(w.detach(), wc, w.shape[0], 1, k, ld)             # fp32 [out, 588] -> bf16 [out, 592], pads stay zero
+                K.relayout(w.detach(), wc, w.shape[0], 1, k, dst_ld=ld)             # fp32 [out, 588] -> bf16 [out, 592], pads stay zero
             return {"proj": Fn.Weights(w, pe.proj.bias.detach(), wc, ld), "pos": self.pos_embed.detach(),
                     "tokens": self.tokens.detach()}
         from .. import stem
@@ -1018,12 +1018,12 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                     w = self.patch_embed.proj.weight
                     ld = ep["proj"].ld
                     k = w.numel() // w.shape[0]
-                    wt = gv(w).view(w.shape[0], k) if ld == k else torch.zeros((w.shape[0], ld), dtype=torch.float32,
-                                                                              device=dev)
+                    wt = gv(w).view(w.shape[0], k) if ld == k else K.zero_(torch.empty((w.shape[0], ld), dtype=torch.float32,
+                                                                                        device=dev))
                     grads = {"proj.w": wt, "proj.b": gv(self.patch_embed.proj.bias), "pos": gv(self.pos_embed)}
                     Fn.embed0_bwd(g, sv, ep, grads, ecfg, ekeep, gt=gt)
                     if ld != k:
-                        gv(w).view(w.shape[0], k).copy_(wt[:, :k])
+                        K.relayout(wt, gv(w), w.shape[0], 1, k, src_ld=ld)       # drop the pad columns
                 else:
                     from .. import stem
                     stem.embed_conv_bwd(self, g, sv, ep, ecfg, ekeep, gv, gt=gt)
