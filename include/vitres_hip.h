@@ -100,7 +100,8 @@ typedef struct vr_gemm_args {
                             kernel: 128x128 tile, one workgroup per tile instead of persistent workgroups); 2 = keep the hardware's
                             round-robin workgroup -> XCD order (default: tiles remapped so that an XCD owns a contiguous run);
                             4 = always use the general kernel (gemm.hip) -- measurement aid; 8 = 8-wave stream-K kernel (gemm_ntw.hip) wherever it
-                            is admissible; 16 = never */
+                            is admissible; 16 = never.  vr_gemm_ln: 8 = the one-workgroup-per-CU form (gemm_nt_lnw.hip) whenever
+                            N <= 256, 16 = never (default: for M >= 64 rows per CU) */
     vr_rowmap a_map;     /* remap of A's token rows (M index if a_trans==0, K index if a_trans==1) */
     vr_rowmap b_map;     /* remap of B's token rows (only meaningful when b_trans==1 && a_trans==1) */
     vr_rowmap c_map;     /* remap of output rows */
@@ -142,6 +143,8 @@ int vr_gemm_group(const vr_gemm_args* args, int32_t count, vr_stream_t stream);
  *       C = (resid ? resid : 0) + dLN/dx(dy);  dw += sum dy*xhat;  db += sum dy;
  *       gt_out[m,c] = c < gt_keep[s] ? C[m,c] * gt_scale[s] : 0 (bf16, optional)  exactly vr_ln_bwd on a fp32 dy
  *     (args.bias / scale / keep_n must be NULL; keep_k / k_period / rows_in keep their vr_gemm meaning).
+ * Two kernels stand behind it with the same results: 64 x 256 / 32 x 512 tiles sharing a CU (gemm_nt_ln.hip), and for N <= 256
+ * and long M one eight-wave workgroup per CU that owns an equal share of the 16-row blocks (gemm_nt_lnw.hip; args.sched 8 / 16).
  */
 typedef struct vr_ln_epilogue {
     int32_t mode;

@@ -784,10 +784,14 @@ def _bf(t):
     return t.to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("B,Nt,C,Kd,masked", [(6, 257, 256, 768, True), (4, 65, 512, 1536, True), (3, 50, 192, 256, False),
-                                              (5, 17, 448, 128, True), (2, 33, 8, 72, False), (5, 257, 320, 1280, True),
-                                              (3, 70, 296, 320, False)])
-def test_gemm_ln_forward(B, Nt, C, Kd, masked):
+# sched 8: the one-workgroup-per-CU form (gemm_nt_lnw.hip, opt-in); 16: never.
+# (130 x 257: not a multiple of 16 rows, 8 or 9 blocks per workgroup; 150 x 257: two tiles per workgroup)
+@pytest.mark.parametrize("B,Nt,C,Kd,masked,sched", [
+    (6, 257, 256, 768, True, 16), (4, 65, 512, 1536, True, 0), (3, 50, 192, 256, False, 16), (5, 17, 448, 128, True, 0),
+    (2, 33, 8, 72, False, 16), (5, 257, 320, 1280, True, 0), (3, 70, 296, 320, False, 0),
+    (6, 257, 256, 768, True, 8), (3, 50, 192, 256, False, 8), (2, 33, 8, 72, False, 8), (21, 257, 248, 200, True, 8),
+    (130, 257, 256, 768, True, 8), (150, 257, 256, 256, True, 8), (130, 257, 256, 768, True, 0)])
+def test_gemm_ln_forward(B, Nt, C, Kd, masked, sched):
     """mode 0 == vr_gemm (residual epilogue) followed by vr_ln_fwd: same residual stream bit for bit (same MFMA order is not
     required: compared with tolerance), LayerNorm output / statistics within bf16 / fp32 rounding."""
     M = B * Nt
@@ -810,7 +814,7 @@ def test_gemm_ln_forward(B, Nt, C, Kd, masked):
     out = torch.empty(M, C, device=DEV)
     kw_d = {k: (cu(v) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
     assert K.gemm_ln_supported(cu(a), C, C)
-    y, mu, rs = K.gemm_ln_fwd(cu(a), cu(w), out, cu(lw), cu(lb), cu(ln_keep), 1e-6, **kw_d)
+    y, mu, rs = K.gemm_ln_fwd(cu(a), cu(w), out, cu(lw), cu(lb), cu(ln_keep), 1e-6, sched=sched, **kw_d)
     torch.cuda.synchronize()
     assert relerr(out, out_ref) < 2e-5
     assert relerr(mu, mu_ref) < 2e-5 and relerr(rs, rs_ref) < 1e-4
@@ -821,11 +825,14 @@ def test_gemm_ln_forward(B, Nt, C, Kd, masked):
     assert float((y.float() - y2.float()).abs().max()) <= 2 ** -6 * float(y2.float().abs().max())
 
 
-@pytest.mark.parametrize("B,Nt,C,Kd,masked,nxt", [(6, 257, 256, 768, True, True), (4, 65, 512, 1536, True, True),
-                                                  (3, 50, 192, 256, False, False), (5, 17, 448, 192, True, False),
-                                                  (2, 33, 8, 72, False, True), (5, 257, 320, 960, True, True),
-                                                  (3, 70, 296, 320, False, False)])
-def test_gemm_ln_backward(B, Nt, C, Kd, masked, nxt):
+@pytest.mark.parametrize("B,Nt,C,Kd,masked,nxt,sched", [
+    (6, 257, 256, 768, True, True, 16), (4, 65, 512, 1536, True, True, 0), (3, 50, 192, 256, False, False, 16),
+    (5, 17, 448, 192, True, False, 0), (2, 33, 8, 72, False, True, 16), (5, 257, 320, 960, True, True, 0),
+    (3, 70, 296, 320, False, False, 0),
+    (6, 257, 256, 768, True, True, 8), (3, 50, 192, 256, False, False, 8), (2, 33, 8, 72, False, True, 8),
+    (21, 257, 248, 200, True, True, 8), (130, 257, 256, 768, True, True, 8), (150, 257, 256, 256, True, False, 8),
+    (130, 257, 256, 768, True, True, 0)])
+def test_gemm_ln_backward(B, Nt, C, Kd, masked, nxt, sched):
     """mode 1 == data-gradient GEMM (fp32 result) followed by vr_ln_bwd."""
     M = B * Nt
     du, wt = _bf(rnd(M, Kd, seed=1)), _bf(rnd(C, Kd, seed=2, scale=Kd ** -0.5))
@@ -850,7 +857,7 @@ def test_gemm_ln_backward(B, Nt, C, Kd, masked, nxt):
     dw, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     real = K.gemm_ln_bwd(cu(du), cu(wt), cu(x), cu(lw), cu(mean), cu(rstd), cu(ln_keep), cu(dx_in), dw, db,
                          next_cast=None if nc is None else (cu(nc[0]), cu(nc[1])), M=M, N=C, K=Kd, lda=Kd, ldb=Kd, rows_in=Nt,
-                         keep_k=cu(keep_k))
+                         keep_k=cu(keep_k), sched=sched)
     torch.cuda.synchronize()
     dx, dx_ref = (real[0], ref[0]) if nxt else (real, ref)
     assert relerr(dx, dx_ref) < 5e-5

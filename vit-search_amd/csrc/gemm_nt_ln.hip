@@ -47,7 +47,8 @@ struct RowMeta {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 template <int MI, int NJ, int MODE, bool KTAIL>
-__global__ __launch_bounds__(NTHR, 3) void ntln_kernel(const vr_gemm_args p, const vr_ln_epilogue f) {
+__global__ __launch_bounds__(NTHR, NJ > 5 ? 2 : 3) void ntln_kernel(   // (32 x 512 tiles: 68 KB of LDS, two per CU)
+   const vr_gemm_args p, const vr_ln_epilogue f) {
     constexpr int BM = 16 * MI, BN = 64 * NJ, WCOLS = 16 * NJ;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int AP = BM / 32, BP = BN / 32;                      // LDS-DMA pieces (8 rows x 128 B) per wave
@@ -422,6 +423,8 @@ template <int MI, int NJ> int launch(const vr_gemm_args& a, const vr_ln_epilogue
 
 }  // namespace vr_gemm_ntln
 
+bool vr_gemm_lnw_launch(const vr_gemm_args& a, const vr_ln_epilogue& f, hipStream_t stream);   // gemm_nt_lnw.hip
+
 extern "C" int vr_gemm_ln_supported(int32_t N) { return N > 0 && N % 8 == 0 && N <= 512; }
 
 extern "C" int vr_gemm_ln(const vr_gemm_args* g, const vr_ln_epilogue* ln, vr_stream_t stream) {
@@ -438,6 +441,10 @@ extern "C" int vr_gemm_ln(const vr_gemm_args* g, const vr_ln_epilogue* ln, vr_st
         if (!ln->x || !ln->mean || !ln->rstd || !ln->dw || !ln->db || a.bias || a.scale || a.keep_n) return VR_EINVAL;
     } else {
         return VR_EINVAL;
+    }
+    if (vr_gemm_lnw_launch(a, *ln, (hipStream_t)stream)) {               // long and narrow: one workgroup per CU, three-stage ring
+        VR_CHECK_LAUNCH();
+        return VR_OK;
     }
     if (a.N <= 256) return launch<4, 4>(a, *ln, (hipStream_t)stream);
     if (a.N <= 320) return launch<4, 5>(a, *ln, (hipStream_t)stream);      // sr_small's first stage: 64 x 320 tiles

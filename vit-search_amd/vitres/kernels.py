@@ -159,10 +159,10 @@ def _launch_gemm_ln(args, ln, a, M, N, K, rows_in, keep_k, keep_n, k_period, ext
 
 
 def gemm_ln_fwd(a, b, out, ln_w, ln_b, ln_keep, eps, *, M, N, K, lda, ldb, ldc, bias=None, scale=None, keep_n=None,
-                resid=None, rows_in=0, keep_k=None, k_period=0):
+                resid=None, rows_in=0, keep_k=None, k_period=0, sched=0):
     """out = resid + scale * mask(a @ b^T + bias) (fp32) and (y, mean, rstd) = masked LayerNorm(out) -- vr_gemm_ln mode 0."""
     args = _gemm_args(a, b, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, bias=bias, scale=scale, keep_n=keep_n, resid=resid,
-                      rows_in=rows_in, keep_k=keep_k, k_period=k_period)
+                      rows_in=rows_in, keep_k=keep_k, k_period=k_period, sched=sched)
     y = torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
     mean = torch.empty(M, dtype=torch.float32, device=out.device)
     rstd = torch.empty(M, dtype=torch.float32, device=out.device)
@@ -174,14 +174,14 @@ def gemm_ln_fwd(a, b, out, ln_w, ln_b, ln_keep, eps, *, M, N, K, lda, ldb, ldc, 
 
 
 def gemm_ln_bwd(du, wt, x, ln_w, mean, rstd, ln_keep, dx_in, dw, db, next_cast=None, *, M, N, K, lda, ldb, rows_in=0,
-                keep_k=None, k_period=0, copies=1):
+                keep_k=None, k_period=0, copies=1, sched=0):
     """LayerNorm backward of dy = du @ wt^T without writing dy -- vr_gemm_ln mode 1; returns dx or (dx, gt) like ln_bwd
     (copies: dw / db are [copies, N] partial rows, see ln_bwd)."""
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     gt = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if next_cast is not None else None
     sc, kp = next_cast if next_cast is not None else (None, None)
     args = _gemm_args(du, wt, dx, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, resid=dx_in, rows_in=rows_in, keep_k=keep_k,
-                      k_period=k_period)
+                      k_period=k_period, sched=sched)
     ln = LnEpilogue()
     ln.mode, ln.eps = 1, 0.0
     ln.w, ln.keep, ln.mean, ln.rstd, ln.x = _p(ln_w), _p(ln_keep), _p(mean), _p(rstd), _p(x)
