@@ -125,6 +125,18 @@ def cpu_baseline_evo(cands, seconds_budget=20.0):
                       "torch %d threads" % (n, B, cores)}
 
 
+def write_launch_table(path, profile, descs, steps):
+    rows = {}
+    for (kind, fl, dense, by, e0, e1), desc in zip(profile, descs):
+        r = rows.setdefault(desc, [0, 0.0, 0.0, 0.0, 0.0])
+        r[0] += 1; r[1] += e0.elapsed_time(e1) * 1e-3; r[2] += fl; r[3] += dense; r[4] += by
+    with open(path, "w") as f:
+        f.write("%-86s %5s %8s %8s %8s %8s %9s\n" % ("launch", "n", "us", "TF kept", "TF dense", "GB/s", "us/step"))
+        for desc, r in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+            f.write("%-86s %5d %8.1f %8.1f %8.1f %8.1f %9.1f\n" % (desc[:86], r[0], r[1] / r[0] * 1e6, r[2] / r[1] / 1e12,
+                                                                 r[3] / r[1] / 1e12, r[4] / r[1] / 1e9, r[1] / steps * 1e6))
+
+
 def run_evo_eval(args, rank, world, device):
     """C5: 512 candidates drawn by the restated gen_random_network_def under the 2.9e9-MAC constraint of
     evolutionary_search/no_distill/small_flexible-conv-patch.sh:19, dealt over the ranks (candidate-sharded), each
@@ -186,11 +198,15 @@ def run_evo_eval(args, rank, world, device):
     roof = None
     if args.profile_steps > 0:
         K.PROFILE = []
+        K.PROFILE_DESC = [] if args.launch_table else None
         for i in range(args.profile_steps):
             torch.cuda.synchronize()
             torch.cuda._sleep(int(0.04 * 2.0e9))         # (see the training workloads: the step is queued before the GPU starts it)
             step(args.warmup + i)
         torch.cuda.synchronize()
+        if args.launch_table:
+            write_launch_table(args.launch_table, K.PROFILE, K.PROFILE_DESC, args.profile_steps)
+            K.PROFILE_DESC = None
         sec = fl = by = dense = 0.0
         n = 0
         for kind, f_, d_, b_, e0, e1 in K.PROFILE:
@@ -418,16 +434,7 @@ def main():
             eager_step(10_000 + i, exchange=False)      # rank 0 only, after the timed region: no collectives here
         torch.cuda.synchronize()
         if args.launch_table:                            # dev aid: per-shape table of the GEMM launches (time, TF/s, GB/s)
-            rows = {}
-            for (kind, fl, dense, by, e0, e1), desc in zip(K.PROFILE, K.PROFILE_DESC):
-                r = rows.setdefault(desc, [0, 0.0, 0.0, 0.0, 0.0])
-                r[0] += 1; r[1] += e0.elapsed_time(e1) * 1e-3; r[2] += fl; r[3] += dense; r[4] += by
-            with open(args.launch_table, "w") as f:
-                f.write("%-86s %5s %8s %8s %8s %8s %9s\n" % ("launch", "n", "us", "TF kept", "TF dense", "GB/s", "us/step"))
-                for desc, r in sorted(rows.items(), key=lambda kv: -kv[1][1]):
-                    f.write("%-86s %5d %8.1f %8.1f %8.1f %8.1f %9.1f\n" % (desc[:86], r[0], r[1] / r[0] * 1e6, r[2] / r[1] / 1e12,
-                                                                         r[3] / r[1] / 1e12, r[4] / r[1] / 1e9,
-                                                                         r[1] / args.profile_steps * 1e6))
+            write_launch_table(args.launch_table, K.PROFILE, K.PROFILE_DESC, args.profile_steps)
             K.PROFILE_DESC = None
         agg = {}
         for kind, fl, dense, by, e0, e1 in K.PROFILE:

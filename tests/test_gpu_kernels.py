@@ -104,6 +104,36 @@ def _wide_case(M, N, K_, variant, rows_in, seed=0):
     return a, b, torch.zeros(M, N, dtype=out_dtype), kw
 
 
+@pytest.mark.parametrize("M,N,K_,rows_in", [(2176, 1024, 3072, 17), (8320, 512, 1536, 65), (2176, 1024, 2304, 17), (1300, 320, 640, 65),
+                                            (4 * 257, 512, 192, 257)])
+@pytest.mark.parametrize("variant", ["res", "dgrad"])
+@pytest.mark.parametrize("sched", [64, 65])
+def test_gemm_split_k(M, N, K_, rows_in, variant, sched):
+    """Split-K form of the 4-wave kernel (gemm_nt.hip SPLIT, sched bit 64: by grid size -- three shares per tile at the first three
+    shapes, two forced at the small ones; bit 1 there: two slices per round): fp32-residual forward and the plain bf16 data
+    gradient, prefix masks on both sides (a share beyond a tile's kept prefix has no slices), launch after launch -- the tickets
+    must come back to zero -- and beside a busy second stream (no share may wait for another)."""
+    a, b, out, kw = _wide_case(M, N, K_, variant, rows_in)
+    ref = E.gemm(a, b, out.clone(), **{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+    kw_d = {k: to(v) for k, v in kw.items()}
+    ad, bd = a.to(DEV), b.to(DEV)
+    t_ = 1e-4 if out.dtype == torch.float32 else 8e-3
+    side = torch.cuda.Stream()
+    busy = torch.randn(4096, 4096, device=DEV)
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            busy = torch.tanh(busy @ busy * 1e-2)
+    for rep in range(4):
+        real = K.gemm(ad, bd, torch.full_like(out, float("nan")).to(DEV), sched=sched, **kw_d)
+        torch.cuda.synchronize()
+        assert relerr(real, ref) < t_, (variant, rep, relerr(real, ref))
+    ws = K._workspace(torch.device(DEV))
+    assert ws is not None and int(ws[:8192].view(torch.int32).abs().sum()) == 0          # tickets back at zero
+    plain = K.gemm(ad, bd, torch.zeros_like(out).to(DEV), sched=0, **kw_d)
+    assert relerr(plain, ref) < t_
+
+
 @pytest.mark.parametrize("M,N,K_,rows_in", [(2176, 1024, 3072, 17), (8320, 512, 1536, 65), (1300, 320, 640, 65), (2176, 768, 1024, 17),
                                             (4 * 257, 1536, 512, 257), (33 * 256, 256, 768, 256), (32896, 1024, 256, 257)])
 @pytest.mark.parametrize("variant", ["fwd", "gelu", "res", "dgrad", "dmul"])

@@ -53,7 +53,7 @@ def _rm(m):
 # that finds none while capturing simply runs without tile sharing.
 _WS = {}
 _WS_ROLE = [0]
-_WIDE_ON = __import__("os").environ.get("VITRES_NT_WIDE", "0") != "0"
+_WIDE_ON = __import__("os").environ.get("VITRES_NT_WIDE", "0") != "0" or __import__("os").environ.get("VITRES_NT_SPLIT", "0") != "0"
 
 
 class ws_role:
@@ -97,7 +97,7 @@ def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=Fals
                a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0, ws="auto"):
     args = GemmArgs()
     if isinstance(ws, str):         # "auto": the role's workspace, when the 8-wave stream-K kernel can be chosen at all (opt-in)
-        ws = _workspace(a.device) if ((_WIDE_ON or (sched & (8 | 32))) and not a_trans and a.dtype == torch.bfloat16 and a.is_cuda and
+        ws = _workspace(a.device) if ((_WIDE_ON or (sched & (8 | 32 | 64))) and not a_trans and a.dtype == torch.bfloat16 and a.is_cuda and
                                       M >= 256 and K >= 128) else None
     if ws is not None:
         args.ws, args.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
