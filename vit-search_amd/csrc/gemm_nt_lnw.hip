@@ -59,7 +59,7 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ float sgpr(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 template <int MODE, bool KTAIL>
-__global__ __launch_bounds__(NTHR, 1) void ntlnw_kernel(const vr_gemm_args p, const vr_ln_epilogue f, const int nblk, const int ntile, const int dbg) {
+__global__ __launch_bounds__(NTHR, 1) void ntlnw_kernel(const vr_gemm_args p, const vr_ln_epilogue f, const int nblk, const int ntile) {
     __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE + MIX * 16 * (int)sizeof(RowMeta)];
     RowMeta* rowmeta = reinterpret_cast<RowMeta*>(smem + NST * STAGE);
     const int t = threadIdx.x, lane = t & 63;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NTHR, 1) void ntlnw_kernel(const vr_gemm_args p, co
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        int cur = (dbg & 1) ? ntiles : live.take();
+        int cur = live.take();
         int nxt = cur < ntiles ? live.take() : ntiles;
         if (cur < ntiles) issue(cur, 0);
         if (nxt < ntiles) issue(nxt, 1);
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(NTHR, 1) void ntlnw_kernel(const vr_gemm_args p, co
 
         // ---- row loop: wave w walks tile rows w, w + 8, ... in rounds of RU ----
         const int nrow = 2 * mi;                                   // rows per wave
-        const int nround = (dbg & 2) ? 0 : (nrow + RU - 1) / RU;
+        const int nround = (nrow + RU - 1) / RU;
         auto request = [&](int it, Side& sd) {
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
@@ -384,14 +384,13 @@ bool vr_gemm_lnw_launch(const vr_gemm_args& a, const vr_ln_epilogue& f, hipStrea
     const int rounds = (nblk + MIX * n_cu - 1) / (MIX * n_cu);
     const int ntile = min(nblk, n_cu * rounds);                    // every tile gets nblk / ntile (+1) blocks <= MIX
     const bool ktail = (a.K % BK) != 0;
-    static const int dbg = [] { const char* e = getenv("VITRES_NTLNW_DBG"); return e ? atoi(e) : 0; }();
     const dim3 grid((unsigned)min(ntile, n_cu)), block(NTHR);
     if (f.mode == 0) {
-        if (ktail) hipLaunchKernelGGL((ntlnw_kernel<0, true>), grid, block, 0, stream, a, f, nblk, ntile, dbg);
-        else hipLaunchKernelGGL((ntlnw_kernel<0, false>), grid, block, 0, stream, a, f, nblk, ntile, dbg);
+        if (ktail) hipLaunchKernelGGL((ntlnw_kernel<0, true>), grid, block, 0, stream, a, f, nblk, ntile);
+        else hipLaunchKernelGGL((ntlnw_kernel<0, false>), grid, block, 0, stream, a, f, nblk, ntile);
     } else {
-        if (ktail) hipLaunchKernelGGL((ntlnw_kernel<1, true>), grid, block, 0, stream, a, f, nblk, ntile, dbg);
-        else hipLaunchKernelGGL((ntlnw_kernel<1, false>), grid, block, 0, stream, a, f, nblk, ntile, dbg);
+        if (ktail) hipLaunchKernelGGL((ntlnw_kernel<1, true>), grid, block, 0, stream, a, f, nblk, ntile);
+        else hipLaunchKernelGGL((ntlnw_kernel<1, false>), grid, block, 0, stream, a, f, nblk, ntile);
     }
     return true;
 }
