@@ -358,7 +358,8 @@ def main():
         if graphed is None:
             return eager_step(i)
         if graphed.optimizer is not None:
-            opt.prepare_step()                                   # this step's lr / bias corrections -> device; the graph does the rest
+            if graphed.defer is None:
+                opt.prepare_step()                               # this step's lr / bias corrections -> device; the graph does the rest
             return graphed(x, t, pt, epoch=31, train_iter=i, arch_sample=arch)
         # fwd + loss + bwd (hipGraph replay) + gradient exchange (averaged), then the optimizer
         loss = graphed.step_with_sync(sync, x, t, pt, average=average, epoch=31, train_iter=i, arch_sample=arch)

@@ -746,14 +746,17 @@ def test_single_stage_patch16_sibling_vs_reference_golden(mode, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_optimizer_inside_the_graph_equals_step_after_the_graph(dtype):
-    """GraphedTrainStep(optimizer=FlatAdamW): the AdamW update captured into the step's hipGraph (arena tail on the side stream
-    beside the rest of the backward, hyper-parameters read from device memory that prepare_step() rewrites per step) walks the
-    same parameter trajectory as graph replay + optimizer.step(), including a learning-rate change between steps."""
+@pytest.mark.parametrize("dtype,defer", [(torch.float32, "0"), (torch.bfloat16, "0"), (torch.bfloat16, "1"), (torch.float32, "1")])
+def test_optimizer_inside_the_graph_equals_step_after_the_graph(dtype, defer, monkeypatch):
+    """GraphedTrainStep(optimizer=FlatAdamW): the AdamW update captured into the step's hipGraph (hyper-parameters read from device
+    memory that prepare_step() rewrites per step) walks the same parameter trajectory as graph replay + optimizer.step(),
+    including a learning-rate change between steps.  defer = 1: the graph OPENS with the previous replay's update (arena head on
+    the main stream, the rest beside the first stage's forward), the first replay's update is a no-op and finish_update() applies
+    the last one."""
     from vitres import engine
     from vitres.optim import FlatAdamW
     from vitres.losses import SoftTargetCrossEntropy
+    monkeypatch.setenv("VITRES_OPT_DEFER", defer)
     crit = SoftTargetCrossEntropy()
     x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1))
     runs = []
@@ -768,18 +771,24 @@ def test_optimizer_inside_the_graph_equals_step_after_the_graph(dtype):
             opt.own_shadow()
         g = engine.GraphedTrainStep(prod, crit, x, t, pt, "seq", optimizer=opt if in_graph else None)
         assert (g.optimizer is not None) == in_graph
+        if in_graph:
+            assert (g.defer is not None) == (defer == "1")
         losses = []
         for it in range(4):
             torch.manual_seed(900 + it)
             if it == 2:
+                if in_graph:
+                    g.finish_update()                              # (a learning-rate change: the pending update is due first)
                 for grp in opt.param_groups:
                     grp["lr"] = 5e-4                               # scheduler-style change
             if in_graph:
-                opt.prepare_step()
+                if g.defer is None:
+                    opt.prepare_step()
                 losses.append(g(x, t, pt, epoch=31, train_iter=it, arch_sample=None).item())
             else:
                 losses.append(g(x, t, pt, epoch=31, train_iter=it, arch_sample=None).item())
                 opt.step()
+        g.finish_update()
         torch.cuda.synchronize()
         runs.append((losses, prod._arena["flat"].clone(), opt._flat_state["v"].clone(), opt._flat_state["ema"].clone(), opt._step,
                      prod._arena["shadow"].clone() if dtype == torch.bfloat16 else None))

@@ -3,6 +3,8 @@
 // otherwise are separate passes over the 70-144 M parameters: the bf16 shadow the next forward's GEMMs read
 // (vr_cast_f32_bf16), the 1/world averaging of the all-reduced gradient, and the ModelEmaV2 update (main.py:357-363,
 // ema = d * ema + (1 - d) * p).  One streaming pass, 16-byte accesses, HBM-bound: 28 B/param (+2 shadow, +8 EMA).
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/vitres_hip.h"
 
@@ -24,6 +26,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const int gi = group_of_8[i];
         if (gi == 255) continue;                                   // padding / frozen parameters
         const vr_adamw_group h = DEV ? groups_dev[gi] : groups.g[gi];
+        if (DEV && h.bias_c1 == 0.f) continue;                     // (1 - beta1^t is never 0: an all-zero group = "no update this replay")
         const long long e = i * 8;
         float pv[8], gv[8], mv[8], vv[8];
 #pragma unroll
@@ -83,7 +86,9 @@ static int adamw_launch(float* p, const float* g, float* m, float* v, void* shad
         for (int i = 0; i < n_groups; ++i) gs.g[i] = groups[i];
     const long long n8 = n / 8;
     long long blocks = (n8 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    static const int knob_blocks = std::getenv("VITRES_ADAMW_BLOCKS") ? std::atoi(std::getenv("VITRES_ADAMW_BLOCKS")) : 0;
+    const long long cap = knob_blocks > 0 ? knob_blocks : 8192;
+    if (blocks > cap) blocks = cap;
     if (on_device)
         hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow,
                            ema, ema_decay, group_of_8, gs, groups, n8);

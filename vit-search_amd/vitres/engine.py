@@ -271,6 +271,20 @@ class GraphedTrainStep:
         self.optimizer = optimizer if (optimizer is not None and hasattr(optimizer, "step_device")) else None
         if self.optimizer is not None and split_for_sync:
             raise ValueError("optimizer-in-graph is for one rank; with a gradient exchange step the optimizer after step_with_sync")
+        # deferred form (VITRES_OPT_DEFER=1, nets with a spatial reduction): the graph OPENS with the update of the previous replay's
+        # gradients -- arena head on the main stream, the rest (stages 2.., heads: most parameters) on the side stream beside the
+        # first stage's forward -- instead of closing with a 0.36 ms pass nothing overlaps.  Same sequence of updates; the LAST one
+        # is applied by finish_update() (call it before evaluating, checkpointing or changing the learning rate: end of an
+        # epoch); this object then calls optimizer.prepare_step() itself.  Measured round 3: 7.73 - 7.84 against 7.80 - 7.85 ms
+        # (the 8192-workgroup update takes the CUs first -- the forward's first GEMM waits 350 us behind it -- and capped at
+        # 256 - 2048 workgroups, VITRES_ADAMW_BLOCKS, the forward slows by what the update reads): within noise, so opt-in.
+        self.defer, self._pending = None, False
+        if self.optimizer is not None and os.environ.get("VITRES_OPT_DEFER", "0") != "0" and hasattr(model, "split_plan"):
+            model._ensure_arena(samples.device)
+            cuts3 = model.split_plan(parts=99)
+            has_sr = any(type(b).__name__ == "SpatialReductionPatchEmbedding" for b in getattr(model, "blocks", []))
+            if has_sr and isinstance(cuts3, list) and cuts3 and cuts3[-1][1] % 8 == 0:
+                self.defer = cuts3[-1][1]                          # arena offset of the first spatial reduction
         # soft-target CE is the training loss of every shipped recipe (main.py:390-398): the whole step then runs without
         # autograd and without torch glue between the heads and the backward (model.loss_and_grad / vr_softce_train)
         from .losses import SoftTargetCrossEntropy
@@ -330,12 +344,15 @@ class GraphedTrainStep:
                 if opt_cut is not None:
                     model._bwd_split = opt_cut[0]
                     model._bwd_join_parts = False                  # the second part follows in the same capture
+            if self.defer is not None:
+                opt_cut = None
+                model._deferred_update = (self.optimizer, self.defer)
             with torch.cuda.graph(self.graph):
                 if self.keep_static is not None:
                     model.attach_plan_buffer(plan, self.keep_static, self._plan_nk)
                 plan.embed_col = self.col_static
                 self.loss = self._step_body(plan)
-                if self.optimizer is not None:
+                if self.optimizer is not None and self.defer is None:
                     from . import functional as Fn
                     n_arena = model._arena["flat"].numel()
                     if opt_cut is not None and getattr(model, "_bwd_state", None) is not None:
@@ -356,6 +373,7 @@ class GraphedTrainStep:
         finally:
             model._bwd_split = None
             model._bwd_join_parts = True
+            model._deferred_update = None
         if self.more_graphs:
             self.graph_b = self.more_graphs[0]
             end = model._arena["gcur"].numel()
@@ -419,6 +437,9 @@ class GraphedTrainStep:
             self.t.copy_(targets, non_blocking=True)
             if self.pt is not None:
                 self.pt.copy_(patch_targets, non_blocking=True)
+        if self.defer is not None:
+            self.optimizer.prepare_step(noop=not self._pending)   # the update this replay opens with: the previous replay's gradients
+            self._pending = True
         self.graph.replay()
         self.model._stem_fold = None                               # (stem.drop_fold: the replay moved BatchNorm's running statistics)
         for k, g in enumerate(self.more_graphs):
@@ -426,6 +447,13 @@ class GraphedTrainStep:
                 self._works.append(self._sync.all_reduce_range(*self.ranges[k]))
             g.replay()
         return self.loss
+
+    def finish_update(self):
+        """Deferred optimizer-in-graph: apply the update of the last replay's gradients now (eagerly).  No-op otherwise."""
+        if self.defer is not None and self._pending:
+            self.optimizer.prepare_step()
+            self.optimizer.step_device(0, self.model._arena["flat"].numel())
+            self._pending = False
 
     _sync, _works = None, ()
 

@@ -758,6 +758,21 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
 
     def _run_forward(self, x, plan, with_patch, save):
         a = self._arena
+        # engine.GraphedTrainStep(optimizer=..., deferred): the PREVIOUS replay's AdamW update opens this forward -- the head of the
+        # arena (tokens, positional embedding, patch embedding, first stage) here, the rest (most parameters) on the side stream
+        # beside the first stage, which does not read them; joined with side_prep in front of the first spatial reduction
+        du = getattr(self, "_deferred_update", None)
+        du_side = None
+        if du is not None:
+            opt_, lo_ = du
+            n_ = a["flat"].numel()
+            if (save and self.compute_dtype == torch.bfloat16 and a["tr"] is not None and Fn.OVERLAP and a["flat"].is_cuda and
+                    0 < lo_ < n_):
+                Fn.join_side()             # (a previous forward's side work)
+                opt_.step_device(0, lo_)
+                du_side = (opt_, lo_, n_)
+            else:
+                opt_.step_device(0, n_)
         if self.compute_dtype == torch.bfloat16:
             if Fn.OVERLAP and a["flat"].is_cuda:
                 Fn.join_side()             # a previous forward's side work (if its backward never ran)
@@ -794,6 +809,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 fresh = a["gflat"] is not None and all(p_.grad is None for p_ in a["params"])
 
                 def side_prep():
+                    if du_side is not None:
+                        du_side[0].step_device(du_side[1], du_side[2])
                     K.cast_transpose_batch(a["flat"], a["shadow_t"], a["tr"])
                     for blk_ in self.blocks:
                         if isinstance(blk_, SpatialReductionPatchEmbedding):

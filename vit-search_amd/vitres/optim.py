@@ -91,22 +91,26 @@ class FlatAdamW(torch.optim.Optimizer):
                              math.sqrt(1.0 - b2 ** t), self.grad_scale)
         return arr
 
-    def prepare_step(self):
+    def prepare_step(self, noop=False):
         """Advance the step count and upload this step's per-group hyper-parameters (learning rates written by the scheduler,
         bias corrections) to the device buffer step_device() launches read -- call once before every replay of a graph that
-        contains step_device() launches (engine.GraphedTrainStep(optimizer=...))."""
+        contains step_device() launches (engine.GraphedTrainStep(optimizer=...)).  noop: upload all-zero groups instead -- the
+        captured launches then change nothing (vr_adamw_flat_dev skips a group whose bias correction is 0) and the step count
+        stays: the first replay of a graph that applies the PREVIOUS replay's gradients."""
         a = self._bind()
         dev = a["flat"].device
         if getattr(self, "_hp_dev", None) is None or self._hp_dev.device != dev:
             self._hp_dev = torch.zeros(MAX_GROUPS * 8, dtype=torch.float32, device=dev)
-        self._step += 1
-        self.model._stem_fold = None           # parameters change through raw pointers: no Tensor._version moves (stem.drop_fold)
-        arr = self._group_structs(self._step)
         vals = []
-        for gi in range(len(self.param_groups)):
-            vals += [getattr(arr[gi], n) for n, _ in _Group._fields_]
+        if not noop:
+            self._step += 1
+            self.model._stem_fold = None       # parameters change through raw pointers: no Tensor._version moves (stem.drop_fold)
+            arr = self._group_structs(self._step)
+            for gi in range(len(self.param_groups)):
+                vals += [getattr(arr[gi], n) for n, _ in _Group._fields_]
         host = torch.zeros(MAX_GROUPS * 8, dtype=torch.float32)
-        host[:len(vals)] = torch.tensor(vals, dtype=torch.float32)
+        if vals:
+            host[:len(vals)] = torch.tensor(vals, dtype=torch.float32)
         if dev.type == "cuda":
             host = host.pin_memory()       # a fresh pinned block per step: the host runs several replays ahead of the device, a
                                            # reused staging buffer would be overwritten before its copy has executed
