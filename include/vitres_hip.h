@@ -208,7 +208,8 @@ int vr_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, fl
                   vr_stream_t stream);
 /* Same pass with `groups_dev` in DEVICE memory (read by the kernel at run time): a launch captured into a hipGraph then follows the
  * schedule -- the caller rewrites the n_groups structs before every replay.  All array arguments may point into the middle of
- * the arena (a range of it, offsets multiples of 8 elements; group_of_8 advanced by offset / 8). */
+ * the arena (a range of it, offsets multiples of 8 elements; group_of_8 advanced by offset / 8).  A group whose bias_c1 is 0
+ * (never the case for a real step) is skipped: an all-zero block turns a captured launch into a no-op for that replay. */
 int vr_adamw_flat_dev(float* p, const float* g, float* m, float* v, void* shadow, float* ema, float ema_decay,
                       const uint8_t* group_of_8, const vr_adamw_group* groups_dev, int32_t n_groups, int64_t n,
                       vr_stream_t stream);
