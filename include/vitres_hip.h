@@ -409,6 +409,12 @@ int vr_conv3x3(const void* a, const void* w, void* out, int32_t B, int32_t H, in
  */
 int vr_conv3x3_bias_relu(const void* a, const void* w, const float* bias, const void* res, void* out, int32_t B, int32_t H,
                          int32_t W, int32_t Cin, int32_t Cout, int32_t out_dtype, vr_stream_t stream);
+/* out = conv(a, w) + res[pixel, co] (bf16): the data gradient of conv2 plus the gradient arriving over the stem's skip connection
+ * (autograd of `x = conv3(conv2(a1)) + a1`, nets/patch_conv.py:69) without a separate add pass. */
+int vr_conv3x3_res(const void* a, const void* w, const void* res, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                   int32_t Cout, int32_t out_dtype, vr_stream_t stream);
+/* Weights of that data-gradient convolution: dst[ci, (kh, kw, co)] = src[co, ci, 2 - kh, 2 - kw] (src fp32 [Co, Ci, 3, 3]). */
+int vr_conv_w_flip(const float* src, void* dst, int32_t Co, int32_t Ci, int32_t dst_dtype, vr_stream_t stream);
 
 /*
  * conv1 of the conv patch embedding (nets/patch_conv.py:63: 3x3 / stride 2 / pad 1, 3 -> Cout <= 32 channels) straight from
@@ -422,6 +428,12 @@ int vr_conv1_direct(const float* img, const void* w, const float* bias, void* ou
 int vr_conv3x3_wgrad(const void* a, const void* dz, float* dw, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                      vr_stream_t stream);
 int vr_bn_stats(const void* z, float* sum, float* sumsq, int64_t R, int32_t C, int32_t z_dtype, vr_stream_t stream);
+/* Between vr_bn_stats and vr_bn_relu in training (torch.nn.BatchNorm2d, nets/patch_conv.py:23-38): mean = sum / n, var = sumsq / n -
+ * mean^2 (>= 0); running_mean / running_var (optional, both or none) <- (1 - momentum) * running + momentum * (mean | var * n / (n - 1));
+ * *num_batches_tracked += 1 (optional); rstd = 1 / sqrt(var + eps), scale = weight * rstd, shift = bias - mean * scale. */
+int vr_bn_finalize(const float* sum, const float* sumsq, int64_t n, const float* weight, const float* bias, float eps, float momentum,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* mean,
+                   float* rstd, int32_t C, vr_stream_t stream);
 int vr_bn_relu(const void* z, const float* scale, const float* shift, const void* res, void* out, int64_t R, int32_t C,
                int32_t dtype, int32_t z_dtype, vr_stream_t stream);
 int vr_bn_bwd(const void* da, const void* z, const float* scale, const float* shift, const float* mean, const float* rstd,

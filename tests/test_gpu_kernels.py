@@ -490,6 +490,39 @@ def test_relayout_and_zero():
         assert float(K.zero_(t).float().abs().max()) == 0.0
 
 
+def test_stem_glue_kernels():
+    """vr_bn_finalize (train-mode BatchNorm2d between the statistics and the normalise pass, running statistics included) against
+    torch.nn.BatchNorm2d itself; vr_conv_w_flip and vr_conv3x3_res against their torch statements."""
+    C, R = 24, 4096
+    z = rnd(R, C, seed=1) * 2 + 0.5
+    bn = torch.nn.BatchNorm2d(C).to(DEV)
+    ref = torch.nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        for m_ in (bn, ref):
+            m_.weight.copy_(1 + 0.1 * rnd(C, seed=2).to(DEV)); m_.bias.copy_(0.1 * rnd(C, seed=3).to(DEV))
+            m_.running_mean.copy_(rnd(C, seed=4).to(DEV)); m_.running_var.copy_(rnd(C, seed=5).abs().to(DEV) + 0.5)
+    zd = z.to(DEV)
+    sq = torch.zeros(2, C, device=DEV)
+    K.bn_stats(zd, sq[0], sq[1])
+    scale, shift, mean, rstd = K.bn_finalize(sq, R, bn, bn.momentum, True)
+    ref.train()
+    y_ref = ref(zd.t().reshape(1, C, R, 1))                              # [N=1, C, H=R, W=1]: statistics over the R rows
+    y = zd * scale + shift
+    assert relerr(y, y_ref.reshape(C, R).t()) < 1e-5
+    assert relerr(bn.running_mean, ref.running_mean) < 1e-6 and relerr(bn.running_var, ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    assert relerr(mean, zd.mean(0)) < 1e-5 and relerr(rstd, torch.rsqrt(zd.var(0, unbiased=False) + bn.eps)) < 1e-5
+    w = rnd(24, 24, 3, 3, seed=6)
+    for dt in (torch.float32, torch.bfloat16):
+        assert torch.equal(K.conv_w_flip(w.to(DEV), dt).cpu(), E.conv_w_flip(w, dt))
+    B, H, W = 2, 20, 36
+    a, wt, res = rnd(B * H * W, 24, seed=7).bfloat16(), (rnd(24, 9 * 24, seed=8) * 0.1).bfloat16(), rnd(B * H * W, 24, seed=9).bfloat16()
+    real = K.conv3x3_res(a.to(DEV), wt.to(DEV), res.to(DEV), B, H, W, 24, 24, torch.bfloat16)
+    assert relerr(real, E.conv3x3_res(a, wt, res, B, H, W, 24, 24, torch.bfloat16)) < 8e-3
+    plain = K.conv3x3(a.to(DEV), wt.to(DEV), B, H, W, 24, 24, torch.float32)
+    assert relerr(plain, E.conv3x3(a, wt, B, H, W, 24, 24, torch.float32)) < 1e-4
+
+
 def test_softce():
     for R, Kc in ((8, 10), (128 * 16, 1000)):
         x = rnd(R, Kc, seed=1) * 3

@@ -92,11 +92,11 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const bf16_t* __restrict__
                         const float4 bb = *reinterpret_cast<const float4*>(bias + co);
                         r4[0] = fmaxf(r4[0] + bb.x, 0.f); r4[1] = fmaxf(r4[1] + bb.y, 0.f);
                         r4[2] = fmaxf(r4[2] + bb.z, 0.f); r4[3] = fmaxf(r4[3] + bb.w, 0.f);
-                        if (res) {
-                            const uint2 rr = *reinterpret_cast<const uint2*>(res + (((long long)b * H + oy) * W + ox) * Cout + co);
-                            r4[0] += __uint_as_float(rr.x << 16); r4[1] += __uint_as_float(rr.x & 0xffff0000u);
-                            r4[2] += __uint_as_float(rr.y << 16); r4[3] += __uint_as_float(rr.y & 0xffff0000u);
-                        }
+                    }
+                    if (res) {       // residual (evaluation: behind the ReLU; data gradients: the gradient of the stem's skip branch)
+                        const uint2 rr = *reinterpret_cast<const uint2*>(res + (((long long)b * H + oy) * W + ox) * Cout + co);
+                        r4[0] += __uint_as_float(rr.x << 16); r4[1] += __uint_as_float(rr.x & 0xffff0000u);
+                        r4[2] += __uint_as_float(rr.y << 16); r4[3] += __uint_as_float(rr.y & 0xffff0000u);
                     }
                     if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(dst + co) = make_float4(r4[0], r4[1], r4[2], r4[3]);
                     else *reinterpret_cast<uint2*>(dst + co) = make_uint2(pack_bf2(r4[0], r4[1]), pack_bf2(r4[2], r4[3]));
@@ -335,6 +335,12 @@ static int conv3x3_entry(const void* a, const void* w, void* out, int32_t B, int
 extern "C" int vr_conv3x3(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                           int32_t out_dtype, vr_stream_t stream) {
     return conv3x3_entry(a, w, out, B, H, W, Cin, Cout, out_dtype, nullptr, nullptr, stream);
+}
+
+extern "C" int vr_conv3x3_res(const void* a, const void* w, const void* res, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                              int32_t Cout, int32_t out_dtype, vr_stream_t stream) {
+    if (!res || ((uintptr_t)res & 7)) return VR_EINVAL;
+    return conv3x3_entry(a, w, out, B, H, W, Cin, Cout, out_dtype, nullptr, res, stream);
 }
 
 extern "C" int vr_conv3x3_bias_relu(const void* a, const void* w, const float* bias, const void* res, void* out, int32_t B,

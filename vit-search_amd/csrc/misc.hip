@@ -726,3 +726,25 @@ extern "C" int vr_relayout(const void* src, void* dst, int32_t A, int32_t B, int
     VR_CHECK_LAUNCH();
     return VR_OK;
 }
+
+// ---- vr_conv_w_flip: weights of the data-gradient convolution of a 3x3 / stride 1 / pad 1 Conv2d ------------------------------
+//   dst[ci, (kh, kw, co)] = src[co, ci, 2 - kh, 2 - kw]   (src fp32 [Co, Ci, 3, 3]; dst fp32 / bf16 [Ci, 9 * Co])
+namespace {
+template <typename TD>
+__global__ __launch_bounds__(256) void conv_w_flip_kernel(const float* __restrict__ src, TD* __restrict__ dst, int Co, int Ci) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Co * Ci * 9) return;
+    const int co = i % Co, tap = (i / Co) % 9, ci = i / (9 * Co);
+    Elem<TD>::st(dst + i, src[((long long)co * Ci + ci) * 9 + (8 - tap)]);
+}
+}  // namespace
+
+extern "C" int vr_conv_w_flip(const float* src, void* dst, int32_t Co, int32_t Ci, int32_t dst_dtype, vr_stream_t stream) {
+    if (!src || !dst || Co <= 0 || Ci <= 0) return VR_EINVAL;
+    const unsigned grid = (unsigned)((Co * Ci * 9 + 255) / 256);
+    if (dst_dtype == VR_F32) hipLaunchKernelGGL(conv_w_flip_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, Co, Ci);
+    else if (dst_dtype == VR_BF16) hipLaunchKernelGGL(conv_w_flip_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, Co, Ci);
+    else return VR_EUNSUPPORTED;
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}

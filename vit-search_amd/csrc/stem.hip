@@ -375,6 +375,43 @@ extern "C" int vr_bn_relu(const void* z, const float* scale, const float* shift,
     return VR_OK;
 }
 
+// Train-mode BatchNorm2d between the statistics pass and the normalise pass, one launch instead of a dozen elementwise ones
+// (torch.nn.BatchNorm2d semantics, nets/patch_conv.py:23-38): biased variance for the normalisation, unbiased for the running
+// estimate, running <- (1 - momentum) * running + momentum * batch, num_batches_tracked += 1.
+namespace {
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, float n, const float* __restrict__ w,
+                                   const float* __restrict__ b, float eps, float momentum, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, long long* __restrict__ nbt, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ mean, float* __restrict__ rstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    const float mu = sum[c] / n;
+    const float var = fmaxf(sumsq[c] / n - mu * mu, 0.f);
+    if (rmean) {
+        rmean[c] = rmean[c] * (1.0f - momentum) + momentum * mu;
+        rvar[c] = rvar[c] * (1.0f - momentum) + momentum * (var * (n / fmaxf(n - 1.0f, 1.0f)));
+    }
+    const float rs = 1.0f / sqrtf(var + eps);
+    const float sc = w[c] * rs;
+    mean[c] = mu;
+    rstd[c] = rs;
+    scale[c] = sc;
+    shift[c] = b[c] - mu * sc;
+}
+}  // namespace
+
+extern "C" int vr_bn_finalize(const float* sum, const float* sumsq, int64_t n, const float* weight, const float* bias, float eps,
+                              float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale,
+                              float* shift, float* mean, float* rstd, int32_t C, vr_stream_t stream) {
+    if (!sum || !sumsq || !weight || !bias || !scale || !shift || !mean || !rstd || n <= 0 || C <= 0) return VR_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return VR_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, (hipStream_t)stream, sum, sumsq, (float)n, weight,
+                       bias, eps, momentum, running_mean, running_var, (long long*)num_batches_tracked, scale, shift, mean, rstd, C);
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
 extern "C" int vr_bn_bwd(const void* da, const void* z, const float* scale, const float* shift, const float* mean,
                          const float* rstd, float* sg, float* sgz, void* dz, int64_t R, int32_t C, int32_t training,
                          int32_t dtype, int32_t z_dtype, vr_stream_t stream) {

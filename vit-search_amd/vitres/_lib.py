@@ -76,6 +76,8 @@ SYMBOLS = {
     "vr_conv3x3_wgrad": [c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
     "vr_conv3x3": [c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p],
     "vr_conv3x3_bias_relu": [c_void_p] * 5 + [c_int32] * 6 + [c_void_p],
+    "vr_conv3x3_res": [c_void_p] * 4 + [c_int32] * 6 + [c_void_p],
+    "vr_conv_w_flip": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p],
     "vr_conv1_direct": [c_void_p] * 4 + [c_int32] * 6 + [c_void_p],
     "vr_token_mix": [c_void_p] * 6 + [c_int32] * 11 + [c_float] * 6 + [c_void_p],
     "vr_token_mean": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],
@@ -94,6 +96,7 @@ SYMBOLS = {
     "vr_im2col3x3": [c_void_p, c_void_p] + [c_int32] * 8 + [c_void_p],
     "vr_col2im3x3": [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p],
     "vr_bn_stats": [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p],
+    "vr_bn_finalize": [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_float] + [c_void_p] * 7 + [c_int32, c_void_p],
     "vr_bn_relu": [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32, c_void_p],
     "vr_bn_bwd": [c_void_p] * 9 + [c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "vr_patch_unfold": [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p],

@@ -524,6 +524,34 @@ def conv3x3(a, w, B, H, W, Cin, Cout, out_dtype):
     return out
 
 
+def conv3x3_res(a, w, res, B, H, W, Cin, Cout, out_dtype):
+    """conv3x3(a, w) + res (bf16 [B*H*W, Cout]) in one pass -- vr_conv3x3_res."""
+    out = torch.empty((B * H * W, Cout), dtype=out_dtype, device=a.device)
+    _lib.check(_lib.lib().vr_conv3x3_res(_p(a), _p(w), _p(res), _p(out), B, H, W, Cin, Cout, _dtcode(out_dtype), _stream()),
+               "vr_conv3x3_res")
+    return out
+
+
+def conv_w_flip(w, out_dtype):
+    """Weights of the data-gradient convolution of a 3x3 / stride 1 / pad 1 Conv2d: [Ci, (kh, kw, co)] = w[co, ci, 2-kh, 2-kw]."""
+    Co, Ci = w.shape[0], w.shape[1]
+    out = torch.empty((Ci, 9 * Co), dtype=out_dtype, device=w.device)
+    _lib.check(_lib.lib().vr_conv_w_flip(_p(w), _p(out), Co, Ci, _dtcode(out_dtype), _stream()), "vr_conv_w_flip")
+    return out
+
+
+def bn_finalize(sq, n, bn, momentum, update_running):
+    """(scale, shift, mean, rstd) fp32 [C] of a train-mode BatchNorm2d from its (sum, sum of squares) [2, C]; updates the module's
+    running statistics and batch counter in place (vr_bn_finalize)."""
+    C = sq.shape[1]
+    out = torch.empty((4, C), dtype=torch.float32, device=sq.device)
+    rm, rv, nbt = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if update_running else (None, None, None)
+    _lib.check(_lib.lib().vr_bn_finalize(_p(sq[0]), _p(sq[1]), int(n), _p(bn.weight.detach()), _p(bn.bias.detach()), float(bn.eps),
+                                         float(momentum), _p(rm), _p(rv), _p(nbt), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]),
+                                         C, _stream()), "vr_bn_finalize")
+    return out[0], out[1], out[2], out[3]
+
+
 def conv1_direct_supported(img, w, Cout):
     return img.dtype == torch.float32 and img.shape[1] == 3 and w.dtype == torch.bfloat16 and w.shape[1] == 32 and \
         Cout <= 32 and Cout % 4 == 0

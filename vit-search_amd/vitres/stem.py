@@ -33,6 +33,8 @@ def embed_params(model):
     def flipped(conv):
         """Weights of the data-gradient convolution: Wt[ci, (kh, kw, co)] = W[co, ci, 2-kh, 2-kw] (3x3, stride 1, pad 1)."""
         w = conv.weight.detach()
+        if w.dtype == torch.float32 and w.is_contiguous():
+            return K.conv_w_flip(w, dt)                                # one launch (was flip + permute + cast + copy)
         return w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], 9 * w.shape[0]).to(dt).contiguous()
     return {"w1": _perm_weight(pe.conv1.conv, dt, ld=32), "w2": _perm_weight(pe.conv2.conv, dt),
             "w3": _perm_weight(pe.conv3.conv, dt), "w2t": flipped(pe.conv2.conv), "w3t": flipped(pe.conv3.conv),
@@ -47,6 +49,10 @@ def _bn_affine(z, bn, training):
         sq = K.zero_(torch.empty((2, C), dtype=torch.float32, device=z.device))
         K.bn_stats(z, sq[0], sq[1])
         n = z.shape[0]
+        if (bn.momentum is not None and bn.track_running_stats and bn.running_mean is not None and bn.running_mean.dtype == torch.float32
+                and bn.weight.dtype == torch.float32):
+            with torch.no_grad():
+                return K.bn_finalize(sq, n, bn, bn.momentum, True)      # one launch (was a dozen elementwise ones per BatchNorm)
         mean = sq[0] / n
         var = (sq[1] / n - mean * mean).clamp_min_(0.)
         with torch.no_grad():
@@ -223,11 +229,17 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
     K.gemm(gt, p["proj"].w_c, dcolp, M=B * P, N=ldk, K=C, lda=C, ldb=ldk, ldc=ldk, b_trans=True, a_map=(P, N, T))
     da3 = K.patch_fold(dcolp, B, g, g, ps, m)                      # d(relu(bn3) + a1)
 
-    def conv_bwd(da, z, bn, col, w, conv_mod, ld, need_dx, wt=None):
-        sg = K.zero_(torch.empty((2, m), dtype=torch.float32, device=dev))
-        dz = K.bn_bwd(da, z, bn[0], bn[1], bn[2], bn[3], sg[0], sg[1], tr)
-        gv(conv_mod.bn.weight).copy_(sg[1])
-        gv(conv_mod.bn.bias).copy_(sg[0])
+    acc_in_place = True      # (every backward starts from a zeroed gradient arena: vit_sr_supernet._run_backward / _zero_grad_arena)
+
+    def conv_bwd(da, z, bn, col, w, conv_mod, ld, need_dx, wt=None, res=None):
+        gbw, gbb = gv(conv_mod.bn.weight), gv(conv_mod.bn.bias)
+        if acc_in_place:                        # the gradient arena is zero here: vr_bn_bwd's sums land where they belong
+            dz = K.bn_bwd(da, z, bn[0], bn[1], bn[2], bn[3], gbb, gbw, tr)
+        else:
+            sg = K.zero_(torch.empty((2, m), dtype=torch.float32, device=dev))
+            dz = K.bn_bwd(da, z, bn[0], bn[1], bn[2], bn[3], sg[0], sg[1], tr)
+            gbw.copy_(sg[1])
+            gbb.copy_(sg[0])
         wg = K.zero_(torch.empty((m, ld), dtype=torch.float32, device=dev))
         cin = conv_mod.conv.weight.shape[1]
         direct_w = wt is not None and K.conv3x3_wgrad_supported(dz, cin, m)
@@ -242,18 +254,22 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
                 if isinstance(c_, tuple):       # conv1 ran straight from the image: its im2col matrix is built here
                     c_ = K.im2col3x3_image(c_[1], 2, ld, dt)
                 Fn.linear_wgrad(dz, c_, wg, R, m, ld, m, ld, sched=1 if ov else 0)
-            gv(conv_mod.conv.weight).copy_(wg[:, :9 * cin].reshape(m, 3, 3, cin).permute(0, 3, 1, 2))
+            K.relayout(wg, gv(conv_mod.conv.weight), m, 9, cin, src_ld=ld)     # [m, (kh, kw), ci] -> [m, ci, kh, kw]
         Fn.on_side(wgrad, dz, wg) if ov else wgrad()
         if not need_dx:
             return None
         if wt is not None:                      # data gradient = direct convolution of dz with the flipped weights
+            if res is not None:                 # (+ the gradient arriving over the skip connection, in the same pass)
+                return K.conv3x3_res(dz, wt, res, B, Hm, Wm, m, m, dt)
             return K.conv3x3(dz, wt, B, Hm, Wm, m, m, dt)
         dcol = torch.empty((R, ld), dtype=dt, device=dev)
         K.gemm(dz, w, dcol, M=R, N=ld, K=m, lda=m, ldb=ld, ldc=ld, b_trans=True)
         return K.col2im3x3(dcol, B, Hm, Wm, m)
     da2 = conv_bwd(da3, z3, bn3, col3, p["w3"], pe.conv3, 9 * m, True, p["w3t"] if direct else None)
-    da1 = conv_bwd(da2, z2, bn2, col2, p["w2"], pe.conv2, 9 * m, True, p["w2t"] if direct else None)
-    da1 = da1 + da3                                                 # residual branch (patch_conv.py:69)
+    fuse_res = direct and da3.dtype == torch.bfloat16
+    da1 = conv_bwd(da2, z2, bn2, col2, p["w2"], pe.conv2, 9 * m, True, p["w2t"] if direct else None, res=da3 if fuse_res else None)
+    if not fuse_res:
+        da1 = da1 + da3                                             # residual branch (patch_conv.py:69)
     conv_bwd(da1, z1, bn1, col1, p["w1"], pe.conv1, 32, False)
     if ov:
         Fn.join_side()
