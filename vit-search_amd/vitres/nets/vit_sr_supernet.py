@@ -738,7 +738,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             base.update(grid=grid, cout=blk.token_transform.out_features)
         return base
 
-    def _embed_params(self):
+    def _embed_params(self, need_bwd=True):
         pe = self.patch_embed
         if self.embed_type == _TYPE_IS_EMBED:
             w = pe.proj.weight
@@ -754,7 +754,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             return {"proj": Fn.Weights(w, pe.proj.bias.detach(), wc, ld), "pos": self.pos_embed.detach(),
                     "tokens": self.tokens.detach()}
         from .. import stem
-        return stem.embed_params(self)
+        return stem.embed_params(self, need_bwd)      # (need_bwd: also the flipped weights of the data-gradient convolutions)
 
     def _run_forward(self, x, plan, with_patch, save):
         a = self._arena
@@ -791,7 +791,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         side_params = {}
         ecfg = {"dtype": self.compute_dtype, "patch": self.patch_size, "patches": self.patch_embed.num_patches,
                 "dim": self.embed_dim, "tokens": self.num_tokens}
-        ep = self._embed_params()
+        ep = self._embed_params(save)
         ekeep = plan.k(plan.layers[0]["embed"])
         if self.embed_type == _TYPE_IS_EMBED:
             h, sv = Fn.embed0_fwd(x, ep, ecfg, ekeep, save, sample_map=plan.embed_map, col=plan.embed_col)

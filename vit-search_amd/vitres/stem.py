@@ -23,7 +23,7 @@ def _perm_weight(conv, dt, ld=None):
     return K.relayout(w, out, o, w.shape[1], w.shape[2] * w.shape[3], ld)
 
 
-def embed_params(model):
+def embed_params(model, need_bwd=True):
     pe, dt = model.patch_embed, model.compute_dtype
     m = pe.mid_chans
     if m % 8:
@@ -37,7 +37,8 @@ def embed_params(model):
             return K.conv_w_flip(w, dt)                                # one launch (was flip + permute + cast + copy)
         return w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], 9 * w.shape[0]).to(dt).contiguous()
     return {"w1": _perm_weight(pe.conv1.conv, dt, ld=32), "w2": _perm_weight(pe.conv2.conv, dt),
-            "w3": _perm_weight(pe.conv3.conv, dt), "w2t": flipped(pe.conv2.conv), "w3t": flipped(pe.conv3.conv),
+            "w3": _perm_weight(pe.conv3.conv, dt),
+            "w2t": flipped(pe.conv2.conv) if need_bwd else None, "w3t": flipped(pe.conv3.conv) if need_bwd else None,
             "proj": Fn.Weights(pe.conv_proj.weight, pe.conv_proj.bias.detach(), wp, wp.shape[1]),
             "pos": model.pos_embed.detach(), "tokens": model.tokens.detach()}
 
