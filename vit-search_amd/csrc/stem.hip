@@ -148,13 +148,20 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const TZ* __restrict__ z,
     const int c8 = threadIdx.x % c8n, rl = threadIdx.x / c8n;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (rl < rows_par) {
-        for (long long r = (long long)blockIdx.x * rows_par + rl; r < R; r += (long long)gridDim.x * rows_par) {
-            float f[8];
-            V8<TZ>::load(z + r * C + c8 * 8, f);
+        const long long step = (long long)gridDim.x * rows_par;                   // (four rows per trip, as in the backward)
+        for (long long r = (long long)blockIdx.x * rows_par + rl; r < R; r += 4 * step) {
+            float f[4][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                s[e] += f[e];
-                q[e] += f[e] * f[e];
+            for (int u = 0; u < 4; ++u) V8<TZ>::load(z + (r + u * step < R ? r + u * step : r) * C + c8 * 8, f[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r + u * step < R) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s[e] += f[u][e];
+                        q[e] += f[u][e] * f[u][e];
+                    }
+                }
             }
         }
     }
@@ -216,15 +223,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         for (int e = 0; e < 8; ++e) {
             sc[e] = scale[c8 * 8 + e]; sh[e] = shift[c8 * 8 + e]; mu[e] = mean[c8 * 8 + e]; rs[e] = rstd[c8 * 8 + e];
         }
-        for (long long r = (long long)blockIdx.x * rows_par + rl; r < R; r += (long long)gridDim.x * rows_par) {
-            float f[8], g[8];
-            V8<TZ>::load(z + r * C + c8 * 8, f);
-            V8<T>::load(da + r * C + c8 * 8, g);
+        // four rows per trip, all eight loads issued before the first sum (one row per trip: 2.5 TB/s, latency-bound)
+        const long long step = (long long)gridDim.x * rows_par;
+        for (long long r = (long long)blockIdx.x * rows_par + rl; r < R; r += 4 * step) {
+            float f[4][8], g[4][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float gg = (f[e] * sc[e] + sh[e] > 0.f) ? g[e] : 0.f;
-                s[e] += gg;
-                q[e] += gg * (f[e] - mu[e]) * rs[e];
+            for (int u = 0; u < 4; ++u) {
+                const long long ru = r + u * step < R ? r + u * step : r;         // (rows past the end: row r again, not summed)
+                V8<TZ>::load(z + ru * C + c8 * 8, f[u]);
+                V8<T>::load(da + ru * C + c8 * 8, g[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r + u * step < R) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gg = (f[u][e] * sc[e] + sh[e] > 0.f) ? g[u][e] : 0.f;
+                        s[e] += gg;
+                        q[e] += gg * (f[u][e] - mu[e]) * rs[e];
+                    }
+                }
             }
         }
     }
