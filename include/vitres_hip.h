@@ -409,6 +409,10 @@ int vr_conv3x3(const void* a, const void* w, void* out, int32_t B, int32_t H, in
  */
 int vr_conv3x3_bias_relu(const void* a, const void* w, const float* bias, const void* res, void* out, int32_t B, int32_t H,
                          int32_t W, int32_t Cin, int32_t Cout, int32_t out_dtype, vr_stream_t stream);
+/* The same with the result written as the patchify operand of the projection behind it ([B*(H/patch)*(W/patch), (i, j, co)], the layout of
+ * vr_patch_unfold; H, W multiples of patch): the last ReLU of the stem and the unfold in one pass (evaluation). */
+int vr_conv3x3_bias_relu_patch(const void* a, const void* w, const float* bias, const void* res, void* out, int32_t B, int32_t H,
+                               int32_t W, int32_t Cin, int32_t Cout, int32_t patch, int32_t out_dtype, vr_stream_t stream);
 /* out = conv(a, w) + res[pixel, co] (bf16): the data gradient of conv2 plus the gradient arriving over the stem's skip connection
  * (autograd of `x = conv3(conv2(a1)) + a1`, nets/patch_conv.py:69) without a separate add pass. */
 int vr_conv3x3_res(const void* a, const void* w, const void* res, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin,

@@ -296,6 +296,11 @@ def conv3x3_bias_relu(a, w, bias, res, B, H, W, Cin, Cout, out_dtype):
     return y.to(out_dtype)
 
 
+def conv3x3_bias_relu_patch(a, w, bias, res, B, H, W, Cin, Cout, patch, out_dtype):
+    y = conv3x3_bias_relu(a, w, bias, res, B, H, W, Cin, Cout, out_dtype)
+    return patch_unfold(y, B, H // patch, W // patch, patch, Cout)
+
+
 def conv3x3_res(a, w, res, B, H, W, Cin, Cout, out_dtype):
     return (conv3x3(a, w, B, H, W, Cin, Cout, torch.float32) + res.float()).to(out_dtype)
 
@@ -453,7 +458,7 @@ def patch_fold(col, B, gh, gw, P, C):
 
 
 ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "gemm_group", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "ln_grad_reduce", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "softce_train", "colsum", "scale_mask_cast",
-       "batchsum", "conv3x3", "conv1_direct", "conv1_direct_supported", "conv3x3_bias_relu", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows", "zero_ranges", "zero_", "relayout", "conv3x3_res", "conv_w_flip", "bn_finalize"]
+       "batchsum", "conv3x3", "conv1_direct", "conv1_direct_supported", "conv3x3_bias_relu", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows", "zero_ranges", "zero_", "relayout", "conv3x3_res", "conv_w_flip", "bn_finalize", "conv3x3_bias_relu_patch"]
 
 
 def zero_ranges(buf, ranges):

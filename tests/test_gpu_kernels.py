@@ -521,6 +521,12 @@ def test_stem_glue_kernels():
     assert relerr(real, E.conv3x3_res(a, wt, res, B, H, W, 24, 24, torch.bfloat16)) < 8e-3
     plain = K.conv3x3(a.to(DEV), wt.to(DEV), B, H, W, 24, 24, torch.float32)
     assert relerr(plain, E.conv3x3(a, wt, B, H, W, 24, 24, torch.float32)) < 1e-4
+    # the evaluation stem's last convolution writing the projection's patchify operand: == the NHWC form + vr_patch_unfold, bit for bit
+    B, H, W, P = 2, 28, 42, 7
+    a, res, bias = rnd(B * H * W, 24, seed=10).bfloat16().to(DEV), rnd(B * H * W, 24, seed=11).bfloat16().to(DEV), rnd(24, seed=12).to(DEV)
+    nhwc = K.conv3x3_bias_relu(a, wt.to(DEV), bias, res, B, H, W, 24, 24, torch.bfloat16)
+    col = K.conv3x3_bias_relu_patch(a, wt.to(DEV), bias, res, B, H, W, 24, 24, P, torch.bfloat16)
+    assert torch.equal(col, K.patch_unfold(nhwc, B, H // P, W // P, P, 24))
 
 
 def test_softce():

@@ -128,8 +128,9 @@ def test_micro_bf16_eval_with_folded_batchnorm(et, monkeypatch):
     x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
     prod.eval()
     calls = []
-    real = K_.conv3x3_bias_relu
+    real, real_p = K_.conv3x3_bias_relu, K_.conv3x3_bias_relu_patch
     monkeypatch.setattr(K_, "conv3x3_bias_relu", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(K_, "conv3x3_bias_relu_patch", lambda *a, **k: (calls.append(1), real_p(*a, **k))[1])   # (conv3: patch-order output)
     with torch.no_grad():
         monkeypatch.setattr(stem, "FOLD_BN", True)
         folded = prod(x.to(DEV))

@@ -21,7 +21,7 @@ constexpr int TH = 16, TW = 16, PH = TH + 2, PW = TW + 2;
 template <int NC, typename TO>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ w,
                                                       TO* __restrict__ out, int B, int H, int W, int Cout,
-                                                      const float* __restrict__ bias, const bf16_t* __restrict__ res) {
+                                                      const float* __restrict__ bias, const bf16_t* __restrict__ res, int psz) {
     constexpr int Cin = 8 * NC, K9 = 9 * NC, STEPS = (K9 + 3) / 4;
     constexpr int PS = Cin * 2 + ((NC & 1) ? 0 : 16);                 // pixel stride in LDS, bytes
     __shared__ __attribute__((aligned(16))) char patch[PH * PW * PS];
@@ -82,7 +82,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const bf16_t* __restrict__
         }
         const int oy = y0 + r, ox = x0 + c;
         if (oy < H && ox < W) {
-            TO* dst = out + (((long long)b * H + oy) * W + ox) * Cout;
+            // psz > 0: the output goes out as the patchify operand of the projection that follows ([B*gh*gw, (i, j, c)], non-
+            // overlapping patch x patch windows: vr_patch_unfold's layout) -- a pixel's Cout channels stay contiguous either way
+            long long opix = ((long long)b * H + oy) * W + ox;
+            if (psz > 0)
+                opix = (((long long)b * (H / psz) + oy / psz) * (W / psz) + ox / psz) * (psz * psz) + (oy % psz) * psz + ox % psz;
+            TO* dst = out + opix * Cout;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int co = 16 * nt + 4 * g;
@@ -303,10 +308,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
 }
 
 template <int NC> int launch(const bf16_t* a, const bf16_t* w, void* out, int B, int H, int W, int Cout, int out_dtype, hipStream_t st,
-                             const float* bias = nullptr, const bf16_t* res = nullptr) {
+                             const float* bias = nullptr, const bf16_t* res = nullptr, int patch = 0) {
     const unsigned grid = (unsigned)(B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW));
-    if (out_dtype == VR_F32) hipLaunchKernelGGL((conv3x3_kernel<NC, float>), dim3(grid), dim3(256), 0, st, a, w, (float*)out, B, H, W, Cout, bias, res);
-    else hipLaunchKernelGGL((conv3x3_kernel<NC, bf16_t>), dim3(grid), dim3(256), 0, st, a, w, (bf16_t*)out, B, H, W, Cout, bias, res);
+    if (out_dtype == VR_F32) hipLaunchKernelGGL((conv3x3_kernel<NC, float>), dim3(grid), dim3(256), 0, st, a, w, (float*)out, B, H, W, Cout, bias, res, patch);
+    else hipLaunchKernelGGL((conv3x3_kernel<NC, bf16_t>), dim3(grid), dim3(256), 0, st, a, w, (bf16_t*)out, B, H, W, Cout, bias, res, patch);
     return 0;
 }
 
@@ -330,7 +335,7 @@ extern "C" int vr_conv3x3_wgrad(const void* a, const void* dz, float* dw, int32_
 }
 
 static int conv3x3_entry(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
-                         int32_t out_dtype, const float* bias, const void* res, vr_stream_t stream);
+                         int32_t out_dtype, const float* bias, const void* res, vr_stream_t stream, int patch = 0);
 
 extern "C" int vr_conv3x3(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                           int32_t out_dtype, vr_stream_t stream) {
@@ -349,17 +354,24 @@ extern "C" int vr_conv3x3_bias_relu(const void* a, const void* w, const float* b
     return conv3x3_entry(a, w, out, B, H, W, Cin, Cout, out_dtype, bias, res, stream);
 }
 
+extern "C" int vr_conv3x3_bias_relu_patch(const void* a, const void* w, const float* bias, const void* res, void* out, int32_t B,
+                                          int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t patch, int32_t out_dtype,
+                                          vr_stream_t stream) {
+    if (!bias || ((uintptr_t)bias & 15) || (res && ((uintptr_t)res & 7)) || patch <= 0 || H % patch || W % patch) return VR_EINVAL;
+    return conv3x3_entry(a, w, out, B, H, W, Cin, Cout, out_dtype, bias, res, stream, patch);
+}
+
 static int conv3x3_entry(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
-                         int32_t out_dtype, const float* bias, const void* res, vr_stream_t stream) {
+                         int32_t out_dtype, const float* bias, const void* res, vr_stream_t stream, int patch) {
     if (!a || !w || !out || B <= 0 || H <= 0 || W <= 0) return VR_EINVAL;
     if (out_dtype != VR_F32 && out_dtype != VR_BF16) return VR_EUNSUPPORTED;
     if (Cout <= 0 || Cout > 32 || Cout % 4) return VR_EUNSUPPORTED;
     if (((uintptr_t)a & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return VR_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     switch (Cin) {
-        case 16: launch<2>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res); break;
-        case 24: launch<3>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res); break;
-        case 32: launch<4>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res); break;
+        case 16: launch<2>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res, patch); break;
+        case 24: launch<3>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res, patch); break;
+        case 32: launch<4>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res, patch); break;
         default: return VR_EUNSUPPORTED;
     }
     VR_CHECK_LAUNCH();

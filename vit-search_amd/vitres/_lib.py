@@ -77,6 +77,7 @@ SYMBOLS = {
     "vr_conv3x3": [c_void_p, c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p],
     "vr_conv3x3_bias_relu": [c_void_p] * 5 + [c_int32] * 6 + [c_void_p],
     "vr_conv3x3_res": [c_void_p] * 4 + [c_int32] * 6 + [c_void_p],
+    "vr_conv3x3_bias_relu_patch": [c_void_p] * 5 + [c_int32] * 7 + [c_void_p],
     "vr_conv_w_flip": [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p],
     "vr_conv1_direct": [c_void_p] * 4 + [c_int32] * 6 + [c_void_p],
     "vr_token_mix": [c_void_p] * 6 + [c_int32] * 11 + [c_float] * 6 + [c_void_p],

@@ -577,6 +577,14 @@ def conv3x3_bias_relu(a, w, bias, res, B, H, W, Cin, Cout, out_dtype):
     return out
 
 
+def conv3x3_bias_relu_patch(a, w, bias, res, B, H, W, Cin, Cout, patch, out_dtype):
+    """conv3x3_bias_relu with the result laid out as patch_unfold would: [B*(H/patch)*(W/patch), patch*patch*Cout]."""
+    out = torch.empty((B * (H // patch) * (W // patch), patch * patch * Cout), dtype=out_dtype, device=a.device)
+    _lib.check(_lib.lib().vr_conv3x3_bias_relu_patch(_p(a), _p(w), _p(bias), _p(res), _p(out), B, H, W, Cin, Cout, patch,
+                                                     _dtcode(out_dtype), _stream()), "vr_conv3x3_bias_relu_patch")
+    return out
+
+
 def conv3x3_wgrad_supported(a, Cin, Cout):
     return a.dtype == torch.bfloat16 and Cin == Cout and Cin in (16, 24, 32)
 

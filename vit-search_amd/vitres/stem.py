@@ -135,9 +135,12 @@ def _embed_conv_eval(model, x, p, cfg, keep):
         a1 = torch.empty((R, m), dtype=dt, device=x.device)
         K.gemm(col1, w1, a1, M=R, N=m, K=32, lda=32, ldb=32, ldc=m, bias=t1, act=3)
     a2 = K.conv3x3_bias_relu(a1, w2, t2, None, B, Hm, Wm, m, m, dt)
-    a3 = K.conv3x3_bias_relu(a2, w3, t3, a1, B, Hm, Wm, m, m, dt)
     ps = model.patch_size // 2
-    colp = K.patch_unfold(a3, B, g, g, ps, m)
+    if Hm % ps == 0 and Wm % ps == 0:          # the last ReLU writes the projection's patchify operand itself
+        colp = K.conv3x3_bias_relu_patch(a2, w3, t3, a1, B, Hm, Wm, m, m, ps, dt)
+    else:
+        a3 = K.conv3x3_bias_relu(a2, w3, t3, a1, B, Hm, Wm, m, m, dt)
+        colp = K.patch_unfold(a3, B, g, g, ps, m)
     ldk = ps * ps * m
     out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
     K.gemm(colp, p["proj"].w_c, out, M=B * P, N=C, K=ldk, lda=ldk, ldb=ldk, ldc=C, bias=p["proj"].b,
