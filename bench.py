@@ -253,7 +253,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=30,
+                    help="untimed steps; the first ~25 steps of a process run 2-3 %% slower (clocks, first-touch): 7.81 ms timed after 5, 7.60-7.65 after 30 or 100")
     ap.add_argument("--workload", default="sr_tiny_supernet", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=None)
