@@ -173,6 +173,18 @@ def run_evo_eval(args, rank, world, device):
             out = model(x, plan=plans[ci])
         out = out[0] if isinstance(out, tuple) else out
         return (out.argmax(dim=1) == y).sum()
+    step_probe = [] if os.environ.get("VITRES_DBG_STEPS") else None   # dev aid: GPU time of every step from the first warm-up step on
+    if step_probe is not None:
+        _step = step
+
+        def step(i):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = _step(i)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            step_probe.append((e0, e1))
+            return r
     for i in range(args.warmup):
         step(i)
     if world > 1:
@@ -370,6 +382,18 @@ def main():
     if graphed is not None and world > 1:
         graphed.exposed = []                                     # (event after the last backward graph, event after the exchange)
 
+    step_probe = [] if os.environ.get("VITRES_DBG_STEPS") else None   # dev aid: GPU time of every step from the first warm-up step on
+    if step_probe is not None:
+        _step = step
+
+        def step(i):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = _step(i)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            step_probe.append((e0, e1))
+            return r
     for i in range(args.warmup):
         step(i)
     if world > 1:
@@ -400,6 +424,9 @@ def main():
     elapsed = float(tmax.item())
     lossv = torch.stack(losses).tolist()
     assert all(v == v and abs(v) != float("inf") for v in lossv), "non-finite loss"
+    if step_probe:
+        print("step probe (ms, from the first warm-up step): " + " ".join("%.2f" % a.elapsed_time(b) for a, b in step_probe),
+              file=sys.stderr)
     if gap_probe:
         inside = sum(a.elapsed_time(b) for a, b in gap_probe) / len(gap_probe)
         between = sum(gap_probe[i][1].elapsed_time(gap_probe[i + 1][0]) for i in range(len(gap_probe) - 1)) / max(len(gap_probe) - 1, 1)

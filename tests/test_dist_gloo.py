@@ -235,3 +235,55 @@ def test_two_rank_search_shards_candidates_and_agrees_with_one_rank(tmp_path):
     r0, r1 = (torch.load(os.path.join(str(tmp_path), "best_w2_r%d.pt" % r)) for r in range(2))
     assert one == r0 == r1
     assert open(os.path.join(str(tmp_path), "w1", "summary.txt")).read() == open(os.path.join(str(tmp_path), "w2", "summary.txt")).read()
+
+
+def _rng_worker(rank, world, port, out_dir):
+    for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "vit-search_amd"), HERE,
+              os.path.join(HERE, "golden"), os.path.join(os.path.dirname(HERE), "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import recipe
+    import vitres
+    from vitres import checkpoint
+
+    def make():
+        return vitres.create_model("flexible_vit_sr_patch14_224_patch_output_supernet", img_size=recipe.MICRO_IMG,
+                                   num_classes=recipe.MICRO_CLASSES, network_def=recipe.MICRO_DEFS[0], drop_path_rate=0.1,
+                                   num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30)
+    torch.manual_seed(7)                               # the SAME global seed on both ranks: the generator adds the rank itself
+    m = make()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    gen = m.drop_path_generator()
+    torch.rand(3 + rank, generator=gen)                # every rank somewhere else in its own stream
+    mine = m.drop_path_rng_state().clone()
+    states = checkpoint.collect_rng_states(m)          # collective
+    full = checkpoint.checkpoint_dict(m, opt, None, 3, rng_states=states)
+    solo = checkpoint.checkpoint_dict(m, opt, None, 3)                  # what rank 0 alone would have written
+    box = [solo if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    solo0 = box[0]
+    res = {}
+    # (a) per-rank list: every rank continues its own stream exactly
+    m2 = make()
+    checkpoint.resume(full, m2, torch.optim.AdamW(m2.parameters(), lr=1e-3))
+    res["own"] = bool(torch.equal(m2.drop_path_rng_state(), mine))
+    # (b) rank 0's state alone: rank 0 continues exactly, rank 1 gets a derived stream -- not rank 0's
+    m3 = make()
+    checkpoint.resume(solo0, m3, torch.optim.AdamW(m3.parameters(), lr=1e-3))
+    st3 = m3.drop_path_rng_state()
+    res["solo_same_as_rank0"] = bool(torch.equal(st3, solo0["vitres_rng"]["drop_path"]))
+    res["draw"] = torch.rand(4, generator=m3.drop_path_generator()).tolist()
+    torch.save(res, os.path.join(out_dir, "rng%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_resume_keeps_per_rank_drop_path_streams(tmp_path):
+    """a checkpoint's DropPath generator state must not make every rank draw the same noise after a resume
+    (reference: per-rank noise from seed + rank, main.py:261-267)."""
+    mp.spawn(_rng_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "rng%d.pt" % r)) for r in (0, 1))
+    assert r0["own"] and r1["own"]
+    assert r0["solo_same_as_rank0"] and not r1["solo_same_as_rank0"]
+    assert r0["draw"] != r1["draw"]

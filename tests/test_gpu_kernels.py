@@ -1067,3 +1067,41 @@ def test_gemm_saved_gelu_derivative_pair(M, C, F):
     du = torch.empty(M, F, dtype=dt, device=DEV)
     K.gemm(cu(gt), cu(w2t), du, dact_u=d, act=2, **{k: cu(v) for k, v in kw2.items()})
     assert relerr(du, du_ref) < 2e-2, relerr(du, du_ref)
+
+
+@pytest.mark.parametrize("B,N,C,F,masked,mapped", [(4, 257, 320, 960, True, True), (3, 65, 64, 192, True, False), (16, 257, 256, 768, False, True),
+                                                   (2, 300, 320, 1280, True, False), (5, 17, 128, 96, True, False), (9, 129, 192, 384, False, True)])
+def test_fused_mlp_forward(B, N, C, F, masked, mapped):
+    """vr_mlp_fwd (one kernel, hidden tensor never written) against the two-GEMM form it replaces (vr_gemm act = 1, then
+    vr_gemm with scale / keep / residual): the same bf16 rounding of the hidden activations, fp32 summation order differs.
+    mapped: the patch rows of every sample through a row map (the class-token row is left untouched)."""
+    gen = torch.Generator().manual_seed(B * 1000 + C)
+    T = 1 if mapped else 0
+    P = N - T
+    y = _bf(rnd(B, N, C, seed=1)).to(DEV)
+    w1 = _bf(rnd(F, C, seed=2, scale=C ** -0.5)).to(DEV)
+    w2 = _bf(rnd(C, F, seed=3, scale=F ** -0.5)).to(DEV)
+    b1, b2 = rnd(F, seed=4).to(DEV), rnd(C, seed=5).to(DEV)
+    x = rnd(B, N, C, seed=6).to(DEV)
+    kin = khid = kout = scale = None
+    if masked:
+        kin = torch.randint(C // 2, C + 1, (B,), generator=gen).int().to(DEV)
+        khid = torch.randint(1, F + 1, (B,), generator=gen).int().to(DEV)
+        kout = kin.clone()
+        scale = (torch.rand(B, generator=gen) + 0.5).to(DEV)
+        y = y * (torch.arange(C, device=DEV)[None, None, :] < kin[:, None, None])       # the LayerNorm output is zero beyond its keep
+    # reference: the two-GEMM path on the same rows
+    ref = x.clone()
+    h = torch.empty(B * P, F, dtype=torch.bfloat16, device=DEV)
+    amap = (P, N, T) if mapped else None
+    K.gemm(y, w1, h, M=B * P, N=F, K=C, lda=C, ldb=C, ldc=F, bias=b1, act=1, keep_n=khid, rows_in=P, keep_k=kin, a_map=amap)
+    K.gemm(h, w2, ref, M=B * P, N=C, K=F, lda=F, ldb=F, ldc=C, bias=b2, scale=scale, keep_n=kout, resid=x, rows_in=P, keep_k=khid,
+           c_map=amap)
+    out = x.clone() if mapped else torch.empty_like(x)
+    assert K.mlp_fwd_supported(y, C, F)
+    K.mlp_fwd(y, w1, b1, w2, b2, x, out, M=B * P, C=C, F=F, ldw1=C, ldw2=F, rows_in=P, scale=scale, keep_in=kin, keep_hid=khid,
+              keep_out=kout, row_map=amap)
+    torch.cuda.synchronize()
+    assert relerr(out, ref) < 1e-4
+    if mapped:
+        assert torch.equal(out[:, 0], x[:, 0])

@@ -4,6 +4,7 @@
 // count: statistics and outputs use only channels c < keep (channels beyond are exactly zero upstream).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 #include "../../include/vitres_hip.h"
 
 namespace {
@@ -231,6 +232,123 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TI* __restrict__ dy, 
     }
 }
 
+// Lean form (round 4): the LayerNorm backward of the 512 - 1280 wide stages runs beside the weight-gradient group of the block it
+// closes, whose workgroups hold half of every SIMD's registers for their whole life -- at 120 - 164 VGPRs the kernel above then
+// fits 1 - 2 waves per SIMD instead of 3 - 4 and takes 46 - 64 us instead of 11 - 16 (profiles/r03_a_step_timeline.txt: every
+// co-running launch ends with the weight-gradient group it started beside).  Here nothing row-invariant lives in registers: the
+// dgamma / dbeta column sums are accumulated with LDS atomics (ds_add_f32, 2 C per row: ~10 % of a row's load latency), gamma
+// is re-read from LDS per row, dy stays packed (bf16), z and dz are recomputed after the two row reductions instead of kept
+// across them: <= 64 VGPRs at C = 1024, so 4+ waves per SIMD fit beside two 128-register GEMM waves.
+template <typename TI, int MAXV>
+__global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const TI* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ w, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const int* __restrict__ keep,
+                                                          const float* __restrict__ dx_in, float* __restrict__ dx_out,
+                                                          float* __restrict__ dw, float* __restrict__ db, TI* __restrict__ gt_out,
+                                                          const float* __restrict__ gt_scale, const int* __restrict__ gt_keep,
+                                                          int M, int C, int rps, int BWD_ROWS, int copies) {
+    __shared__ __attribute__((aligned(16))) float sw[MAXV * 256], sdw[MAXV * 256], sdb[MAXV * 256];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // rows are wave-uniform: scalar row bases, 32-bit lane offsets
+    for (int c = threadIdx.x; c < MAXV * 256; c += 256) {
+        sw[c] = c < C ? w[c] : 0.f;
+        sdw[c] = 0.f;
+        sdb[c] = 0.f;
+    }
+    __syncthreads();
+    const int mbeg = blockIdx.x * BWD_ROWS;
+    for (int rr = wave; rr < BWD_ROWS; rr += 4) {
+        const int m = mbeg + rr;
+        if (m >= M) break;
+        const int kc = keep ? keep[m / rps] : C;
+        const float mu = mean[m], rs = rstd[m];
+        TI const* dyr = dy + (long long)m * C;
+        const float* xr = x + (long long)m * C;
+        float4 xv[MAXV], rv[MAXV];
+        typename std::conditional<sizeof(TI) == 4, float4, uint2>::type gq[MAXV];        // dy as loaded (bf16 stays packed)
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            const int cc = c < C ? c : 0;                                                // clamped: loads are never branched around
+            if constexpr (sizeof(TI) == 4) gq[j] = *reinterpret_cast<const float4*>(dyr + cc);
+            else gq[j] = *reinterpret_cast<const uint2*>(dyr + cc);
+            xv[j] = *reinterpret_cast<const float4*>(xr + cc);
+            rv[j] = dx_in ? *reinterpret_cast<const float4*>(dx_in + (long long)m * C + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        auto dyv = [&](int j) -> float4 {
+            if constexpr (sizeof(TI) == 4) return gq[j];
+            else return make_float4(__uint_as_float(gq[j].x << 16), __uint_as_float(gq[j].x & 0xffff0000u),
+                                    __uint_as_float(gq[j].y << 16), __uint_as_float(gq[j].y & 0xffff0000u));
+        };
+        const float inv_n = kc > 0 ? 1.0f / (float)kc : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < C) {
+                float4 a = dyv(j);
+                const float4 xx = xv[j];
+                if (!(c + 0 < kc)) a.x = 0.f;
+                if (!(c + 1 < kc)) a.y = 0.f;
+                if (!(c + 2 < kc)) a.z = 0.f;
+                if (!(c + 3 < kc)) a.w = 0.f;
+                const float4 z = make_float4((xx.x - mu) * rs, (xx.y - mu) * rs, (xx.z - mu) * rs, (xx.w - mu) * rs);
+                const float4 wv = *reinterpret_cast<const float4*>(&sw[c]);
+                const float4 g = make_float4(a.x * wv.x, a.y * wv.y, a.z * wv.z, a.w * wv.w);
+                s1 += g.x + g.y + g.z + g.w;
+                s2 += g.x * z.x + g.y * z.y + g.z * z.z + g.w * z.w;
+                // (masked channels: a == 0 -> both products vanish whatever z is)
+                atomicAdd(&sdw[c + 0], a.x * z.x); atomicAdd(&sdw[c + 1], a.y * z.y);
+                atomicAdd(&sdw[c + 2], a.z * z.z); atomicAdd(&sdw[c + 3], a.w * z.w);
+                atomicAdd(&sdb[c + 0], a.x); atomicAdd(&sdb[c + 1], a.y); atomicAdd(&sdb[c + 2], a.z); atomicAdd(&sdb[c + 3], a.w);
+            }
+        }
+        s1 = wave_sum(s1) * inv_n;
+        s2 = wave_sum(s2) * inv_n;
+        // the second pass RECOMPUTES dz and z from the loaded values: without this fence the compiler keeps the first pass's
+        // products alive across the reductions (common subexpressions) and the kernel is back at 170 registers
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            asm volatile("" : "+v"(xv[j].x), "+v"(xv[j].y), "+v"(xv[j].z), "+v"(xv[j].w));
+            if constexpr (sizeof(TI) == 4) asm volatile("" : "+v"(gq[j].x), "+v"(gq[j].y), "+v"(gq[j].z), "+v"(gq[j].w));
+            else asm volatile("" : "+v"(gq[j].x), "+v"(gq[j].y));
+        }
+        const int k2 = (gt_out && gt_keep) ? gt_keep[m / rps] : C;
+        const float sc2 = (gt_out && gt_scale) ? gt_scale[m / rps] : 1.0f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int c = (lane + 64 * j) * 4;
+            if (c < C) {
+                const float4 a = dyv(j);
+                const float4 xx = xv[j];
+                const float4 wv = *reinterpret_cast<const float4*>(&sw[c]);
+                const float4 r = rv[j];
+                float4 o;
+                o.x = (c + 0 < kc) ? (a.x * wv.x - (s1 + (xx.x - mu) * rs * s2)) * rs + r.x : 0.f;
+                o.y = (c + 1 < kc) ? (a.y * wv.y - (s1 + (xx.y - mu) * rs * s2)) * rs + r.y : 0.f;
+                o.z = (c + 2 < kc) ? (a.z * wv.z - (s1 + (xx.z - mu) * rs * s2)) * rs + r.z : 0.f;
+                o.w = (c + 3 < kc) ? (a.w * wv.w - (s1 + (xx.w - mu) * rs * s2)) * rs + r.w : 0.f;
+                *reinterpret_cast<float4*>(dx_out + (long long)m * C + c) = o;
+                if (gt_out) {
+                    float4 t;
+                    t.x = (c + 0 < k2) ? o.x * sc2 : 0.f;
+                    t.y = (c + 1 < k2) ? o.y * sc2 : 0.f;
+                    t.z = (c + 2 < k2) ? o.z * sc2 : 0.f;
+                    t.w = (c + 3 < k2) ? o.w * sc2 : 0.f;
+                    if constexpr (sizeof(TI) == 4) *reinterpret_cast<float4*>(gt_out + (long long)m * C + c) = t;
+                    else *reinterpret_cast<uint2*>(gt_out + (long long)m * C + c) = make_uint2(pack_bf2(t.x, t.y), pack_bf2(t.z, t.w));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const long long row = (long long)(blockIdx.x % (unsigned)copies) * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(dw + row + c, sdw[c]);
+        atomicAdd(db + row + c, sdb[c]);
+    }
+}
+
 struct GradSlots {
     static constexpr int MAX = 32;
     vr_ln_grad_slot s[MAX];
@@ -317,6 +435,29 @@ extern "C" int vr_ln_bwd(const void* dy, const float* x, const float* w, const f
                                        : (M >= 32768 ? 64 : (M >= 8192 ? 32 : (M >= 2048 ? 8 : 4)));
     dim3 grid((M + BWD_ROWS - 1) / BWD_ROWS);
     const int nv = (C + 255) / 256;
+    // lean form: widths of the later stages (>= 384), where the kernel runs beside a weight-gradient group (VITRES_LN_BWD_LEAN: 0 never,
+    // 1 C >= 384, 2 always)
+    static const int knob_lean = std::getenv("VITRES_LN_BWD_LEAN") ? std::atoi(std::getenv("VITRES_LN_BWD_LEAN")) : 1;
+    if ((knob_lean == 1 && C >= 384) || knob_lean >= 2) {
+#define VR_LN_BWDL(NV)                                                                                                 \
+    if (dy_dtype == VR_F32)                                                                                            \
+        hipLaunchKernelGGL((ln_bwd_lean_kernel<float, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, x, w, \
+                           mean, rstd, keep, dx_in, dx_out, dw, db, (float*)gt_out, gt_scale, gt_keep, M, C, rows_per_sample, BWD_ROWS, copies); \
+    else                                                                                                               \
+        hipLaunchKernelGGL((ln_bwd_lean_kernel<bf16_t, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, x, \
+                           w, mean, rstd, keep, dx_in, dx_out, dw, db, (bf16_t*)gt_out, gt_scale, gt_keep, M, C, rows_per_sample, BWD_ROWS, copies);
+        switch (nv) {
+            case 1: VR_LN_BWDL(1) break;
+            case 2: VR_LN_BWDL(2) break;
+            case 3: VR_LN_BWDL(3) break;
+            case 4: VR_LN_BWDL(4) break;
+            case 5: VR_LN_BWDL(5) break;
+            default: VR_LN_BWDL(8) break;
+        }
+#undef VR_LN_BWDL
+        VR_CHECK_LAUNCH();
+        return VR_OK;
+    }
 #define VR_LN_BWD(NV)                                                                                                  \
     if (dy_dtype == VR_F32)                                                                                            \
         hipLaunchKernelGGL((ln_bwd_kernel<float, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, x, w, \

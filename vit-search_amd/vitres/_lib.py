@@ -40,6 +40,13 @@ class LnEpilogue(ctypes.Structure):
                 ("gt_out", c_void_p), ("gt_scale", c_void_p), ("gt_keep", c_void_p), ("grad_copies", c_int32)]
 
 
+class MlpArgs(ctypes.Structure):
+    _fields_ = [("y", c_void_p), ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p), ("resid", c_void_p),
+                ("out", c_void_p), ("scale", c_void_p), ("keep_in", c_void_p), ("keep_hid", c_void_p), ("keep_out", c_void_p),
+                ("M", c_int32), ("C", c_int32), ("F", c_int32), ("ldy", c_int32), ("ldw1", c_int32), ("ldw2", c_int32),
+                ("ldo", c_int32), ("rows_in", c_int32), ("map", RowMap)]
+
+
 MAX_ZERO_RANGES = 24
 
 
@@ -58,6 +65,8 @@ SYMBOLS = {
     "vr_gemm": [ctypes.POINTER(GemmArgs), c_void_p],
     "vr_gemm_group": [ctypes.POINTER(GemmArgs), ctypes.c_int32, c_void_p],
     "vr_gemm_ln": [ctypes.POINTER(GemmArgs), ctypes.POINTER(LnEpilogue), c_void_p],
+    "vr_mlp_fwd": [ctypes.POINTER(MlpArgs), c_void_p],
+    "vr_mlp_fwd_supported": [c_int32, c_int32],
     "vr_gemm_ln_supported": [c_int32],
     "vr_gemm_ws_bytes": [],
     "vr_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],

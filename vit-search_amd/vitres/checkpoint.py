@@ -27,8 +27,38 @@ def _cpu(tree):
     return tree
 
 
-def checkpoint_dict(model, optimizer, lr_scheduler, epoch, args=None, model_ema=None):
-    """model_ema: a state_dict (e.g. FlatAdamW.ema_state_dict()) or a module holding the averaged weights."""
+def _rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def collect_rng_states(model):
+    """COLLECTIVE (every rank calls it, e.g. at the end of an epoch before rank 0 writes the checkpoint): the DropPath generator
+    state of every rank, indexed by rank -- pass the result to checkpoint_dict / save_checkpoint(rng_states=...) so that a
+    resumed multi-rank run continues every rank's own noise stream.  One rank: a one-element list, no communication."""
+    import torch.distributed as dist
+    state = model.drop_path_rng_state() if hasattr(model, 'drop_path_rng_state') else None
+    rank, world = _rank_world()
+    if world == 1:
+        return [state]
+    out = [None] * world
+    dist.all_gather_object(out, state)
+    return out
+
+
+def _derived_seed(state, rank):
+    """A seed that is a function of a saved generator state and a rank: ranks whose own state is not in the checkpoint continue
+    with streams that differ from one another and from the saving rank's, reproducibly."""
+    import hashlib
+    h = hashlib.sha256(bytes(state.numpy().tobytes()) + int(rank).to_bytes(8, 'little')).digest()
+    return int.from_bytes(h[:8], 'little') % (2 ** 63)
+
+
+def checkpoint_dict(model, optimizer, lr_scheduler, epoch, args=None, model_ema=None, rng_states=None):
+    """model_ema: a state_dict (e.g. FlatAdamW.ema_state_dict()) or a module holding the averaged weights.
+    rng_states: collect_rng_states(model) (per-rank DropPath generator states); None: this rank's state alone is saved."""
     out = {'model': _cpu(model.state_dict()), 'optimizer': _cpu(_optimizer_state(optimizer)),
            'lr_scheduler': lr_scheduler.state_dict() if lr_scheduler is not None else {}, 'epoch': epoch, 'args': args}
     if model_ema is not None:
@@ -36,13 +66,22 @@ def checkpoint_dict(model, optimizer, lr_scheduler, epoch, args=None, model_ema=
     if hasattr(model, 'drop_path_rng_state'):
         # one key beyond the reference's layout (its loaders index by name and ignore it): the DropPath draws of this stack come
         # from a private CPU generator, so a resumed run continues the same noise stream
-        out['vitres_rng'] = {'drop_path': model.drop_path_rng_state()}
+        # (the reference draws DropPath noise per rank from seed + rank, main.py:261-267: states are kept PER RANK)
+        rank, world = _rank_world()
+        out['vitres_rng'] = {'drop_path': model.drop_path_rng_state(), 'rank': rank, 'world': world}
+        if rng_states is not None:
+            if len(rng_states) != world:
+                raise ValueError('rng_states has %d entries for %d ranks' % (len(rng_states), world))
+            out['vitres_rng']['drop_path_by_rank'] = list(rng_states)
+    if getattr(optimizer, '_graph_pending', None) is not None and optimizer._graph_pending():
+        raise RuntimeError('a deferred in-graph optimizer update is pending: call GraphedTrainStep.finish_update() before '
+                           'checkpointing (the weights are one step behind)')
     return out
 
 
-def save_checkpoint(output_dir, model, optimizer, lr_scheduler, epoch, args=None, model_ema=None):
+def save_checkpoint(output_dir, model, optimizer, lr_scheduler, epoch, args=None, model_ema=None, rng_states=None):
     """Writes <output_dir>/checkpoint.pth.tar and, for epoch % 10 == 9, epoch@<epoch>_checkpoint.pth.tar (main.py:504-515)."""
-    d = checkpoint_dict(model, optimizer, lr_scheduler, epoch, args=args, model_ema=model_ema)
+    d = checkpoint_dict(model, optimizer, lr_scheduler, epoch, args=args, model_ema=model_ema, rng_states=rng_states)
     os.makedirs(output_dir, exist_ok=True)
     path = os.path.join(output_dir, CHECKPOINT_NAME)
     torch.save(d, path)
@@ -66,7 +105,19 @@ def resume(path_or_dict, model, optimizer=None, lr_scheduler=None, eval_mode=Fal
             lr_scheduler.load_state_dict(ck['lr_scheduler'])
         start = ck['epoch'] + 1
         if 'vitres_rng' in ck and hasattr(model, 'set_drop_path_rng_state'):
-            model.set_drop_path_rng_state(ck['vitres_rng']['drop_path'])
+            # every rank continues ITS OWN DropPath stream: the per-rank list when the checkpoint has one for this world size; else
+            # the saved state on the rank that saved it and, on the others, a stream derived from (saved state, rank) -- never the
+            # same state on two ranks (they would draw identical noise for the rest of training).  Without the key: the fresh
+            # (seed + rank) stream drop_path_generator() makes.
+            bundle = ck['vitres_rng']
+            rank, world = _rank_world()
+            by_rank = bundle.get('drop_path_by_rank')
+            if by_rank is not None and len(by_rank) == world and by_rank[rank] is not None:
+                model.set_drop_path_rng_state(by_rank[rank])
+            elif world == 1 or rank == bundle.get('rank', 0):
+                model.set_drop_path_rng_state(bundle['drop_path'])
+            else:
+                model.drop_path_generator(seed=None).manual_seed(_derived_seed(bundle['drop_path'], rank))
         if 'model_ema' in ck:
             if load_ema is not None:
                 load_ema(ck['model_ema'])

@@ -52,6 +52,17 @@ class Meter:
         return self.total / max(self.count, 1)
 
 
+class _WireWork:
+    """Handle of an all-reduce that ran on the wire buffer: the work + the arena range GradSync.finish() copies back."""
+    __slots__ = ("work", "lo", "hi")
+
+    def __init__(self, work, lo, hi):
+        self.work, self.lo, self.hi = work, lo, hi
+
+    def wait(self):
+        return self.work.wait()
+
+
 class GradSync:
     """Data-parallel gradient exchange for a vitres model: parameters are broadcast once from rank 0
     (reference DDP constructor, main.py:367) and, every step, the flat gradient arena is all-reduced
@@ -69,7 +80,7 @@ class GradSync:
         self.world = world_size()
         self.wire_dtype = wire_dtype
         self._wire = None
-        self._ranges = []
+        self._warned = False
 
     def broadcast_parameters(self):
         if self.world == 1:
@@ -116,8 +127,9 @@ class GradSync:
             return dist.all_reduce(g[lo:hi], async_op=True)
         wire = self._wire_buffer(g)
         self._to_wire(g[lo:hi], wire[lo:hi])
-        self._ranges.append((lo, hi))
-        return dist.all_reduce(wire[lo:hi], async_op=True)
+        # the range travels WITH its handle: finish() copies back exactly the ranges whose handles it was given (a handle dropped
+        # by an exception, or waited on by the caller, leaves nothing behind that a later finish() could copy over valid gradients)
+        return _WireWork(dist.all_reduce(wire[lo:hi], async_op=True), lo, hi)
 
     def _wire_buffer(self, g):
         if self._wire is None or self._wire.numel() != g.numel() or self._wire.device != g.device:
@@ -141,12 +153,14 @@ class GradSync:
             if w is not None:
                 w.wait()
         g = self.model._arena["gcur"]
-        if self._ranges:                       # bf16 wire: summed ranges back into the fp32 arena (averaging folded in)
-            for lo, hi in self._ranges:
-                g[lo:hi].copy_(self._wire[lo:hi])
+        wired = [w for w in works if isinstance(w, _WireWork)]
+        if wired:                              # bf16 wire: summed ranges back into the fp32 arena (averaging folded in)
+            if len(wired) != sum(1 for w in works if w is not None):
+                raise RuntimeError("GradSync.finish: fp32 and wire-dtype handles mixed in one exchange")
+            for w in wired:
+                g[w.lo:w.hi].copy_(self._wire[w.lo:w.hi])
                 if average:
-                    g[lo:hi].mul_(1.0 / self.world)
-            self._ranges = []
+                    g[w.lo:w.hi].mul_(1.0 / self.world)
             return
         if average:
             g.mul_(1.0 / self.world)
@@ -164,6 +178,11 @@ class GradSync:
             if average:
                 g.mul_(1.0 / self.world)
             return
+        if self.wire_dtype != torch.float32 and not self._warned:
+            import warnings
+            warnings.warn("GradSync: gradients are not views of the flat arena (autograd cloned them): the per-tensor fallback "
+                          "exchanges fp32, wire_dtype=%s is ignored" % self.wire_dtype)
+            self._warned = True
         for p in self.model.parameters():                         # autograd cloned the views: per-tensor fallback
             if p.grad is not None:
                 dist.all_reduce(p.grad)
@@ -294,6 +313,9 @@ class GraphedTrainStep:
         self.pt = patch_targets.clone() if patch_targets is not None else None
         B = samples.shape[0]
         rng = torch.random.get_rng_state()
+        # the DropPath draws come from the model's private generator: the warm-up steps and the capture's plan must not advance the
+        # stream a checkpoint restored (the first replay then continues exactly where the saved run stopped)
+        dp_rng = model.drop_path_rng_state() if hasattr(model, "drop_path_rng_state") else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                              # eager warm-up (arena, LDS attributes, allocator)
@@ -383,6 +405,8 @@ class GraphedTrainStep:
             self.ranges.append((0, end))
         self.loss = self.loss.detach()
         torch.random.set_rng_state(rng)
+        if dp_rng is not None:
+            model.set_drop_path_rng_state(dp_rng)
 
     def _gather(self, samples, plan):
         """Patch gather of the caller's batch into the graph's static patchify operand (internal, arch-grouped sample order)."""

@@ -135,15 +135,50 @@ def on_side(fn, *keepalive, defer=True):
     _pending.extend(keepalive)
 
 
+# Auxiliary streams (round 4): named branches besides the weight-gradient side stream -- "tail": the patch-embedding weight
+# gradient and the small reductions that close a backward run beside the first block's weight-gradient group instead of behind
+# one another on the main queue.  (Measured and dropped: AdamW over finished arena ranges on an "opt" stream beside the rest of
+# the backward -- 7.52 -> 7.98 ms however the update was throttled)
+_aux_streams = {}
+_aux_used = set()
+_AUX_ROLE = {}           # stream-K workspace role of each auxiliary stream (kernels.ws_role)
+
+
+def aux_stream(dev, name):
+    st = _aux_streams.get((dev, name))
+    if st is None:
+        st = _aux_streams[(dev, name)] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def on_aux(name, fn, *keepalive, after_side=False):
+    """Run fn() on the auxiliary stream `name` after everything queued so far on the current stream (and, after_side, on the
+    side streams: weight gradients already launched there).  Joined by join_side(); keepalive as on_side."""
+    flush_side()
+    main = torch.cuda.current_stream()
+    st = aux_stream(main.device, name)
+    st.wait_stream(main)
+    if after_side:
+        for side in _side_streams.get(main.device, ()):
+            st.wait_stream(side)
+    with torch.cuda.stream(st), K.ws_role(_AUX_ROLE.setdefault(name, 8 + len(_AUX_ROLE))):
+        fn()
+    _aux_used.add((main.device, name))
+    _pending.extend(keepalive)
+
+
 def join_side():
     """Current stream waits for ALL side-stream work issued so far (and releases every tensor kept for it)."""
     if _block_wgrads:
         flush_wgrads()
     flush_side()
-    if _pending or _side_streams:
+    if _pending or _side_streams or _aux_used:         # (CPU runs never get here: nothing was ever put on a side stream)
         main = torch.cuda.current_stream()
         for side in _side_streams.get(main.device, ()):
             main.wait_stream(side)
+        for key in [k for k in _aux_used if k[0] == main.device]:
+            main.wait_stream(_aux_streams[key])
+            _aux_used.discard(key)
     _pending.clear()
     _lagged.clear()
 
@@ -208,13 +243,14 @@ def wgrad_store_ok(tokens, dtype, is_cuda):
 
 
 def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None, db=None, keep_rows=None,
-                 keep_cols=None, row_period=0, tokens_per_sample=0, sched=0, collect=None, store=False):
+                 keep_cols=None, row_period=0, tokens_per_sample=0, sched=0, collect=None, store=False, split=0):
     """dw[N_out, K_in] += dy[M, N_out]^T @ x[M, K_in]  (fp32 atomics, split over tokens; db[N_out] += colsum(dy)).
     keep_rows / keep_cols: per-sample kept prefix of dy's / x's channels -> fully masked tiles are skipped.
     collect: a list -> the call is appended to it instead of being launched (K.gemm_group launches the list as one kernel).
-    store: dw and db are OVERWRITTEN (one workgroup per tile over all tokens, plain stores) -- see WGRAD_STORE."""
+    store: dw and db are OVERWRITTEN (one workgroup per tile over all tokens, plain stores) -- see WGRAD_STORE.
+    split: explicit token split (workgroups per output tile); 0 = the kernel's rule (32 slices of 64 tokens per workgroup)."""
     kw = dict(M=N_out, N=K_in, K=M, lda=lddy, ldb=ldx, ldc=ldw or K_in, a_trans=True, b_trans=True,
-              atomic=(2 if store else True), split_k=(1 if store else 0), a_map=a_map, b_map=b_map, bias_grad=db,
+              atomic=(2 if store else True), split_k=(1 if store else split), a_map=a_map, b_map=b_map, bias_grad=db,
               keep_k=keep_rows, keep_n=keep_cols, k_period=row_period, rows_in=tokens_per_sample, sched=sched)
     if collect is not None:
         collect.append((dy, x, dw, kw))
@@ -344,6 +380,11 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     return out
 
 
+# VITRES_FUSED_MLP: 1 = forward-only MLPs of first-stage width (C <= 320) run as one vr_mlp_fwd launch unless the fc2 + LayerNorm
+# kernel applies (width <= 256); 2 = always where supported; 0 = never
+FUSED_MLP = int(_os.environ.get('VITRES_FUSED_MLP', '1'))
+
+
 def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save, pre=None, next_ln=None):
     B, N, C = x.shape
     M = B * N
@@ -357,6 +398,24 @@ def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save, pre=N
         u = torch.empty((B, N, F), dtype=dt, device=x.device)
         K.gemm(y, p["fc1"].w_c, u, out2=h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b,
                act=(2 if dt == torch.bfloat16 else 1), keep_n=mlp_keep, rows_in=N, keep_k=embed_keep)
+    elif FUSED_MLP and K.mlp_fwd_supported(y, C, F) and (FUSED_MLP >= 2 or not _ln_fusable(y, C, next_ln)):
+        # forward-only, first-stage widths: ONE kernel for fc1 -> GELU -> mask -> fc2 -> scale / mask / residual (vr_mlp_fwd); the
+        # hidden tensor is never written.  The kernel walks 128-row tiles with one workgroup per CU: a sample of 256 patch tokens
+        # + 1 class token would leave it a 129th-row tile per sample pair, so the class-token rows (one per sample) go through the
+        # two-GEMM form with row maps and the fused kernel sees B x 256 rows
+        x2 = torch.empty_like(x)
+        T = 1 if (N % 128 == 1 and B >= 8) else 0
+        P = N - T
+        K.mlp_fwd(y, p["fc1"].w_c, p["fc1"].b, p["fc2"].w_c, p["fc2"].b, x, x2, M=B * P, C=C, F=F, ldw1=p["fc1"].ld,
+                  ldw2=p["fc2"].ld, rows_in=P, scale=scale, keep_in=embed_keep, keep_hid=mlp_keep, keep_out=out_keep,
+                  row_map=(P, N, T) if T else None)
+        if T:
+            ht = torch.empty((B * T, F), dtype=dt, device=x.device)
+            K.gemm(y, p["fc1"].w_c, ht, M=B * T, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b, act=1,
+                   keep_n=mlp_keep, rows_in=T, keep_k=embed_keep, a_map=(T, N, 0))
+            K.gemm(ht, p["fc2"].w_c, x2, M=B * T, N=C, K=F, lda=F, ldb=p["fc2"].ld, ldc=C, bias=p["fc2"].b, scale=scale,
+                   keep_n=out_keep, resid=x, rows_in=T, keep_k=mlp_keep, c_map=(T, N, 0))
+        return x2, None, None
     else:                                       # forward-only: the pre-activation is not kept, fc1 writes gelu(u) alone
         u = None
         K.gemm(y, p["fc1"].w_c, h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b, act=1,
@@ -503,6 +562,16 @@ def embed0_fwd(img, p, cfg, keep, save, sample_map=None, col=None):
     return x, ((col,) if save else None)
 
 
+# Token split of the patch-embedding weight gradient (2 x 5 tiles of 128^2 over 32 768 tokens): the kernel's coarse rule gives it
+# 160 workgroups walking 32 slices each (103 us, and it was the first kernel of a serial step tail); EMBED_WGRAD_SLICES slices
+# per workgroup -> 4x the workgroups, each paying |tile| x 4 B of atomics (42 MB in all at 8).
+EMBED_WGRAD_SLICES = int(_os.environ.get('VITRES_EMBED_WGRAD_SLICES', '8'))
+# VITRES_TAIL_AUX=1: the end of a backward -- patch-embedding weight gradient, positional-embedding sums, LayerNorm partial-row
+# folds -- runs on the auxiliary stream "tail" beside the first block's weight-gradient group (they feed nothing but the
+# optimizer); 0: in line on the main stream (round 3: 0.15 ms of kernels one after another with nothing beside them).
+TAIL_AUX = _os.environ.get('VITRES_TAIL_AUX', '1') != '0'
+
+
 def embed0_bwd(g, saved, p, grads, cfg, keep, gt=None):
     flush_wgrads()
     (col,) = saved
@@ -513,7 +582,10 @@ def embed0_bwd(g, saved, p, grads, cfg, keep, gt=None):
     ldk = p["proj"].ld
     if gt is None:
         gt = K.scale_mask_cast(g, None, keep, N, dt)
-    linear_wgrad(gt, col, grads["proj.w"], B * P, C, ldk, C, ldk, a_map=(P, N, T), db=grads["proj.b"])
+    split = 0
+    if EMBED_WGRAD_SLICES > 0 and g.is_cuda and dt == torch.bfloat16:
+        split = max(1, -(-(B * P) // (64 * EMBED_WGRAD_SLICES)))
+    linear_wgrad(gt, col, grads["proj.w"], B * P, C, ldk, C, ldk, a_map=(P, N, T), db=grads["proj.b"], split=split)
     K.batchsum(g, grads["pos"])                                             # d pos_embed [N, C] (rows 0..T-1 also = d tokens)
 
 

@@ -116,6 +116,37 @@ def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=Fals
     return args
 
 
+def mlp_fwd_supported(y, C, F):
+    """vr_mlp_fwd covers this MLP (bf16 activations, first-stage widths)."""
+    return y.dtype == torch.bfloat16 and y.is_cuda and bool(_lib.lib().vr_mlp_fwd_supported(C, F))
+
+
+def mlp_fwd(y, w1, b1, w2, b2, resid, out, *, M, C, F, ldw1, ldw2, rows_in=0, scale=None, keep_in=None, keep_hid=None,
+            keep_out=None, row_map=None):
+    """out = resid + scale * mask_out(mask_hid(gelu(y W1^T + b1)) W2^T + b2)  (vr_mlp_fwd: forward-only fused MLP; the hidden
+    tensor is never written).  y bf16 [rows, C]; resid / out fp32 [rows, C]; row_map: the M rows of the problem among them."""
+    a = _lib.MlpArgs()
+    a.y, a.w1, a.b1, a.w2, a.b2 = _p(y), _p(w1), _p(b1), _p(w2), _p(b2)
+    a.resid, a.out, a.scale = _p(resid), _p(out), _p(scale)
+    a.keep_in, a.keep_hid, a.keep_out = _p(keep_in), _p(keep_hid), _p(keep_out)
+    a.M, a.C, a.F, a.ldy, a.ldw1, a.ldw2, a.ldo, a.rows_in = M, C, F, C, ldw1, ldw2, C, rows_in
+    a.map = _rm(row_map)
+    assert w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and resid.dtype == torch.float32 and out.dtype == torch.float32
+    ev = None
+    if PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    _lib.check(_lib.lib().vr_mlp_fwd(ctypes.byref(a), _stream()), "vr_mlp_fwd")
+    if ev is not None:
+        ev[1].record()
+        fl = _kept_flops(M, F, C, rows_in, keep_in, keep_hid) + _kept_flops(M, C, F, rows_in, keep_hid, keep_out)
+        by = M * C * (2 + 4 + 4) + 2 * F * C * 2
+        PROFILE.append(("mlp_fwd", fl, 4.0 * M * C * F, by, ev[0], ev[1]))
+        if PROFILE_DESC is not None:
+            PROFILE_DESC.append("mlp_fwd M%d C%d F%d" % (M, C, F))
+    return out
+
+
 def gemm_ln_supported(a, N, ldc):
     """vr_gemm_ln covers this Linear (bf16 operands, whole rows in one tile)."""
     return a.dtype == torch.bfloat16 and N == ldc and bool(_lib.lib().vr_gemm_ln_supported(N))

@@ -758,6 +758,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
 
     def _run_forward(self, x, plan, with_patch, save):
         a = self._arena
+        if save and Fn.reset_ln_grads() and a.get("ln_parts_flat") is not None:      # (a backward died: see _run_backward)
+            a["ln_parts_flat"].zero_()
         # engine.GraphedTrainStep(optimizer=..., deferred): the PREVIOUS replay's AdamW update opens this forward -- the head of the
         # arena (tokens, positional embedding, patch embedding, first stage) here, the rest (most parameters) on the side stream
         # beside the first stage, which does not read them; joined with side_prep in front of the first spatial reduction
@@ -895,11 +897,13 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         if fresh and not a.pop("gzeroed", False):      # (the forward may have zeroed it on the side stream already)
             self._zero_grad_arena(a["gcur"], plan.batch)
         a["gzeroed"] = False
+        # leftovers of a backward that raised: weight-gradient calls collected for a block and never launched (join_side would
+        # launch them first -- into the arena just zeroed) and LayerNorm partial rows never folded
+        stale = Fn.reset_ln_grads()
         Fn.join_side()                     # transposed weight shadows (issued beside the forward)
-        del Fn._block_wgrads[:]            # (weight gradients a dead backward collected and never launched)
         if Fn.LN_COPIES > 1:
             self._ln_parts()
-            if Fn.reset_ln_grads():        # a backward died between a LayerNorm kernel and flush_ln_grads()
+            if stale:
                 a["ln_parts_flat"].zero_()
         st = {"rtape": list(reversed(tape)), "plan": plan, "dcls": dcls, "dpat": dpat, "i": 0, "g": None, "gt": None,
               "ready": ready}
@@ -977,6 +981,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 return (None, ekeep0)
             return None
         gt = st["gt"]
+        tail_aux = False
         parts = a.get("ln_parts") if Fn.LN_COPIES > 1 else None
 
         def with_parts(grads, *pairs):
@@ -1038,14 +1043,27 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                     wt = gv(w).view(w.shape[0], k) if ld == k else K.zero_(torch.empty((w.shape[0], ld), dtype=torch.float32,
                                                                                         device=dev))
                     grads = {"proj.w": wt, "proj.b": gv(self.patch_embed.proj.bias), "pos": gv(self.pos_embed)}
-                    Fn.embed0_bwd(g, sv, ep, grads, ecfg, ekeep, gt=gt)
-                    if ld != k:
-                        K.relayout(wt, gv(w), w.shape[0], 1, k, src_ld=ld)       # drop the pad columns
+
+                    def tail(g=g, sv=sv, ep=ep, grads=grads, ecfg=ecfg, ekeep=ekeep, gt=gt, wt=wt, w=w, k=k, ld=ld):
+                        Fn.embed0_bwd(g, sv, ep, grads, ecfg, ekeep, gt=gt)
+                        if ld != k:
+                            K.relayout(wt, gv(w), w.shape[0], 1, k, src_ld=ld)   # drop the pad columns
+                        gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:self.num_tokens, :])
+                    if Fn.TAIL_AUX and Fn.OVERLAP and g.is_cuda:
+                        # nothing downstream but the optimizer: beside the first block's weight-gradient group, not after it
+                        Fn.flush_wgrads()
+                        Fn.on_aux("tail", tail, g, gt, wt, *sv)
+                        tail_aux = True
+                    else:
+                        tail()
                 else:
                     from .. import stem
                     stem.embed_conv_bwd(self, g, sv, ep, ecfg, ekeep, gv, gt=gt)
-                gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:self.num_tokens, :])
-        Fn.flush_ln_grads()                # LayerNorm weight / bias gradients of this part: partial rows -> arena
+                    gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:self.num_tokens, :])
+        if tail_aux:
+            Fn.on_aux("tail", Fn.flush_ln_grads)
+        else:
+            Fn.flush_ln_grads()            # LayerNorm weight / bias gradients of this part: partial rows -> arena
         if stop >= len(rtape) or getattr(self, "_bwd_join_parts", True):
             Fn.join_side()                 # weight-gradient GEMMs trail on the side stream (functional.on_side); an intermediate
                                            # stop joins too unless the next part follows in the same capture (_bwd_join_parts)
