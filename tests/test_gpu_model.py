@@ -871,7 +871,7 @@ def test_bf16_step_trains_like_the_fp32_step():
         losses = []
         for it in range(50):
             torch.manual_seed(4000 + it)                            # the same architectures in both runs
-            losses.append(g(x, t, pt, epoch=31, train_iter=it, arch_sample="multi"))
+            losses.append(g(x, t, pt, epoch=31, train_iter=it, arch_sample="multi").clone())   # (the graph's static loss tensor)
             opt.step()
         traj[dtype] = torch.stack(losses).cpu().double()
     f, b = traj[torch.float32], traj[torch.bfloat16]

@@ -258,13 +258,20 @@ struct TnGroup {
     int first[MAXG + 1];
     int count;
 };
+// Resident form (round 4): the launch is capped at `cap` workgroups per CU and a workgroup walks work items blockIdx.x,
+// blockIdx.x + gridDim.x, ... (gridDim.x a multiple of 8: an item stays on the XCD the tile order gave it).  An uncapped group is
+// 680 - 1280 workgroups that live 25 - 50 us each: as the short-lived workgroups of the main chain's kernel retire, the group's
+// pending ones take their slots -- up to all four per CU -- and the kernel the group runs beside is left a third of the chip
+// (stage-1 data gradients 28.6 -> 51.8 us, LayerNorm backward 16.5 -> 31.7 us: profiles/r04_wgrad_contention.txt).
 template <bool MAPPED, int TW>
 __global__ __launch_bounds__(NTHR, 4) void tn_group_kernel(const TnGroup g) {
-    int k = 0;
+    for (int bid = (int)blockIdx.x; bid < g.first[MAXG]; bid += (int)gridDim.x) {
+        int k = 0;
 #pragma unroll
-    for (int i = 1; i < MAXG; ++i)
-        if (i < g.count && (int)blockIdx.x >= g.first[i]) k = i;
-    tn_body<true, MAPPED, TW, 1>(g.a[k], (int)blockIdx.x - g.first[k]);
+        for (int i = 1; i < MAXG; ++i)
+            if (i < g.count && bid >= g.first[i]) k = i;
+        tn_body<true, MAPPED, TW, 1>(g.a[k], bid - g.first[k]);
+    }
 }
 
 template <int TW, int STAGES> void launch_tw(const vr_gemm_args& a, hipStream_t stream, long long total) {
@@ -325,8 +332,15 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
         next += (int)((tiles * g.a[i].split_k + 7) / 8 * 8);
     }
     for (int i = count; i <= MAXG; ++i) g.first[i] = next;
-    if (TWv == 64) hipLaunchKernelGGL((tn_group_kernel<false, 64>), dim3((unsigned)next), dim3(NTHR), 0, stream, g);
-    else hipLaunchKernelGGL((tn_group_kernel<false, 128>), dim3((unsigned)next), dim3(NTHR), 0, stream, g);
+    // VITRES_TN_GROUP_CAP = workgroups per CU the group may hold at once, in tenths (15 = 1.5 per CU; 0 = one workgroup per item)
+    static const int knob_cap = std::getenv("VITRES_TN_GROUP_CAP") ? std::atoi(std::getenv("VITRES_TN_GROUP_CAP")) : 0;
+    int grid = next;
+    if (knob_cap > 0) {
+        const int lim = (knob_cap * n_cu / 10 + 7) / 8 * 8;
+        grid = next < lim ? next : lim;
+    }
+    if (TWv == 64) hipLaunchKernelGGL((tn_group_kernel<false, 64>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
+    else hipLaunchKernelGGL((tn_group_kernel<false, 128>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
     return true;
 }
 

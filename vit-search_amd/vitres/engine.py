@@ -269,6 +269,9 @@ def train_step(model, criterion, optimizer, samples, targets, patch_targets=None
     return loss.detach()
 
 
+RUN_AHEAD = int(os.environ.get("VITRES_RUN_AHEAD", "2"))
+
+
 class GraphedTrainStep:
     """forward + loss + backward of one iteration captured ONCE into a hipGraph and replayed every step
     (the step issues ~600 kernel launches; replay removes their host cost).  What changes between iterations goes
@@ -284,6 +287,7 @@ class GraphedTrainStep:
         of the backward -- most of the time -- is still running."""
         self.model, self.criterion, self.pot = model, criterion, patch_output_type
         self.graph_b, self.split, self.more_graphs, self.ranges = None, None, [], []
+        self._inflight = []
         # optimizer (a vitres.optim.FlatAdamW, single rank): the update becomes part of the graph -- the arena tail (last stage +
         # heads, most parameters) is updated on the side stream as soon as its gradients are final, beside the rest of the
         # backward; the remainder after it.  Call optimizer.prepare_step() before every replay instead of optimizer.step().
@@ -464,12 +468,23 @@ class GraphedTrainStep:
         if self.defer is not None:
             self.optimizer.prepare_step(noop=not self._pending)   # the update this replay opens with: the previous replay's gradients
             self._pending = True
+        # bounded run-ahead: the host needs ~3 ms for a 7.5 ms step, so left alone it queues replay after replay until the runtime's
+        # queue limit stops it (~25 steps in); on the way the runtime grows its per-launch resources a few times, and each growth
+        # stalls the device for ~1 ms (six 8.3 - 8.9 ms steps among the first 26 of a run, none after).  RUN_AHEAD replays in
+        # flight keep the device fed with the host two steps ahead from the third step on (VITRES_RUN_AHEAD, 0 = unbounded).
+        if RUN_AHEAD > 0:
+            if len(self._inflight) >= RUN_AHEAD:
+                self._inflight.pop(0).synchronize()
         self.graph.replay()
         self.model._stem_fold = None                               # (stem.drop_fold: the replay moved BatchNorm's running statistics)
         for k, g in enumerate(self.more_graphs):
             if self._sync is not None:                            # the arena range of the part just replayed is final: exchange it now
                 self._works.append(self._sync.all_reduce_range(*self.ranges[k]))
             g.replay()
+        if RUN_AHEAD > 0:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._inflight.append(ev)
         return self.loss
 
     def finish_update(self):
@@ -480,6 +495,7 @@ class GraphedTrainStep:
             self._pending = False
 
     _sync, _works = None, ()
+    _inflight = None
 
     def step_with_sync(self, grad_sync, samples, targets, patch_targets=None, average=True, **kw):
         """Replay + data-parallel gradient exchange: with split_for_sync the all-reduce of the last stage's gradients
