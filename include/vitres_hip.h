@@ -122,6 +122,8 @@ typedef struct vr_gemm_args {
 
 /* bytes of vr_gemm_args.ws that enable tile sharing on the current device */
 int vr_gemm_ws_bytes(void);
+/* 1 when the library was built with `make EXPERIMENTAL=1` (the kernel forms of csrc/experimental/, include/vitres_hip_experimental.h) */
+int vr_experimental(void);
 
 int vr_gemm(const vr_gemm_args* args, vr_stream_t stream);
 
@@ -167,37 +169,6 @@ typedef struct vr_ln_epilogue {
 } vr_ln_epilogue;
 int vr_gemm_ln(const vr_gemm_args* args, const vr_ln_epilogue* ln, vr_stream_t stream);
 int vr_gemm_ln_supported(int32_t N);
-
-/*
- * Fused forward MLP of a transformer block for the forward-only paths (engine.py:194-261 evaluate, evolutionary-search candidate
- * scoring): Mlp.forward (nets/supernet_blocks.py:37-52) + the block's DropPath / channel masks / residual add (:247-253) in ONE
- * kernel -- the hidden tensor [rows, F] is never written:
- *     out[r, :] = resid[r, :] + scale[s] * mask_{keep_out[s]}( mask_{keep_hid[s]}( gelu(y[r, :] W1^T + b1) ) W2^T + b2 )
- * y: bf16 [rows, ldy] (the block's norm2 output; columns >= keep_in[s] are zero), W1: bf16 [F, ldw1], W2: bf16 [C, ldw2],
- * resid / out: fp32 [rows, ldo].  Row m of the problem (m < M, sample s = m / rows_in) is row map(m) of y, resid and out.
- * Same results as vr_gemm(act = 1, single store) followed by vr_gemm(resid, scale, keep_n) up to the bf16 rounding of the hidden
- * activations (identical) and fp32 summation order.  C <= 320 (the first stage of every shipped search space), C % 8 == 0,
- * F <= 2048: vr_mlp_fwd_supported(C, F).
- */
-typedef struct vr_mlp_args {
-    const void* y;
-    const void* w1;
-    const float* b1;            /* [F] or NULL */
-    const void* w2;
-    const float* b2;            /* [C] or NULL */
-    const float* resid;
-    float* out;
-    const float* scale;         /* [batch] or NULL */
-    const int32_t* keep_in;     /* [batch] or NULL: kept prefix of y's columns (work skipping) */
-    const int32_t* keep_hid;    /* [batch] or NULL: kept prefix of the hidden units */
-    const int32_t* keep_out;    /* [batch] or NULL: kept prefix of the output columns */
-    int32_t M, C, F;
-    int32_t ldy, ldw1, ldw2, ldo;
-    int32_t rows_in;            /* rows per sample of the m index (0: one sample) */
-    vr_rowmap map;
-} vr_mlp_args;
-int vr_mlp_fwd(const vr_mlp_args* args, vr_stream_t stream);
-int vr_mlp_fwd_supported(int32_t C, int32_t F);
 
 /* fp32 -> bf16 (round to nearest even), n elements.  Replaces autocast's per-op weight casts (engine.py:112). */
 int vr_cast_f32_bf16(const float* src, void* dst, int64_t n, vr_stream_t stream);

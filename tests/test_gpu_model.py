@@ -880,3 +880,36 @@ def test_bf16_step_trains_like_the_fp32_step():
     print(msg)
     assert f[-1] < 0.6 * f[0] and b[-1] < 0.6 * b[0], msg
     assert rel_.max() < 0.06 and rel_.mean() < 0.02, msg
+
+
+OPT_IN_FORMS = ["VITRES_NT_SPLIT=2", "VITRES_WGRAD_STORE=1", "VITRES_TN_GROUP_CAP=0", "VITRES_LN_XCD=0 VITRES_ATTN_XCD=0",
+                "VITRES_TAIL_AUX=0 VITRES_EMBED_WGRAD_SLICES=0", "VITRES_OVERLAP=0"]
+
+
+def test_opt_in_forms_at_model_level(tmp_path):
+    """Every kernel form / schedule that stays in the product library behind an environment knob runs one whole bf16 training step
+    of the micro supernet (tests/knob_worker.py, one process per setting: the knobs are read at import time) and must reproduce the
+    default path: masks bit for bit, logits / loss / every parameter gradient up to fp32 summation order of bf16 products."""
+    import subprocess
+    import sys
+
+    def run(env_s, tag):
+        env = dict(os.environ)
+        for kv in env_s.split():
+            k, v = kv.split("=")
+            env[k] = v
+        out = str(tmp_path / ("%s.pt" % tag))
+        subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "knob_worker.py"), out],
+                       env=env, check=True, timeout=600)
+        return torch.load(out)
+
+    ref = run("", "default")
+    for i, env_s in enumerate(OPT_IN_FORMS):
+        got = run(env_s, "k%d" % i)
+        assert len(got["keeps"]) == len(ref["keeps"])
+        for a, b in zip(got["keeps"], ref["keeps"]):
+            assert (a is None and b is None) or torch.equal(torch.as_tensor(a), torch.as_tensor(b)), env_s
+        assert rel(got["cls"], ref["cls"]) < 5e-3 and rel(got["pat"], ref["pat"]) < 5e-3, env_s
+        assert abs(got["loss"] - ref["loss"]) < 2e-3 * abs(ref["loss"]), env_s
+        worst = max(rel(g, ref["grads"][n]) for n, g in got["grads"].items())
+        assert worst < 2e-2, (env_s, worst)

@@ -176,12 +176,13 @@ template <int D, int NP> struct Img {
 template <int D, int NKP, int NW, int PB, int OCC, bool FULL>
 __global__ __launch_bounds__(NW * 64, OCC) void fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                            float* __restrict__ lse, const int* __restrict__ keep_hd, int B,
-                                                           int N, int H, float scale) {
+                                                           int N, int H, float scale, int ATTN_XCD) {
     static_assert(NKP % PB == 0, "key-tile pairs must split into whole blocks");
     constexpr int NP = 32 * NKP;
     typedef Img<D, NP> I;
     extern __shared__ __attribute__((aligned(16))) char sm[];
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int bidx = xcd_block((int)blockIdx.x, (int)gridDim.x, ATTN_XCD);   // (sample-major: XCD x gets samples [x B / 8, ..))
+    const int b = bidx / H, h = bidx % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int HD = H * D, RS = 3 * HD;
     const bf16_t* base = qkv + (long long)b * N * RS + h * D;
@@ -304,11 +305,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void bwd_dq_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                               float* __restrict__ delta, bf16_t* __restrict__ dqkv,
                                                               const int* __restrict__ keep_hd, int B, int N, int H,
-                                                              float scale) {
+                                                              float scale, int ATTN_XCD) {
     constexpr int NP = 32 * NKP;
     typedef Img<D, NP> I;
     extern __shared__ __attribute__((aligned(16))) char sm[];
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int bidx = xcd_block((int)blockIdx.x, (int)gridDim.x, ATTN_XCD);   // (sample-major: XCD x gets samples [x B / 8, ..))
+    const int b = bidx / H, h = bidx % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int HD = H * D, RS = 3 * HD;
     const bf16_t* base = qkv + (long long)b * N * RS + h * D;
@@ -412,11 +414,12 @@ template <int D, int NKP, int NW, int OCC, bool FULL>
 __global__ __launch_bounds__(NW * 64, OCC) void bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, const int* __restrict__ keep_hd,
-                                                               int B, int N, int H, float scale) {
+                                                               int B, int N, int H, float scale, int ATTN_XCD) {
     constexpr int NP = 32 * NKP;
     typedef Img<D, NP> I;
     extern __shared__ __attribute__((aligned(16))) char sm[];
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int bidx = xcd_block((int)blockIdx.x, (int)gridDim.x, ATTN_XCD);   // (sample-major: XCD x gets samples [x B / 8, ..))
+    const int b = bidx / H, h = bidx % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int HD = H * D, RS = 3 * HD;
     const bf16_t* base = qkv + (long long)b * N * RS + h * D;
@@ -566,12 +569,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void bwd_short_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                  float* __restrict__ delta, bf16_t* __restrict__ dqkv,
                                                                  const int* __restrict__ keep_hd, int B, int N, int H,
-                                                                 float scale) {
+                                                                 float scale, int ATTN_XCD) {
     constexpr int NP = 32 * NKP, NT = NW * 64;
     constexpr int IT = (NP * AC<D>::NCH + NT - 1) / NT;
     typedef Img<D, NP> I;
     extern __shared__ __attribute__((aligned(16))) char sm[];
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int bidx = xcd_block((int)blockIdx.x, (int)gridDim.x, ATTN_XCD);   // (sample-major: XCD x gets samples [x B / 8, ..))
+    const int b = bidx / H, h = bidx % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int HD = H * D, RS = 3 * HD;
     const bf16_t* base = qkv + (long long)b * N * RS + h * D;
@@ -1069,6 +1073,11 @@ template <int NKP> struct Plan {
     static constexpr int PB = NKP >= 9 ? 3 : NKP;
 };
 
+// VITRES_ATTN_XCD (default 1): sample-major block order per XCD (common.h xcd_block)
+static int attn_xcd() {
+    static const int k = std::getenv("VITRES_ATTN_XCD") ? std::atoi(std::getenv("VITRES_ATTN_XCD")) : 1;
+    return k;
+}
 template <int D, int NKP>
 static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, const int* keep, int B, int N, int H, float scale,
                       hipStream_t st) {
@@ -1079,12 +1088,12 @@ static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, const int* keep,
         int rc = set_lds(fwd_kernel<D, NKP, NW, PB, OCC, true>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((fwd_kernel<D, NKP, NW, PB, OCC, true>), dim3(B * H), dim3(NW * 64), lds, st, qkv, o, lse, keep, B, N, H,
-                           scale);
+                           scale, attn_xcd());
     } else {
         int rc = set_lds(fwd_kernel<D, NKP, NW, PB, OCC, false>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((fwd_kernel<D, NKP, NW, PB, OCC, false>), dim3(B * H), dim3(NW * 64), lds, st, qkv, o, lse, keep, B, N, H,
-                           scale);
+                           scale, attn_xcd());
     }
     return 0;
 }
@@ -1106,12 +1115,12 @@ static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, con
                 int rc = set_lds(bwd_short_kernel<D, NKP, NW, SOCC, true>, l3);
                 if (rc) return rc;
                 hipLaunchKernelGGL((bwd_short_kernel<D, NKP, NW, SOCC, true>), dim3(B * H), dim3(NW * 64), l3, st, qkv, o, d_o, lse, delta,
-                                   dqkv, keep, B, N, H, scale);
+                                   dqkv, keep, B, N, H, scale, attn_xcd());
             } else {
                 int rc = set_lds(bwd_short_kernel<D, NKP, NW, SOCC, false>, l3);
                 if (rc) return rc;
                 hipLaunchKernelGGL((bwd_short_kernel<D, NKP, NW, SOCC, false>), dim3(B * H), dim3(NW * 64), l3, st, qkv, o, d_o, lse, delta,
-                                   dqkv, keep, B, N, H, scale);
+                                   dqkv, keep, B, N, H, scale, attn_xcd());
             }
             return 0;
         }
@@ -1122,18 +1131,18 @@ static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, con
         rc = set_lds(bwd_dkv_kernel<D, NKP, NW, OCC, true>, l2);
         if (rc) return rc;
         hipLaunchKernelGGL((bwd_dq_kernel<D, NKP, NW, OCC, true>), dim3(B * H), dim3(NW * 64), l1, st, qkv, o, d_o, lse, delta, dqkv,
-                           keep, B, N, H, scale);
+                           keep, B, N, H, scale, attn_xcd());
         hipLaunchKernelGGL((bwd_dkv_kernel<D, NKP, NW, OCC, true>), dim3(B * H), dim3(NW * 64), l2, st, qkv, d_o, lse, delta, dqkv,
-                           keep, B, N, H, scale);
+                           keep, B, N, H, scale, attn_xcd());
     } else {
         int rc = set_lds(bwd_dq_kernel<D, NKP, NW, OCC, false>, l1);
         if (rc) return rc;
         rc = set_lds(bwd_dkv_kernel<D, NKP, NW, OCC, false>, l2);
         if (rc) return rc;
         hipLaunchKernelGGL((bwd_dq_kernel<D, NKP, NW, OCC, false>), dim3(B * H), dim3(NW * 64), l1, st, qkv, o, d_o, lse, delta, dqkv,
-                           keep, B, N, H, scale);
+                           keep, B, N, H, scale, attn_xcd());
         hipLaunchKernelGGL((bwd_dkv_kernel<D, NKP, NW, OCC, false>), dim3(B * H), dim3(NW * 64), l2, st, qkv, d_o, lse, delta, dqkv,
-                           keep, B, N, H, scale);
+                           keep, B, N, H, scale, attn_xcd());
     }
     return 0;
 }

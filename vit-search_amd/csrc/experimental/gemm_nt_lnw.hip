@@ -16,9 +16,9 @@
 // every wave walks whole rows; the side operands of the next four rows are requested before the current four are worked on.
 #include <cstdlib>
 
-#include "common.h"
-#include "../../include/vitres_hip.h"
-#include "gemm_shared.h"
+#include "../common.h"
+#include "../../../include/vitres_hip.h"
+#include "../gemm_shared.h"
 
 namespace vr_gemm_ntlnw {
 using namespace vr_gemm_shared;

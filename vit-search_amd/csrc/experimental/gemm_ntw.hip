@@ -24,7 +24,7 @@
 // gemm_nt.hip (gemm_nt_parts.h).
 #include <cstdlib>
 
-#include "gemm_nt_parts.h"
+#include "../gemm_nt_parts.h"
 
 namespace vr_gemm_nt {
 

@@ -24,9 +24,9 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "common.h"
-#include "gemm_shared.h"
-#include "../../include/vitres_hip.h"
+#include "../common.h"
+#include "../gemm_shared.h"
+#include "../../../include/vitres_hip_experimental.h"
 
 namespace vr_mlp {
 using namespace vr_gemm_shared;

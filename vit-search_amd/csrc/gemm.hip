@@ -26,7 +26,6 @@
 
 bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);   // gemm_nt.hip
 bool vr_gemm_tn_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);   // gemm_tn.hip
-size_t vr_gemm_ntw_ws_bytes(int n_cu);                                          // gemm_ntw.hip
 bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t stream, int n_cu);
 
 namespace {
@@ -797,7 +796,11 @@ static int gemm_validate(vr_gemm_args& a) {
     return VR_OK;
 }
 
-extern "C" int vr_gemm_ws_bytes(void) { return (int)vr_gemm_ntw_ws_bytes(cu_count()); }
+// tickets (16 KB) + two 256 x 128 fp32 slabs per CU: what the split-K form of gemm_nt.hip and the experimental stream-K kernel share
+extern "C" int vr_gemm_ws_bytes(void) { return (int)(4096 * 4 + (size_t)cu_count() * 2 * (256 * 128) * sizeof(float)); }
+// 1 when the library was built with `make EXPERIMENTAL=1` (csrc/experimental/: kernel forms that lost inside the training step)
+__attribute__((weak)) bool vr_gemm_ntw_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu, int mode);
+extern "C" int vr_experimental(void) { return vr_gemm_ntw_launch ? 1 : 0; }
 
 extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
     if (!args) return VR_EINVAL;

@@ -423,7 +423,8 @@ template <int MI, int NJ> int launch(const vr_gemm_args& a, const vr_ln_epilogue
 
 }  // namespace vr_gemm_ntln
 
-bool vr_gemm_lnw_launch(const vr_gemm_args& a, const vr_ln_epilogue& f, hipStream_t stream);   // gemm_nt_lnw.hip
+// experimental/gemm_nt_lnw.hip (EXPERIMENTAL builds only: weak reference)
+__attribute__((weak)) bool vr_gemm_lnw_launch(const vr_gemm_args& a, const vr_ln_epilogue& f, hipStream_t stream);
 
 extern "C" int vr_gemm_ln_supported(int32_t N) { return N > 0 && N % 8 == 0 && N <= 512; }
 
@@ -442,7 +443,7 @@ extern "C" int vr_gemm_ln(const vr_gemm_args* g, const vr_ln_epilogue* ln, vr_st
     } else {
         return VR_EINVAL;
     }
-    if (vr_gemm_lnw_launch(a, *ln, (hipStream_t)stream)) {               // long and narrow: one workgroup per CU, three-stage ring
+    if (vr_gemm_lnw_launch && vr_gemm_lnw_launch(a, *ln, (hipStream_t)stream)) {               // long and narrow: one workgroup per CU, three-stage ring
         VR_CHECK_LAUNCH();
         return VR_OK;
     }

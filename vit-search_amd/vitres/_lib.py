@@ -65,10 +65,9 @@ SYMBOLS = {
     "vr_gemm": [ctypes.POINTER(GemmArgs), c_void_p],
     "vr_gemm_group": [ctypes.POINTER(GemmArgs), ctypes.c_int32, c_void_p],
     "vr_gemm_ln": [ctypes.POINTER(GemmArgs), ctypes.POINTER(LnEpilogue), c_void_p],
-    "vr_mlp_fwd": [ctypes.POINTER(MlpArgs), c_void_p],
-    "vr_mlp_fwd_supported": [c_int32, c_int32],
     "vr_gemm_ln_supported": [c_int32],
     "vr_gemm_ws_bytes": [],
+    "vr_experimental": [],
     "vr_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "vr_adamw_flat": [c_void_p] * 6 + [c_float, c_void_p, c_void_p, c_int32, c_int64, c_void_p],
     "vr_adamw_flat_dev": [c_void_p] * 6 + [c_float, c_void_p, c_void_p, c_int32, c_int64, c_void_p],
@@ -112,6 +111,12 @@ SYMBOLS = {
     "vr_patch_unfold": [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p],
 }
 
+# include/vitres_hip_experimental.h: present only in `make EXPERIMENTAL=1` builds (VITRES_LIB=.../libvitres_hip_exp.so)
+EXPERIMENTAL_SYMBOLS = {
+    "vr_mlp_fwd": [ctypes.POINTER(MlpArgs), c_void_p],
+    "vr_mlp_fwd_supported": [c_int32, c_int32],
+}
+
 _lib = None
 
 
@@ -131,8 +136,18 @@ def lib():
                 raise RuntimeError("libvitres_hip.so does not export %s" % name) from e
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
+        if L.vr_experimental():
+            for name, argtypes in EXPERIMENTAL_SYMBOLS.items():
+                fn = getattr(L, name)
+                fn.argtypes = argtypes
+                fn.restype = ctypes.c_int
         _lib = L
     return _lib
+
+
+def experimental():
+    """True when the loaded library carries the kernel forms of csrc/experimental/ (an EXPERIMENTAL=1 build)."""
+    return bool(lib().vr_experimental())
 
 
 _ERR = {-1: "VR_EINVAL (bad argument)", -2: "VR_EALIGN (pointer / leading-dimension alignment)",

@@ -308,6 +308,9 @@ class GraphedTrainStep:
             has_sr = any(type(b).__name__ == "SpatialReductionPatchEmbedding" for b in getattr(model, "blocks", []))
             if has_sr and isinstance(cuts3, list) and cuts3 and cuts3[-1][1] % 8 == 0:
                 self.defer = cuts3[-1][1]                          # arena offset of the first spatial reduction
+                # checkpoint_dict / evaluate / FlatAdamW.state_dict refuse to run while an update is pending (weights one step behind)
+                self.optimizer._graph_pending = lambda: self._pending
+                model._graph_pending = self.optimizer._graph_pending
         # soft-target CE is the training loss of every shipped recipe (main.py:390-398): the whole step then runs without
         # autograd and without torch glue between the heads and the backward (model.loss_and_grad / vr_softce_train)
         from .losses import SoftTargetCrossEntropy
@@ -594,6 +597,9 @@ def evaluate(data_loader, model, device, print_freq=100, logger=None):
     criterion = torch.nn.CrossEntropyLoss()
     print_out = logger.info if logger else print
     meters = defaultdict(Meter)
+    if getattr(model, "_graph_pending", None) is not None and model._graph_pending():
+        raise RuntimeError("a deferred in-graph optimizer update is pending (weights one step behind): call "
+                           "GraphedTrainStep.finish_update() before evaluating")
     model.eval()
     for images, target in data_loader:
         images = images.to(device, non_blocking=True)

@@ -382,7 +382,7 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
 
 # VITRES_FUSED_MLP: 1 = forward-only MLPs of first-stage width (C <= 320) run as one vr_mlp_fwd launch unless the fc2 + LayerNorm
 # kernel applies (width <= 256); 2 = always where supported; 0 = never
-FUSED_MLP = int(_os.environ.get('VITRES_FUSED_MLP', '1'))
+FUSED_MLP = int(_os.environ.get('VITRES_FUSED_MLP', '0'))
 
 
 def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save, pre=None, next_ln=None):

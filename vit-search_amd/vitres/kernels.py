@@ -117,8 +117,8 @@ def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=Fals
 
 
 def mlp_fwd_supported(y, C, F):
-    """vr_mlp_fwd covers this MLP (bf16 activations, first-stage widths)."""
-    return y.dtype == torch.bfloat16 and y.is_cuda and bool(_lib.lib().vr_mlp_fwd_supported(C, F))
+    """vr_mlp_fwd covers this MLP (bf16 activations, first-stage widths; EXPERIMENTAL builds of the library only)."""
+    return y.dtype == torch.bfloat16 and y.is_cuda and _lib.experimental() and bool(_lib.lib().vr_mlp_fwd_supported(C, F))
 
 
 def mlp_fwd(y, w1, b1, w2, b2, resid, out, *, M, C, F, ldw1, ldw2, rows_in=0, scale=None, keep_in=None, keep_hid=None,

@@ -151,6 +151,8 @@ class FlatAdamW(torch.optim.Optimizer):
 
     # ---- checkpoint / EMA views -------------------------------------------------------------------------------
     def state_dict(self):
+        if getattr(self, "_graph_pending", None) is not None and self._graph_pending():
+            raise RuntimeError("a deferred in-graph update is pending: call GraphedTrainStep.finish_update() first")
         self._bind()
         st = self._flat_state
         return {"step": self._step, "exp_avg": st["m"].clone(), "exp_avg_sq": st["v"].clone(),
