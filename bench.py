@@ -43,6 +43,20 @@ REF_TINY_DEF = ((4, 192),) + ((1, (192, 3, 64), (192, 768), 1),) * 4 + ((3, 192,
 MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}      # dense TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def load_traffic(workload, batch, dtype):
+    """PMC traffic of this workload (tools/traffic_run.sh -> profiles/r04_traffic_<workload>.json), used only when the file was
+    measured on the same workload, per-GPU batch and dtype as this run (its "key"); otherwise `traffic` stays null."""
+    name = "r04_traffic_%s.json" % workload
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    try:
+        tj = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    if tj.get("key") != {"workload": workload, "batch": int(batch), "dtype": dtype}:
+        return None, None
+    return tj, name
+
+
 def build_model(name, dtype, device):
     import vitres
     from vitres import supernet_config
@@ -229,13 +243,12 @@ def run_evo_eval(args, rank, world, device):
         if n:
             gbps, ach = by / sec / 1e9, fl / sec / 1e12
             traffic, traffic_note = None, None
-            tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_evo_traffic.json")
-            if os.path.exists(tfile):
-                tj = json.load(open(tfile))
+            tj, tj_name = load_traffic(args.workload, B, args.dtype)
+            if tj is not None:
                 for fam, tv in tj["kernels"].items():
                     if fam.startswith("vr_gemm_nt::nt_kernel"):
                         traffic = round(tv["read_bytes_per_launch"] + tv["write_bytes_per_launch"], 1)
-                        traffic_note = "HBM-side bytes per launch (read + write) from profiles/r03_evo_traffic.json: %s" % tj["source"]
+                        traffic_note = "HBM-side bytes per launch (read + write) from profiles/%s: %s" % (tj_name, tj["source"])
             roof = {"bound": "hbm", "kernel": "vr_gemm_nt::nt_kernel (forward)", "achieved": round(gbps, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "launches_per_step": n // args.profile_steps, "avg_launch_us": round(sec / n * 1e6, 2),
@@ -265,8 +278,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=30,
-                    help="untimed steps; the first ~25 steps of a process run 2-3 %% slower (clocks, first-touch): 7.81 ms timed after 5, 7.60-7.65 after 30 or 100")
+    ap.add_argument("--warmup", type=int, default=5,
+                    help="untimed steps (the driver's protocol: --steps 20 --warmup 5; steady state = --steps 100 --warmup 30, ~0.5 %% lower "
+                         "since the graphed step bounds its run-ahead)")
     ap.add_argument("--workload", default="sr_tiny_supernet", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=None)
@@ -297,6 +311,11 @@ def main():
         port = s_.getsockname()[1]
         s_.close()
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # RCCL's ring kernels take one workgroup (one CU) per channel and run beside the backward, whose side stream already fills
+        # the CUs the main chain leaves idle: cap them at 8 channels (8 of 256 CUs; a ring over 7 xGMI links needs no more to
+        # saturate them at 92 - 228 MB per range) unless the caller chose otherwise.  DESIGN.md section 6.
+        env.setdefault("NCCL_MIN_NCHANNELS", "4")
+        env.setdefault("NCCL_MAX_NCHANNELS", "8")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
@@ -441,8 +460,10 @@ def main():
         exchange = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "allreduce_bytes_per_step": (2 if args.wire == "bf16" else 4) * n_arena,
                     "dtype": args.wire, "ranges": (len(graphed.ranges) if graphed is not None and graphed.ranges else 1),
                     "exposed_ms_per_step": exposed,
+                    "nccl_channels": {k: os.environ.get(k) for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS")},
                     "note": "exposed = GPU time between the end of the last backward graph and the end of the last all-reduce "
-                            "(rank 0, HIP events on the compute stream)"}
+                            "(rank 0, HIP events on the compute stream); compare ms_per_step with the N = 1 line of the same box: "
+                            "ms_per_step(N) - ms_per_step(1) = exposed exchange + what RCCL's kernels cost the backward they run beside"}
 
     if rank != 0:
         if world > 1:
@@ -492,12 +513,7 @@ def main():
             for i in range(5):
                 a[i] += v[i]
         HBM_PEAK = 8000.0                                                   # GB/s, /opt/skills/guides/MI355X_MICROARCH.md
-        tj = None
-        for tname in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):
-            tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname)
-            if os.path.exists(tfile) and args.workload == "sr_tiny_supernet":
-                tj, tj_name = json.load(open(tfile)), tname
-                break
+        tj, tj_name = load_traffic(args.workload, B, args.dtype)
 
         def family_roof(name, sec, fl, by, n, dense, dt_):
             """Which roof binds a kernel family: its arithmetic intensity -- KEPT FLOPs per KEPT algorithmic byte of a launch --
@@ -535,10 +551,24 @@ def main():
         if wg:
             roof["wgrad"] = family_roof(wg[0][0], *wg[0][1])
         peak, ach, gbps = MFMA_PEAK[dom_dt], fl / sec / 1e12, by / sec / 1e9
+        # the same family inside the replayed graph (rocprofv3 trace of this workload, tools/prof_step.sh): eager launches run ~10 %
+        # slower than the graph's, so `frac` above is the pessimistic figure
+        try:
+            gj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_graph_kernels_%s.json" % args.workload)))
+        except (OSError, ValueError):
+            gj = None
+        if gj and gj.get("key") == {"workload": args.workload, "batch": int(B), "dtype": args.dtype}:
+            fam_ = [k for k in gj["kernels"] if roof["kernel"].startswith(k)]
+            if fam_:
+                us = gj["kernels"][fam_[0]]["avg_us"]
+                gb_ = roof["algorithmic_bytes_per_launch"] / us / 1e3
+                roof["graph"] = {"avg_launch_us": round(us, 2), "achieved_GBps": round(gb_, 1), "frac_hbm": round(gb_ / HBM_PEAK, 4),
+                                 "achieved_TFLOPs_kept": round(roof["flops_per_launch"] / us / 1e6, 2),
+                                 "source": "profiles/r04_graph_kernels_%s.json: %s" % (args.workload, gj["source"])}
         roof.update({
                 "note": "FLOPs and bytes = kept (un-masked) sub-problems only; HIP events (recorded on the stream each kernel is launched "
                         "on) around every vr_gemm launch of %d extra eager steps after the timed region, each queued behind a 40 ms GPU spin so that "
-                        "the pairs time the GPU, not the host's launch gaps (profiles/r03_a_kernel_stats.txt has the replayed graph's "
+                        "the pairs time the GPU, not the host's launch gaps (roofline.graph has the replayed graph's "
                         "averages)" % args.profile_steps,
                 "all_gemm_ms_per_step": round(gemm_sec * 1e3, 3),
                 "all_gemm_kinds": {k: {
@@ -547,20 +577,29 @@ def main():
                     for k, v in byname.items()}})
     here = os.path.dirname(os.path.abspath(__file__))
     n1_file = os.path.join(here, "gpurun_out", ".bench_n1_%s.json" % args.workload)
+    import platform
+    import subprocess
+    try:
+        commit = subprocess.run(["git", "-C", here, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+    except (OSError, subprocess.SubprocessError):
+        commit = ""
+    if not commit:                                                 # (the GPU box gets a snapshot without .git: the library identifies the tree)
+        import hashlib
+        from vitres import _lib as _L
+        commit = "lib:" + hashlib.sha256(open(_L.LIB_PATH, "rb").read()).hexdigest()[:16]
+    run_key = {"host": platform.node(), "commit": commit, "workload": args.workload, "batch": B, "dtype": args.dtype}
     if world > 1:                                                   # timed on rank 0 at N = 1 only
         cpu = {"value": None, "unit": "images/sec", "cores": None, "kind": "port",
                "sample": "not timed at N > 1: the CPU oracle runs beside the N = 1 line only (same workload, see that line)"}
-        # ... but a sibling N = 1 line of this workload (written by the N = 1 run on this box, or the tracked one) carries it over
-        for src in (n1_file, os.path.join(here, "profiles", "r03_bench_c3_sr_tiny.json") if args.workload == "sr_tiny_supernet" else None):
-            try:
-                sib = json.load(open(src)) if src else None
-            except (OSError, ValueError):
-                sib = None
-            if sib and sib.get("n_gpus") == 1 and sib.get("config", {}).get("workload") == args.workload and \
-                    (sib.get("cpu_baseline") or {}).get("value"):
-                cpu = dict(sib["cpu_baseline"], copied_from="%s (the N = 1 line of the same workload; not re-timed at N = %d)" % (
-                    os.path.relpath(src, here), world))
-                break
+        # ... but the N = 1 line this box wrote for the same workload, batch, dtype and commit carries it over (anything else --
+        # another box, another tree, a tracked line of an earlier round -- would misstate the speed-up: left null)
+        try:
+            sib = json.load(open(n1_file))
+        except (OSError, ValueError):
+            sib = None
+        if sib and sib.get("n_gpus") == 1 and sib.get("run_key") == run_key and (sib.get("cpu_baseline") or {}).get("value"):
+            cpu = dict(sib["cpu_baseline"], copied_from="the N = 1 line of this box, commit and configuration (%s); not re-timed at "
+                                                        "N = %d" % (os.path.relpath(n1_file, here), world))
     else:
         cpu = None if args.no_cpu_baseline else cpu_baseline(args.workload)
     from vitres.network_utils.compute_flop_mac import train_flops_per_image
@@ -578,7 +617,7 @@ def main():
                                      if (graphed is not None and graphed.graph_b is not None) else
                                      "1 all-reduce of the flat fp32 arena" if world > 1 else "none (1 rank)"),
                    "exchange": exchange, "final_loss": round(lossv[-1], 4)},
-        "roofline": roof, "cpu_baseline": cpu,
+        "roofline": roof, "cpu_baseline": cpu, "run_key": run_key,
         "dense_equiv": {"train_gflop_per_image": round(dense_flops / 1e9, 2),
                         "tflops_per_gpu": round(dense_flops * img_s / world / 1e12, 1),
                         "frac_of_bf16_mfma_peak": round(dense_flops * img_s / world / 2.5e15, 4),

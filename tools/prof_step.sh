@@ -11,5 +11,6 @@ db=$(find $out -name '*.db' | head -1)
 python $root/tools/rocpd_stats.py $db 60 > $root/gpurun_out/${tag}_stats.txt 2>&1
 python $root/tools/rocpd_step.py $db 6 list > $root/gpurun_out/${tag}_step.txt 2>&1
 python $root/tools/rocpd_queues.py $db > $root/gpurun_out/${tag}_queues.txt 2>&1
+python $root/tools/rocpd_family_json.py $db $root/gpurun_out/${tag}_graph_kernels.json ${PROF_KEY:-sr_tiny_supernet:128:bf16} > /dev/null 2>&1
 rm -rf $out
 grep '^{' $root/gpurun_out/${tag}_bench.log | tail -1 | cut -c1-400

@@ -50,6 +50,10 @@ for k, (n, rd, wr) in rows[:28]:
     print("%-44s %7d %14.2f %14.2f %14.1f" % (k, n, rd / n / 1e6, wr / n / 1e6, (rd + wr) / steps / 1e6))
     out[k] = {"launches": n, "read_bytes_per_launch": rd / n, "write_bytes_per_launch": wr / n}
 if len(sys.argv) > 3:
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1 --no-graph` "
+    key = None
+    if len(sys.argv) > 4:                       # workload:batch:dtype of the run (bench.load_traffic refuses a file measured on another one)
+        wl, b, dt = sys.argv[4].split(":")
+        key = {"workload": wl, "batch": int(b), "dtype": dt}
+    json.dump({"key": key, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1 --no-graph` "
                          "single stream; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported", "kernels": out},
               open(sys.argv[3], "w"), indent=1)
