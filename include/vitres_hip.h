@@ -102,7 +102,8 @@ typedef struct vr_gemm_args {
                             4 = always use the general kernel (gemm.hip) -- measurement aid; 8 = 8-wave stream-K kernel (gemm_ntw.hip) wherever it
                             is admissible; 16 = never; 64 = split-K form of the 4-wave kernel (gemm_nt.hip: shares of a tile's K
                             slices on several workgroups, fp32 slabs in ws, the last arriver runs the epilogue) wherever a cut
-                            exists.  vr_gemm_ln: 8 = the one-workgroup-per-CU form (gemm_nt_lnw.hip) whenever
+                            exists; 128 (vr_gemm_group, first problem) = the group may fill the chip (default: capped at two resident workgroups
+                            per CU, VITRES_TN_GROUP_CAP).  vr_gemm_ln: 8 = the one-workgroup-per-CU form (gemm_nt_lnw.hip) whenever
                             N <= 256, 16 = never (default: for M >= 64 rows per CU) */
     vr_rowmap a_map;     /* remap of A's token rows (M index if a_trans==0, K index if a_trans==1) */
     vr_rowmap b_map;     /* remap of B's token rows (only meaningful when b_trans==1 && a_trans==1) */

@@ -883,7 +883,7 @@ def test_bf16_step_trains_like_the_fp32_step():
 
 
 OPT_IN_FORMS = ["VITRES_NT_SPLIT=2", "VITRES_WGRAD_STORE=1", "VITRES_TN_GROUP_CAP=0", "VITRES_LN_XCD=0 VITRES_ATTN_XCD=0",
-                "VITRES_TAIL_AUX=0 VITRES_EMBED_WGRAD_SLICES=0", "VITRES_OVERLAP=0"]
+                "VITRES_TAIL_AUX=0 VITRES_EMBED_WGRAD_SLICES=0", "VITRES_OVERLAP=0", "VITRES_LAST_UNCAP=0"]
 
 
 def test_opt_in_forms_at_model_level(tmp_path):

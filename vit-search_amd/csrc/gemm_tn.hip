@@ -335,7 +335,7 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
     // VITRES_TN_GROUP_CAP = workgroups per CU the group may hold at once, in tenths (15 = 1.5 per CU; 0 = one workgroup per item)
     static const int knob_cap = std::getenv("VITRES_TN_GROUP_CAP") ? std::atoi(std::getenv("VITRES_TN_GROUP_CAP")) : 20;
     int grid = next;
-    if (knob_cap > 0) {
+    if (knob_cap > 0 && !(args[0].sched & 128)) {            // (sched bit 128: nothing runs beside this group -- the step's last)
         const int lim = (knob_cap * n_cu / 10 + 7) / 8 * 8;
         grid = next < lim ? next : lim;
     }

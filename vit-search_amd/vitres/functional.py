@@ -269,6 +269,15 @@ _block_wgrads = []       # collected (dy, x, dw, kwargs) of the block being walk
 WGRAD_EARLY = _os.environ.get('VITRES_WGRAD_EARLY', '0') != '0'
 
 
+# The LAST block of a backward (the network's first block): nothing follows it on the main chain and the optimizer waits for its
+# weight-gradient group.  (Measured and dropped: launching its fc2 / fc1 / proj gradients early and qkv's alone at the end --
+# the side stream then runs one capped group behind at the end of the step, 7.66 against 7.58 ms.)
+# VITRES_LAST_UNCAP=1: the last block's weight-gradient group(s) are launched without the per-CU cap (sched bit 128): little or
+# nothing of the main chain is left to protect, and the optimizer waits for them
+LAST_UNCAP = _os.environ.get('VITRES_LAST_UNCAP', '1') != '0'
+LAST_BLOCK = [False]         # set by the model's backward walk around the last block
+
+
 def flush_wgrads():
     """Launch the collected weight gradients as one group on the side stream (no-op when nothing is pending)."""
     if not _block_wgrads:
@@ -330,6 +339,7 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     dt = cfg["dtype"]
     ov = _overlap(g)
     sch = 1 if ov else 0
+    wsch = sch | (128 if (LAST_UNCAP and LAST_BLOCK[0]) else 0)     # weight gradients of the step's last block: uncapped group
     if gt is None:
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                   # d(branch output), compute dtype
 
@@ -337,7 +347,7 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
 
     def wgrad_proj():
         linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"], keep_rows=out_keep, keep_cols=attn_keep,
-                     tokens_per_sample=N, sched=sch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
+                     tokens_per_sample=N, sched=wsch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
     if grp is not None:
         wgrad_proj()
         if WGRAD_EARLY:
@@ -354,7 +364,7 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
 
     def wgrad_qkv():
         linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C, db=grads["qkv.b"], keep_rows=attn_keep,
-                     keep_cols=embed_keep, row_period=HD, tokens_per_sample=N, sched=sch, collect=grp,
+                     keep_cols=embed_keep, row_period=HD, tokens_per_sample=N, sched=wsch, collect=grp,
                      store=wgrad_store_ok(M, dt, g.is_cuda))
     if grp is not None:
         wgrad_qkv()
@@ -441,6 +451,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     dt = cfg["dtype"]
     ov = _overlap(g)
     sch = 1 if ov else 0
+    wsch = sch | (128 if (LAST_UNCAP and LAST_BLOCK[0]) else 0)     # weight gradients of the step's last block: uncapped group
     if gt is None:
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
 
@@ -448,7 +459,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
 
     def wgrad_fc2():
         linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"], keep_rows=out_keep, keep_cols=mlp_keep,
-                     tokens_per_sample=N, sched=sch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
+                     tokens_per_sample=N, sched=wsch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
     if ov and grp is None:
         on_side(wgrad_fc2, gt)
     else:
@@ -459,7 +470,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
 
     def wgrad_fc1():
         linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"], keep_rows=mlp_keep, keep_cols=embed_keep,
-                     tokens_per_sample=N, sched=sch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
+                     tokens_per_sample=N, sched=wsch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
     if ov and grp is None:
         on_side(wgrad_fc1, du)
     else:
@@ -572,7 +583,9 @@ EMBED_WGRAD_SLICES = int(_os.environ.get('VITRES_EMBED_WGRAD_SLICES', '8'))
 TAIL_AUX = _os.environ.get('VITRES_TAIL_AUX', '1') != '0'
 
 
-def embed0_bwd(g, saved, p, grads, cfg, keep, gt=None):
+def embed0_bwd(g, saved, p, grads, cfg, keep, gt=None, wgrad=True, pos=True):
+    """wgrad / pos: which half to run (the step tail issues the projection's weight gradient on an auxiliary stream and the
+    positional-embedding sums on the main one: nothing orders them)."""
     flush_wgrads()
     (col,) = saved
     B, N, C = g.shape
@@ -585,8 +598,10 @@ def embed0_bwd(g, saved, p, grads, cfg, keep, gt=None):
     split = 0
     if EMBED_WGRAD_SLICES > 0 and g.is_cuda and dt == torch.bfloat16:
         split = max(1, -(-(B * P) // (64 * EMBED_WGRAD_SLICES)))
-    linear_wgrad(gt, col, grads["proj.w"], B * P, C, ldk, C, ldk, a_map=(P, N, T), db=grads["proj.b"], split=split)
-    K.batchsum(g, grads["pos"])                                             # d pos_embed [N, C] (rows 0..T-1 also = d tokens)
+    if wgrad:
+        linear_wgrad(gt, col, grads["proj.w"], B * P, C, ldk, C, ldk, a_map=(P, N, T), db=grads["proj.b"], split=split)
+    if pos:
+        K.batchsum(g, grads["pos"])                                         # d pos_embed [N, C] (rows 0..T-1 also = d tokens)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -981,7 +981,6 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 return (None, ekeep0)
             return None
         gt = st["gt"]
-        tail_aux = False
         parts = a.get("ln_parts") if Fn.LN_COPIES > 1 else None
 
         def with_parts(grads, *pairs):
@@ -1012,9 +1011,13 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                          "fc1.w": gv(blk.mlp.fc1.weight), "fc1.b": gv(blk.mlp.fc1.bias),
                          "fc2.w": gv(blk.mlp.fc2.weight), "fc2.b": gv(blk.mlp.fc2.bias)}
                 with_parts(grads, ("n1w", blk.norm1.weight), ("n2w", blk.norm2.weight))
-                g, gt = Fn.mlp_branch_bwd(g, sm, p, grads, cfg, ek, km, ko, s2, gt=gt, next_cast=(s1, ko))      # gt: attention branch's
-                nc = consumer_cast(ti)
-                g = Fn.attn_branch_bwd(g, sa, p, grads, cfg, ek, ka, ko, s1, gt=gt, next_cast=nc)
+                Fn.LAST_BLOCK[0] = not any(e[0] == "block" for e in rtape[ti + 1:])     # (no block follows: functional.LAST_EARLY)
+                try:
+                    g, gt = Fn.mlp_branch_bwd(g, sm, p, grads, cfg, ek, km, ko, s2, gt=gt, next_cast=(s1, ko))      # gt: attention branch's
+                    nc = consumer_cast(ti)
+                    g = Fn.attn_branch_bwd(g, sa, p, grads, cfg, ek, ka, ko, s1, gt=gt, next_cast=nc)
+                finally:
+                    Fn.LAST_BLOCK[0] = False
                 g, gt = g if nc is not None else (g, None)
             elif kind == "sr":
                 _, blk, p, cfg, (ek, nk), sv = entry
@@ -1044,26 +1047,27 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                                                                                         device=dev))
                     grads = {"proj.w": wt, "proj.b": gv(self.patch_embed.proj.bias), "pos": gv(self.pos_embed)}
 
-                    def tail(g=g, sv=sv, ep=ep, grads=grads, ecfg=ecfg, ekeep=ekeep, gt=gt, wt=wt, w=w, k=k, ld=ld):
-                        Fn.embed0_bwd(g, sv, ep, grads, ecfg, ekeep, gt=gt)
-                        if ld != k:
+                    def tail(wgrad=True, pos=True, g=g, sv=sv, ep=ep, grads=grads, ecfg=ecfg, ekeep=ekeep, gt=gt, wt=wt, w=w, k=k, ld=ld):
+                        Fn.embed0_bwd(g, sv, ep, grads, ecfg, ekeep, gt=gt, wgrad=wgrad, pos=pos)
+                        if wgrad and ld != k:
                             K.relayout(wt, gv(w), w.shape[0], 1, k, src_ld=ld)   # drop the pad columns
-                        gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:self.num_tokens, :])
+                        if pos:
+                            gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:self.num_tokens, :])
                     if Fn.TAIL_AUX and Fn.OVERLAP and g.is_cuda:
-                        # nothing downstream but the optimizer: beside the first block's weight-gradient group, not after it
+                        # nothing downstream but the optimizer: the projection's weight gradient on the auxiliary stream beside the
+                        # first block's last weight gradient, the small reductions meanwhile on the main stream
                         Fn.flush_wgrads()
-                        Fn.on_aux("tail", tail, g, gt, wt, *sv)
-                        tail_aux = True
+                        if gt is None:
+                            gt = K.scale_mask_cast(g, None, ekeep, g.shape[1], ecfg["dtype"])
+                        Fn.on_aux("tail", lambda gt=gt: tail(True, False, gt=gt), g, gt, wt, *sv)
+                        tail(False, True, gt=gt)
                     else:
                         tail()
                 else:
                     from .. import stem
                     stem.embed_conv_bwd(self, g, sv, ep, ecfg, ekeep, gv, gt=gt)
                     gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:self.num_tokens, :])
-        if tail_aux:
-            Fn.on_aux("tail", Fn.flush_ln_grads)
-        else:
-            Fn.flush_ln_grads()            # LayerNorm weight / bias gradients of this part: partial rows -> arena
+        Fn.flush_ln_grads()                # LayerNorm weight / bias gradients of this part: partial rows -> arena
         if stop >= len(rtape) or getattr(self, "_bwd_join_parts", True):
             Fn.join_side()                 # weight-gradient GEMMs trail on the side stream (functional.on_side); an intermediate
                                            # stop joins too unless the next part follows in the same capture (_bwd_join_parts)
