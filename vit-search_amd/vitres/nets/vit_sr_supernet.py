@@ -1011,7 +1011,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                          "fc1.w": gv(blk.mlp.fc1.weight), "fc1.b": gv(blk.mlp.fc1.bias),
                          "fc2.w": gv(blk.mlp.fc2.weight), "fc2.b": gv(blk.mlp.fc2.bias)}
                 with_parts(grads, ("n1w", blk.norm1.weight), ("n2w", blk.norm2.weight))
-                Fn.LAST_BLOCK[0] = not any(e[0] == "block" for e in rtape[ti + 1:])     # (no block follows: functional.LAST_EARLY)
+                Fn.LAST_BLOCK[0] = not any(e[0] == "block" for e in rtape[ti + 1:])     # (no block follows: functional.LAST_UNCAP)
                 try:
                     g, gt = Fn.mlp_branch_bwd(g, sm, p, grads, cfg, ek, km, ko, s2, gt=gt, next_cast=(s1, ko))      # gt: attention branch's
                     nc = consumer_cast(ti)
