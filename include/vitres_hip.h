@@ -420,6 +420,10 @@ int vr_conv3x3_bias_relu_patch(const void* a, const void* w, const float* bias, 
  * (autograd of `x = conv3(conv2(a1)) + a1`, nets/patch_conv.py:69) without a separate add pass. */
 int vr_conv3x3_res(const void* a, const void* w, const void* res, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin,
                    int32_t Cout, int32_t out_dtype, vr_stream_t stream);
+/* the same with `res` stored in PATCH order (vr_patch_unfold's layout, windows of res_patch x res_patch pixels): the projection's data
+ * gradient as its GEMM writes it -- no fold pass between the 7 x 7 / stride-7 projection and the stem's backward (round 4). */
+int vr_conv3x3_res_patch(const void* a, const void* w, const void* res, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                         int32_t Cout, int32_t out_dtype, int32_t res_patch, vr_stream_t stream);
 /* Weights of that data-gradient convolution: dst[ci, (kh, kw, co)] = src[co, ci, 2 - kh, 2 - kw] (src fp32 [Co, Ci, 3, 3]). */
 int vr_conv_w_flip(const float* src, void* dst, int32_t Co, int32_t Ci, int32_t dst_dtype, vr_stream_t stream);
 
@@ -448,6 +452,14 @@ int vr_bn_bwd(const void* da, const void* z, const float* scale, const float* sh
               vr_stream_t stream);
 int vr_patch_unfold(void* a, void* col, int32_t B, int32_t gh, int32_t gw, int32_t P, int32_t C, int32_t fold, int32_t dtype,
                     vr_stream_t stream);
+/* Training-mode patchify without the unfold / fold passes (nets/patch_conv.py:56-58,70-72; round 4): vr_bn_relu_patch writes
+ * relu(bn(z)) (+ res, NHWC) straight into the patchify operand col [B*(H/patch)*(W/patch), (i, j, c)] of the projection GEMM;
+ * vr_bn_bwd_patch reads `da` in that layout (the projection's data gradient as its GEMM leaves it), z and dz stay NHWC. */
+int vr_bn_relu_patch(const void* z, const float* scale, const float* shift, const void* res, void* out, int32_t B, int32_t H,
+                     int32_t W, int32_t patch, int32_t C, int32_t dtype, int32_t z_dtype, vr_stream_t stream);
+int vr_bn_bwd_patch(const void* da, const void* z, const float* scale, const float* shift, const float* mean, const float* rstd,
+                    float* sg, float* sgz, void* dz, int32_t B, int32_t H, int32_t W, int32_t patch, int32_t C, int32_t training,
+                    int32_t dtype, int32_t z_dtype, vr_stream_t stream);
 
 #ifdef __cplusplus
 }

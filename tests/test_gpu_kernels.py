@@ -537,6 +537,21 @@ def test_stem_glue_kernels():
     nhwc = K.conv3x3_bias_relu(a, wt.to(DEV), bias, res, B, H, W, 24, 24, torch.bfloat16)
     col = K.conv3x3_bias_relu_patch(a, wt.to(DEV), bias, res, B, H, W, 24, 24, P, torch.bfloat16)
     assert torch.equal(col, K.patch_unfold(nhwc, B, H // P, W // P, P, 24))
+    # training-mode patchify without the unfold / fold passes (round 4): BatchNorm + ReLU (+ skip) writing patch order, BatchNorm
+    # backward and the skip connection's add reading it -- each == the NHWC form around vr_patch_unfold
+    z = (rnd(B * H * W, 24, seed=13) * 2).to(DEV)
+    sc, sh = (1 + 0.1 * rnd(24, seed=14)).to(DEV), (0.1 * rnd(24, seed=15)).to(DEV)
+    mu, rs = (0.2 * rnd(24, seed=16)).to(DEV), (1 + 0.1 * rnd(24, seed=17).abs()).to(DEV)
+    for zz in (z, z.bfloat16()):
+        colp = K.bn_relu_patch(zz, sc, sh, res, B, H, W, P, torch.bfloat16)
+        assert torch.equal(colp, K.patch_unfold(K.bn_relu(zz, sc, sh, res, torch.bfloat16), B, H // P, W // P, P, 24))
+        dcol = rnd(B * (H // P) * (W // P), P * P * 24, seed=18).bfloat16().to(DEV)
+        sg = torch.zeros(4, 24, device=DEV)
+        dz_p = K.bn_bwd_patch(dcol, zz, sc, sh, mu, rs, sg[0], sg[1], True, B, H, W, P)
+        dz_r = K.bn_bwd(K.patch_fold(dcol, B, H // P, W // P, P, 24), zz, sc, sh, mu, rs, sg[2], sg[3], True)
+        assert relerr(sg[0], sg[2]) < 1e-5 and relerr(sg[1], sg[3]) < 1e-5 and relerr(dz_p, dz_r) < 8e-3
+    got = K.conv3x3_res_patch(a, wt.to(DEV), dcol, B, H, W, 24, 24, P, torch.bfloat16)
+    assert torch.equal(got, K.conv3x3_res(a, wt.to(DEV), K.patch_fold(dcol, B, H // P, W // P, P, 24), B, H, W, 24, 24, torch.bfloat16))
 
 
 def test_softce():

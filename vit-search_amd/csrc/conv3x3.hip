@@ -21,7 +21,7 @@ constexpr int TH = 16, TW = 16, PH = TH + 2, PW = TW + 2;
 template <int NC, typename TO>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ w,
                                                       TO* __restrict__ out, int B, int H, int W, int Cout,
-                                                      const float* __restrict__ bias, const bf16_t* __restrict__ res, int psz) {
+                                                      const float* __restrict__ bias, const bf16_t* __restrict__ res, int psz, int rpsz) {
     constexpr int Cin = 8 * NC, K9 = 9 * NC, STEPS = (K9 + 3) / 4;
     constexpr int PS = Cin * 2 + ((NC & 1) ? 0 : 16);                 // pixel stride in LDS, bytes
     __shared__ __attribute__((aligned(16))) char patch[PH * PW * PS];
@@ -99,7 +99,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const bf16_t* __restrict__
                         r4[2] = fmaxf(r4[2] + bb.z, 0.f); r4[3] = fmaxf(r4[3] + bb.w, 0.f);
                     }
                     if (res) {       // residual (evaluation: behind the ReLU; data gradients: the gradient of the stem's skip branch)
-                        const uint2 rr = *reinterpret_cast<const uint2*>(res + (((long long)b * H + oy) * W + ox) * Cout + co);
+                        long long rpix = ((long long)b * H + oy) * W + ox;         // rpsz > 0: the residual is stored in patch order
+                        if (rpsz > 0)
+                            rpix = (((long long)b * (H / rpsz) + oy / rpsz) * (W / rpsz) + ox / rpsz) * (rpsz * rpsz) + (oy % rpsz) * rpsz + ox % rpsz;
+                        const uint2 rr = *reinterpret_cast<const uint2*>(res + rpix * Cout + co);
                         r4[0] += __uint_as_float(rr.x << 16); r4[1] += __uint_as_float(rr.x & 0xffff0000u);
                         r4[2] += __uint_as_float(rr.y << 16); r4[3] += __uint_as_float(rr.y & 0xffff0000u);
                     }
@@ -308,10 +311,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const bf16_t* __rest
 }
 
 template <int NC> int launch(const bf16_t* a, const bf16_t* w, void* out, int B, int H, int W, int Cout, int out_dtype, hipStream_t st,
-                             const float* bias = nullptr, const bf16_t* res = nullptr, int patch = 0) {
+                             const float* bias = nullptr, const bf16_t* res = nullptr, int patch = 0, int rpatch = 0) {
     const unsigned grid = (unsigned)(B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW));
-    if (out_dtype == VR_F32) hipLaunchKernelGGL((conv3x3_kernel<NC, float>), dim3(grid), dim3(256), 0, st, a, w, (float*)out, B, H, W, Cout, bias, res, patch);
-    else hipLaunchKernelGGL((conv3x3_kernel<NC, bf16_t>), dim3(grid), dim3(256), 0, st, a, w, (bf16_t*)out, B, H, W, Cout, bias, res, patch);
+    if (out_dtype == VR_F32) hipLaunchKernelGGL((conv3x3_kernel<NC, float>), dim3(grid), dim3(256), 0, st, a, w, (float*)out, B, H, W, Cout, bias, res, patch, rpatch);
+    else hipLaunchKernelGGL((conv3x3_kernel<NC, bf16_t>), dim3(grid), dim3(256), 0, st, a, w, (bf16_t*)out, B, H, W, Cout, bias, res, patch, rpatch);
     return 0;
 }
 
@@ -335,7 +338,7 @@ extern "C" int vr_conv3x3_wgrad(const void* a, const void* dz, float* dw, int32_
 }
 
 static int conv3x3_entry(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
-                         int32_t out_dtype, const float* bias, const void* res, vr_stream_t stream, int patch = 0);
+                         int32_t out_dtype, const float* bias, const void* res, vr_stream_t stream, int patch = 0, int rpatch = 0);
 
 extern "C" int vr_conv3x3(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                           int32_t out_dtype, vr_stream_t stream) {
@@ -346,6 +349,14 @@ extern "C" int vr_conv3x3_res(const void* a, const void* w, const void* res, voi
                               int32_t Cout, int32_t out_dtype, vr_stream_t stream) {
     if (!res || ((uintptr_t)res & 7)) return VR_EINVAL;
     return conv3x3_entry(a, w, out, B, H, W, Cin, Cout, out_dtype, nullptr, res, stream);
+}
+
+// the same with `res` stored in patch order (non-overlapping res_patch x res_patch windows, vr_patch_unfold's layout): the gradient
+// of the stem's skip connection as the projection's data gradient leaves it
+extern "C" int vr_conv3x3_res_patch(const void* a, const void* w, const void* res, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                    int32_t Cout, int32_t out_dtype, int32_t res_patch, vr_stream_t stream) {
+    if (!res || ((uintptr_t)res & 7) || res_patch <= 0 || H % res_patch || W % res_patch) return VR_EINVAL;
+    return conv3x3_entry(a, w, out, B, H, W, Cin, Cout, out_dtype, nullptr, res, stream, 0, res_patch);
 }
 
 extern "C" int vr_conv3x3_bias_relu(const void* a, const void* w, const float* bias, const void* res, void* out, int32_t B,
@@ -362,16 +373,16 @@ extern "C" int vr_conv3x3_bias_relu_patch(const void* a, const void* w, const fl
 }
 
 static int conv3x3_entry(const void* a, const void* w, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
-                         int32_t out_dtype, const float* bias, const void* res, vr_stream_t stream, int patch) {
+                         int32_t out_dtype, const float* bias, const void* res, vr_stream_t stream, int patch, int rpatch) {
     if (!a || !w || !out || B <= 0 || H <= 0 || W <= 0) return VR_EINVAL;
     if (out_dtype != VR_F32 && out_dtype != VR_BF16) return VR_EUNSUPPORTED;
     if (Cout <= 0 || Cout > 32 || Cout % 4) return VR_EUNSUPPORTED;
     if (((uintptr_t)a & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return VR_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     switch (Cin) {
-        case 16: launch<2>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res, patch); break;
-        case 24: launch<3>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res, patch); break;
-        case 32: launch<4>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res, patch); break;
+        case 16: launch<2>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res, patch, rpatch); break;
+        case 24: launch<3>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res, patch, rpatch); break;
+        case 32: launch<4>((const bf16_t*)a, (const bf16_t*)w, out, B, H, W, Cout, out_dtype, st, bias, (const bf16_t*)res, patch, rpatch); break;
         default: return VR_EUNSUPPORTED;
     }
     VR_CHECK_LAUNCH();

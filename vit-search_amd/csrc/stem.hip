@@ -185,10 +185,24 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const TZ* __restrict__ z,
 }
 
 // out = relu(z * scale[c] + shift[c]) (+ res)
+// Pixel (b, y, x) of an NHWC tensor -> its row in the patchify operand of the 7 x 7 / stride-7 projection ([B*gh*gw, (i, j, c)],
+// vr_patch_unfold's layout): the P x P windows do not overlap, so patch order is a permutation of the pixels and a pixel's C channels
+// stay contiguous.  Round 4: the last BatchNorm + ReLU of the stem WRITES patch order, and the backward's readers of d(that tensor)
+// (BatchNorm backward, the skip connection's add in the data-gradient convolution) READ it -- the unfold / fold passes (410 MB each
+// way at B = 128) are gone from the training step.  P = 0: identity.
+__device__ __forceinline__ long long patch_pix(long long pix, int H, int W, int P) {
+    if (P <= 0) return pix;
+    const int x = (int)(pix % W);
+    const long long t = pix / W;
+    const int y = (int)(t % H);
+    const long long b = t / H;
+    return ((b * (H / P) + y / P) * (W / P) + x / P) * (P * P) + (y % P) * P + x % P;
+}
+
 template <typename T, typename TZ>
 __global__ __launch_bounds__(256) void bn_relu_kernel(const TZ* __restrict__ z, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const T* __restrict__ res,
-                                                      T* __restrict__ out, long long total8, int C) {
+                                                      T* __restrict__ out, long long total8, int C, int H, int W, int P) {
     const int c8n = C / 8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
         const int c0 = (int)(i % c8n) * 8;
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const TZ* __restrict__ z, 
             if (res) v += r[e];
             f[e] = v;
         }
-        V8<T>::store(out + i * 8, f);
+        V8<T>::store(out + patch_pix(i / c8n, H, W, P) * C + c0, f);
     }
 }
 
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             float* __restrict__ sg, float* __restrict__ sgz, long long R,
-                                                            int C) {
+                                                            int C, int H, int W, int P) {
     __shared__ float red[2][256 * 8];
     const int c8n = C / 8;
     const int rows_par = 256 / c8n;
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             for (int u = 0; u < 4; ++u) {
                 const long long ru = r + u * step < R ? r + u * step : r;         // (rows past the end: row r again, not summed)
                 V8<TZ>::load(z + ru * C + c8 * 8, f[u]);
-                V8<T>::load(da + ru * C + c8 * 8, g[u]);
+                V8<T>::load(da + patch_pix(ru, H, W, P) * C + c8 * 8, g[u]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -270,13 +284,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ sg, const float* __restrict__ sgz,
-                                                           float inv_n, T* __restrict__ dz, long long total8, int C) {
+                                                           float inv_n, T* __restrict__ dz, long long total8, int C, int H, int W,
+                                                           int P) {
     const int c8n = C / 8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
         const int c0 = (int)(i % c8n) * 8;
         float f[8], g[8];
         V8<TZ>::load(z + i * 8, f);
-        V8<T>::load(da + i * 8, g);
+        V8<T>::load(da + patch_pix(i / c8n, H, W, P) * C + c0, g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e;
@@ -374,23 +389,33 @@ extern "C" int vr_bn_stats(const void* z, float* sum, float* sumsq, int64_t R, i
     return VR_OK;
 }
 
-extern "C" int vr_bn_relu(const void* z, const float* scale, const float* shift, const void* res, void* out, int64_t R,
-                          int32_t C, int32_t dtype, int32_t z_dtype, vr_stream_t stream) {
+static int bn_relu_entry(const void* z, const float* scale, const float* shift, const void* res, void* out, int64_t R,
+                          int32_t C, int32_t dtype, int32_t z_dtype, vr_stream_t stream, int H, int W, int P) {
     if (!z || !scale || !shift || !out || R <= 0 || C <= 0) return VR_EINVAL;
     if (C % 8) return VR_EUNSUPPORTED;
     if (z_dtype != VR_F32 && !(z_dtype == VR_BF16 && dtype == VR_BF16)) return VR_EUNSUPPORTED;
     const long long total8 = (long long)R * (C / 8);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VR_F32)
-        hipLaunchKernelGGL((bn_relu_kernel<float, float>), dim3(grid_for(total8)), dim3(256), 0, st, (const float*)z, scale, shift, (const float*)res, (float*)out, total8, C);
+        hipLaunchKernelGGL((bn_relu_kernel<float, float>), dim3(grid_for(total8)), dim3(256), 0, st, (const float*)z, scale, shift, (const float*)res, (float*)out, total8, C, H, W, P);
     else if (dtype == VR_BF16 && z_dtype == VR_F32)
-        hipLaunchKernelGGL((bn_relu_kernel<bf16_t, float>), dim3(grid_for(total8)), dim3(256), 0, st, (const float*)z, scale, shift, (const bf16_t*)res, (bf16_t*)out, total8, C);
+        hipLaunchKernelGGL((bn_relu_kernel<bf16_t, float>), dim3(grid_for(total8)), dim3(256), 0, st, (const float*)z, scale, shift, (const bf16_t*)res, (bf16_t*)out, total8, C, H, W, P);
     else if (dtype == VR_BF16)
-        hipLaunchKernelGGL((bn_relu_kernel<bf16_t, bf16_t>), dim3(grid_for(total8)), dim3(256), 0, st, (const bf16_t*)z, scale, shift, (const bf16_t*)res, (bf16_t*)out, total8, C);
+        hipLaunchKernelGGL((bn_relu_kernel<bf16_t, bf16_t>), dim3(grid_for(total8)), dim3(256), 0, st, (const bf16_t*)z, scale, shift, (const bf16_t*)res, (bf16_t*)out, total8, C, H, W, P);
     else
         return VR_EUNSUPPORTED;
     VR_CHECK_LAUNCH();
     return VR_OK;
+}
+
+extern "C" int vr_bn_relu(const void* z, const float* scale, const float* shift, const void* res, void* out, int64_t R,
+                          int32_t C, int32_t dtype, int32_t z_dtype, vr_stream_t stream) {
+    return bn_relu_entry(z, scale, shift, res, out, R, C, dtype, z_dtype, stream, 0, 0, 0);
+}
+extern "C" int vr_bn_relu_patch(const void* z, const float* scale, const float* shift, const void* res, void* out, int32_t B, int32_t H,
+                                int32_t W, int32_t patch, int32_t C, int32_t dtype, int32_t z_dtype, vr_stream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || patch <= 0 || H % patch || W % patch) return VR_EINVAL;
+    return bn_relu_entry(z, scale, shift, res, out, (int64_t)B * H * W, C, dtype, z_dtype, stream, H, W, patch);
 }
 
 // Train-mode BatchNorm2d between the statistics pass and the normalise pass, one launch instead of a dozen elementwise ones
@@ -430,9 +455,9 @@ extern "C" int vr_bn_finalize(const float* sum, const float* sumsq, int64_t n, c
     return VR_OK;
 }
 
-extern "C" int vr_bn_bwd(const void* da, const void* z, const float* scale, const float* shift, const float* mean,
+static int bn_bwd_entry(const void* da, const void* z, const float* scale, const float* shift, const float* mean,
                          const float* rstd, float* sg, float* sgz, void* dz, int64_t R, int32_t C, int32_t training,
-                         int32_t dtype, int32_t z_dtype, vr_stream_t stream) {
+                         int32_t dtype, int32_t z_dtype, vr_stream_t stream, int H, int W, int P) {
     if (!da || !z || !scale || !shift || !mean || !rstd || !sg || !sgz || !dz || R <= 0 || C <= 0) return VR_EINVAL;
     if (C % 8 || C > 256) return VR_EUNSUPPORTED;
     if (dtype != VR_F32 && dtype != VR_BF16) return VR_EUNSUPPORTED;
@@ -446,9 +471,9 @@ extern "C" int vr_bn_bwd(const void* da, const void* z, const float* scale, cons
 #define VR_BN_BWD(T, TZ)                                                                                                       \
     do {                                                                                                                       \
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, TZ>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)da, (const TZ*)z,  \
-                           scale, shift, mean, rstd, sg, sgz, (long long)R, C);                                                \
+                           scale, shift, mean, rstd, sg, sgz, (long long)R, C, H, W, P);                                                \
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T, TZ>), dim3(grid_for(total8)), dim3(256), 0, st, (const T*)da, (const TZ*)z,   \
-                           scale, shift, mean, rstd, sg, sgz, inv_n, (T*)dz, total8, C);                                       \
+                           scale, shift, mean, rstd, sg, sgz, inv_n, (T*)dz, total8, C, H, W, P);                                       \
     } while (0)
     if (dtype == VR_F32) VR_BN_BWD(float, float);
     else if (z_dtype == VR_F32) VR_BN_BWD(bf16_t, float);
@@ -456,6 +481,18 @@ extern "C" int vr_bn_bwd(const void* da, const void* z, const float* scale, cons
 #undef VR_BN_BWD
     VR_CHECK_LAUNCH();
     return VR_OK;
+}
+
+extern "C" int vr_bn_bwd(const void* da, const void* z, const float* scale, const float* shift, const float* mean,
+                         const float* rstd, float* sg, float* sgz, void* dz, int64_t R, int32_t C, int32_t training,
+                         int32_t dtype, int32_t z_dtype, vr_stream_t stream) {
+    return bn_bwd_entry(da, z, scale, shift, mean, rstd, sg, sgz, dz, R, C, training, dtype, z_dtype, stream, 0, 0, 0);
+}
+extern "C" int vr_bn_bwd_patch(const void* da, const void* z, const float* scale, const float* shift, const float* mean,
+                               const float* rstd, float* sg, float* sgz, void* dz, int32_t B, int32_t H, int32_t W, int32_t patch,
+                               int32_t C, int32_t training, int32_t dtype, int32_t z_dtype, vr_stream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || patch <= 0 || H % patch || W % patch) return VR_EINVAL;
+    return bn_bwd_entry(da, z, scale, shift, mean, rstd, sg, sgz, dz, (int64_t)B * H * W, C, training, dtype, z_dtype, stream, H, W, patch);
 }
 
 extern "C" int vr_patch_unfold(void* a, void* col, int32_t B, int32_t gh, int32_t gw, int32_t P, int32_t C, int32_t fold,

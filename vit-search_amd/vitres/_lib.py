@@ -109,6 +109,9 @@ SYMBOLS = {
     "vr_bn_relu": [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32, c_void_p],
     "vr_bn_bwd": [c_void_p] * 9 + [c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p],
     "vr_patch_unfold": [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p],
+    "vr_bn_relu_patch": [c_void_p] * 5 + [c_int32] * 7 + [c_void_p],
+    "vr_bn_bwd_patch": [c_void_p] * 9 + [c_int32] * 8 + [c_void_p],
+    "vr_conv3x3_res_patch": [c_void_p] * 4 + [c_int32] * 7 + [c_void_p],
 }
 
 # include/vitres_hip_experimental.h: present only in `make EXPERIMENTAL=1` builds (VITRES_LIB=.../libvitres_hip_exp.so)

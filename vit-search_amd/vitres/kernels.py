@@ -563,6 +563,14 @@ def conv3x3_res(a, w, res, B, H, W, Cin, Cout, out_dtype):
     return out
 
 
+def conv3x3_res_patch(a, w, res_col, B, H, W, Cin, Cout, res_patch, out_dtype):
+    """conv3x3_res with `res` in patch order ([B*(H/p)*(W/p), p*p*Cout], patch_unfold's layout) -- vr_conv3x3_res_patch."""
+    out = torch.empty((B * H * W, Cout), dtype=out_dtype, device=a.device)
+    _lib.check(_lib.lib().vr_conv3x3_res_patch(_p(a), _p(w), _p(res_col), _p(out), B, H, W, Cin, Cout, _dtcode(out_dtype), res_patch,
+                                               _stream()), "vr_conv3x3_res_patch")
+    return out
+
+
 def conv_w_flip(w, out_dtype):
     """Weights of the data-gradient convolution of a 3x3 / stride 1 / pad 1 Conv2d: [Ci, (kh, kw, co)] = w[co, ci, 2-kh, 2-kw]."""
     Co, Ci = w.shape[0], w.shape[1]
@@ -650,6 +658,24 @@ def bn_bwd(da, z, scale, shift, mean, rstd, sg, sgz, training):
     dz = torch.empty((R, C), dtype=da.dtype, device=z.device)
     _lib.check(_lib.lib().vr_bn_bwd(_p(da), _p(z), _p(scale), _p(shift), _p(mean), _p(rstd), _p(sg), _p(sgz), _p(dz), R, C,
                                     int(training), _dt(da), _dt(z), _stream()), "vr_bn_bwd")
+    return dz
+
+
+def bn_relu_patch(z, scale, shift, res, B, H, W, patch, out_dtype):
+    """bn_relu with the result written as the patchify operand [B*(H/patch)*(W/patch), patch*patch*C] (patch_unfold's layout)."""
+    C = z.shape[-1]
+    col = torch.empty((B * (H // patch) * (W // patch), patch * patch * C), dtype=out_dtype, device=z.device)
+    _lib.check(_lib.lib().vr_bn_relu_patch(_p(z), _p(scale), _p(shift), _p(res), _p(col), B, H, W, patch, C, _dtcode(out_dtype),
+                                           _dt(z), _stream()), "vr_bn_relu_patch")
+    return col
+
+
+def bn_bwd_patch(dcol, z, scale, shift, mean, rstd, sg, sgz, training, B, H, W, patch):
+    """bn_bwd whose incoming gradient is in patch order (the projection's data gradient as its GEMM leaves it); dz is NHWC."""
+    R, C = z.shape
+    dz = torch.empty((R, C), dtype=dcol.dtype, device=z.device)
+    _lib.check(_lib.lib().vr_bn_bwd_patch(_p(dcol), _p(z), _p(scale), _p(shift), _p(mean), _p(rstd), _p(sg), _p(sgz), _p(dz), B, H, W,
+                                          patch, C, int(training), _dt(dcol), _dt(z), _stream()), "vr_bn_bwd_patch")
     return dz
 
 

@@ -82,6 +82,8 @@ DIRECT_CONV1 = __import__("os").environ.get("VITRES_STEM_DIRECT_CONV1", "1") != 
 # from 0.07 to 0.09 (bf16 has 3 mantissa bits fewer than the fp16 autocast gives the reference's convolutions), so the default
 # keeps fp32.
 Z_BF16 = __import__("os").environ.get("VITRES_STEM_Z_BF16", "0") != "0"
+# VITRES_STEM_PATCH_DIRECT=0: keep the unfold / fold passes around the 7 x 7 / stride-7 projection in training (measurement)
+PATCH_DIRECT = __import__("os").environ.get("VITRES_STEM_PATCH_DIRECT", "1") != "0"
 
 
 def drop_fold(model):
@@ -194,22 +196,29 @@ def embed_conv_fwd(model, x, p, cfg, keep, save):
         col3 = K.im2col3x3(a2, B, Hm, Wm, m)
         z3 = conv(col3, p["w3"], 9 * m)
     bn3 = _bn_affine(z3, pe.conv3.bn, tr)
-    a3 = K.bn_relu(z3, bn3[0], bn3[1], a1, dt)
     ps = model.patch_size // 2
-    colp = K.patch_unfold(a3, B, g, g, ps, m)
+    # PATCH_DIRECT (round 4): the last BatchNorm + ReLU (+ skip) writes the projection's patchify operand itself and the backward
+    # reads the projection's data gradient where its GEMM leaves it (vr_bn_relu_patch / vr_bn_bwd_patch / vr_conv3x3_res_patch):
+    # no patch_unfold / patch_fold pass (410 MB each way at B = 128).  Fast path only (direct convolutions, bf16).
+    pdirect = PATCH_DIRECT and direct and dt == torch.bfloat16 and Hm == g * ps and Wm == g * ps
+    if pdirect:
+        colp = K.bn_relu_patch(z3, bn3[0], bn3[1], a1, B, Hm, Wm, ps, dt)
+    else:
+        a3 = K.bn_relu(z3, bn3[0], bn3[1], a1, dt)
+        colp = K.patch_unfold(a3, B, g, g, ps, m)
     ldk = ps * ps * m
     out = torch.empty((B, N, C), dtype=torch.float32, device=x.device)
     K.gemm(colp, p["proj"].w_c, out, M=B * P, N=C, K=ldk, lda=ldk, ldb=ldk, ldc=C, bias=p["proj"].b,
            pos=p["pos"][0, T:], keep_n=keep, rows_in=P, c_map=(P, N, T))
     K.embed_cls(p["tokens"], p["pos"], out, keep, T)
     saved = (col1 if col1 is not None else ("image", x), z1, bn1, col2, z2, bn2, col3, z3, bn3, colp,
-             (B, Hm, Wm, m, g, ps, tr, direct)) if save else None
+             (B, Hm, Wm, m, g, ps, tr, direct, pdirect)) if save else None
     return out, saved
 
 
 def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
     pe, dt = model.patch_embed, cfg["dtype"]
-    col1, z1, bn1, col2, z2, bn2, col3, z3, bn3, colp, (B, Hm, Wm, m, g, ps, tr, direct) = saved
+    col1, z1, bn1, col2, z2, bn2, col3, z3, bn3, colp, (B, Hm, Wm, m, g, ps, tr, direct, pdirect) = saved
     dev = gx.device
     _, N, C = gx.shape
     T = cfg.get("tokens", 1)
@@ -231,13 +240,15 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
     Fn.on_side(wgrad_proj, gt, wtmp) if ov else wgrad_proj()
     dcolp = torch.empty((B * P, ldk), dtype=dt, device=dev)
     K.gemm(gt, p["proj"].w_c, dcolp, M=B * P, N=ldk, K=C, lda=C, ldb=ldk, ldc=ldk, b_trans=True, a_map=(P, N, T))
-    da3 = K.patch_fold(dcolp, B, g, g, ps, m)                      # d(relu(bn3) + a1)
+    da3 = dcolp if pdirect else K.patch_fold(dcolp, B, g, g, ps, m)     # d(relu(bn3) + a1); pdirect: still in patch order
 
     acc_in_place = True      # (every backward starts from a zeroed gradient arena: vit_sr_supernet._run_backward / _zero_grad_arena)
 
-    def conv_bwd(da, z, bn, col, w, conv_mod, ld, need_dx, wt=None, res=None):
+    def conv_bwd(da, z, bn, col, w, conv_mod, ld, need_dx, wt=None, res=None, da_patch=False, res_patch=False):
         gbw, gbb = gv(conv_mod.bn.weight), gv(conv_mod.bn.bias)
-        if acc_in_place:                        # the gradient arena is zero here: vr_bn_bwd's sums land where they belong
+        if da_patch:                            # (pdirect implies acc_in_place's fast path)
+            dz = K.bn_bwd_patch(da, z, bn[0], bn[1], bn[2], bn[3], gbb, gbw, tr, B, Hm, Wm, ps)
+        elif acc_in_place:                      # the gradient arena is zero here: vr_bn_bwd's sums land where they belong
             dz = K.bn_bwd(da, z, bn[0], bn[1], bn[2], bn[3], gbb, gbw, tr)
         else:
             sg = K.zero_(torch.empty((2, m), dtype=torch.float32, device=dev))
@@ -264,14 +275,17 @@ def embed_conv_bwd(model, gx, saved, p, cfg, keep, gv, gt=None):
             return None
         if wt is not None:                      # data gradient = direct convolution of dz with the flipped weights
             if res is not None:                 # (+ the gradient arriving over the skip connection, in the same pass)
+                if res_patch:
+                    return K.conv3x3_res_patch(dz, wt, res, B, Hm, Wm, m, m, ps, dt)
                 return K.conv3x3_res(dz, wt, res, B, Hm, Wm, m, m, dt)
             return K.conv3x3(dz, wt, B, Hm, Wm, m, m, dt)
         dcol = torch.empty((R, ld), dtype=dt, device=dev)
         K.gemm(dz, w, dcol, M=R, N=ld, K=m, lda=m, ldb=ld, ldc=ld, b_trans=True)
         return K.col2im3x3(dcol, B, Hm, Wm, m)
-    da2 = conv_bwd(da3, z3, bn3, col3, p["w3"], pe.conv3, 9 * m, True, p["w3t"] if direct else None)
+    da2 = conv_bwd(da3, z3, bn3, col3, p["w3"], pe.conv3, 9 * m, True, p["w3t"] if direct else None, da_patch=pdirect)
     fuse_res = direct and da3.dtype == torch.bfloat16
-    da1 = conv_bwd(da2, z2, bn2, col2, p["w2"], pe.conv2, 9 * m, True, p["w2t"] if direct else None, res=da3 if fuse_res else None)
+    da1 = conv_bwd(da2, z2, bn2, col2, p["w2"], pe.conv2, 9 * m, True, p["w2t"] if direct else None, res=da3 if fuse_res else None,
+                   res_patch=pdirect)
     if not fuse_res:
         da1 = da1 + da3                                             # residual branch (patch_conv.py:69)
     conv_bwd(da1, z1, bn1, col1, p["w1"], pe.conv1, 32, False)
