@@ -270,11 +270,10 @@ WGRAD_EARLY = _os.environ.get('VITRES_WGRAD_EARLY', '0') != '0'
 
 
 # The LAST block of a backward (the network's first block): nothing follows it on the main chain and the optimizer waits for its
-# weight-gradient group.  (Measured and dropped: launching its fc2 / fc1 / proj gradients early and qkv's alone at the end --
-# the side stream then runs one capped group behind at the end of the step, 7.66 against 7.58 ms.)
-# VITRES_LAST_UNCAP=1: the last block's weight-gradient group(s) are launched without the per-CU cap (sched bit 128): little or
-# nothing of the main chain is left to protect, and the optimizer waits for them
-LAST_UNCAP = _os.environ.get('VITRES_LAST_UNCAP', '1') != '0'
+# weight-gradient group.  VITRES_LAST_UNCAP=1 launches that group without the per-CU cap (sched bit 128): 7.42 - 7.47 against
+# 7.38 - 7.41 ms capped (it runs beside the patch-embedding weight gradient) -- off.  Also measured and dropped: its fc2 / fc1
+# (/ proj) gradients as an early group of their own (every block: +0.08 ms; last block only: +-0).
+LAST_UNCAP = _os.environ.get('VITRES_LAST_UNCAP', '0') != '0'
 LAST_BLOCK = [False]         # set by the model's backward walk around the last block
 
 
@@ -581,6 +580,10 @@ EMBED_WGRAD_SLICES = int(_os.environ.get('VITRES_EMBED_WGRAD_SLICES', '8'))
 # folds -- runs on the auxiliary stream "tail" beside the first block's weight-gradient group (they feed nothing but the
 # optimizer); 0: in line on the main stream (round 3: 0.15 ms of kernels one after another with nothing beside them).
 TAIL_AUX = _os.environ.get('VITRES_TAIL_AUX', '1') != '0'
+# VITRES_TAIL_SPLIT=1: positional-embedding sums and LayerNorm folds on the MAIN stream while the auxiliary one runs the projection's
+# weight gradient.  Measured slower (round 4): hipGraph's executor runs the step's end on two hardware queues, and a third branch
+# lands on the weight gradients' queue in front of the last two groups (they start ~330 us late, profiles/r04_step_tail_ab.txt).
+TAIL_SPLIT = _os.environ.get('VITRES_TAIL_SPLIT', '0') != '0'
 
 
 def embed0_bwd(g, saved, p, grads, cfg, keep, gt=None, wgrad=True, pos=True):

@@ -981,6 +981,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 return (None, ekeep0)
             return None
         gt = st["gt"]
+        tail_aux = False
         parts = a.get("ln_parts") if Fn.LN_COPIES > 1 else None
 
         def with_parts(grads, *pairs):
@@ -1057,17 +1058,24 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                         # nothing downstream but the optimizer: the projection's weight gradient on the auxiliary stream beside the
                         # first block's last weight gradient, the small reductions meanwhile on the main stream
                         Fn.flush_wgrads()
-                        if gt is None:
-                            gt = K.scale_mask_cast(g, None, ekeep, g.shape[1], ecfg["dtype"])
-                        Fn.on_aux("tail", lambda gt=gt: tail(True, False, gt=gt), g, gt, wt, *sv)
-                        tail(False, True, gt=gt)
+                        if Fn.TAIL_SPLIT:
+                            if gt is None:
+                                gt = K.scale_mask_cast(g, None, ekeep, g.shape[1], ecfg["dtype"])
+                            Fn.on_aux("tail", lambda gt=gt: tail(True, False, gt=gt), g, gt, wt, *sv)
+                            tail(False, True, gt=gt)
+                        else:
+                            Fn.on_aux("tail", tail, g, gt, wt, *sv)
+                            tail_aux = True
                     else:
                         tail()
                 else:
                     from .. import stem
                     stem.embed_conv_bwd(self, g, sv, ep, ecfg, ekeep, gv, gt=gt)
                     gv(self.tokens).copy_(gv(self.pos_embed)[:, 0:self.num_tokens, :])
-        Fn.flush_ln_grads()                # LayerNorm weight / bias gradients of this part: partial rows -> arena
+        if tail_aux:                       # (behind the patch-embedding weight gradient on the auxiliary stream: the graph executor
+            Fn.on_aux("tail", Fn.flush_ln_grads)   #  runs a third branch on the weight gradients' queue, IN FRONT of the last groups)
+        else:
+            Fn.flush_ln_grads()            # LayerNorm weight / bias gradients of this part: partial rows -> arena
         if stop >= len(rtape) or getattr(self, "_bwd_join_parts", True):
             Fn.join_side()                 # weight-gradient GEMMs trail on the side stream (functional.on_side); an intermediate
                                            # stop joins too unless the next part follows in the same capture (_bwd_join_parts)
