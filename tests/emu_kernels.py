@@ -447,6 +447,18 @@ def bn_bwd(da, z, scale, shift, mean, rstd, sg, sgz, training):
     return (scale * (g - sg * inv_n - zh * sgz * inv_n)).to(da.dtype)
 
 
+def bn_relu_patch(z, scale, shift, res, B, H, W, patch, out_dtype):
+    return patch_unfold(bn_relu(z, scale, shift, res, out_dtype), B, H // patch, W // patch, patch, z.shape[-1])
+
+
+def bn_bwd_patch(dcol, z, scale, shift, mean, rstd, sg, sgz, training, B, H, W, patch):
+    return bn_bwd(patch_fold(dcol, B, H // patch, W // patch, patch, z.shape[-1]), z, scale, shift, mean, rstd, sg, sgz, training)
+
+
+def conv3x3_res_patch(a, w, res_col, B, H, W, Cin, Cout, res_patch, out_dtype):
+    return conv3x3_res(a, w, patch_fold(res_col, B, H // res_patch, W // res_patch, res_patch, Cout), B, H, W, Cin, Cout, out_dtype)
+
+
 def patch_unfold(a, B, gh, gw, P, C):
     x = a.view(B, gh, P, gw, P, C).permute(0, 1, 3, 2, 4, 5)
     return x.reshape(B * gh * gw, P * P * C).clone()
@@ -458,7 +470,7 @@ def patch_fold(col, B, gh, gw, P, C):
 
 
 ALL = ["im2col3x3_image", "im2col3x3", "col2im3x3", "bn_stats", "bn_relu", "bn_bwd", "patch_unfold", "patch_fold", "gemm", "gemm_group", "cast_bf16", "cast_transpose_batch", "ln_fwd", "ln_bwd", "ln_grad_reduce", "gemm_ln_supported", "gemm_ln_fwd", "gemm_ln_bwd", "attn_fwd", "attn_bwd", "softce", "softce_train", "colsum", "scale_mask_cast",
-       "batchsum", "conv3x3", "conv1_direct", "conv1_direct_supported", "conv3x3_bias_relu", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows", "zero_ranges", "zero_", "relayout", "conv3x3_res", "conv_w_flip", "bn_finalize", "conv3x3_bias_relu_patch"]
+       "batchsum", "conv3x3", "conv1_direct", "conv1_direct_supported", "conv3x3_bias_relu", "conv3x3_supported", "conv3x3_wgrad", "conv3x3_wgrad_supported", "token_mean", "token_mean_bwd", "im2col_patch", "embed_cls", "sr_im2col", "sr_col2im", "sr_resid", "sr_resid_bwd", "mask_rows", "zero_ranges", "zero_", "relayout", "conv3x3_res", "conv_w_flip", "bn_finalize", "conv3x3_bias_relu_patch", "bn_relu_patch", "bn_bwd_patch", "conv3x3_res_patch"]
 
 
 def zero_ranges(buf, ranges):
