@@ -375,9 +375,11 @@ def main():
     if not args.no_graph:
         # N > 1: the backward is captured as two graphs so that the all-reduce of the last stage's gradients (the tail of
         # the flat arena, most of the parameters) runs on RCCL's stream while the rest of the backward is still computing
-        # VITRES_OPT_IN_GRAPH=1 (one rank, FlatAdamW): the update is captured into the graph as well (measured neutral: 9.10 vs
-        # 9.06 ms; with the arena tail updated beside the rest of the backward, VITRES_OPT_TAIL_OVERLAP=1, slower: 9.43)
-        opt_in_graph = world == 1 and args.optimizer == "flat" and os.environ.get("VITRES_OPT_IN_GRAPH", "0") != "0"
+        # one rank, FlatAdamW: the update is captured into the graph as well, the arena's tail (last stage + heads: most parameters)
+        # updated on the weight gradients' stream beside the rest of the backward by a capped launch (engine.GraphedTrainStep,
+        # VITRES_OPT_OVERLAP; round 4: 7.47 -> 7.37 ms).  VITRES_OPT_IN_GRAPH=0: replay, then optimizer.step().  With more than one
+        # rank the exchange sits between the backward and the update: step_with_sync + optimizer.step()
+        opt_in_graph = world == 1 and args.optimizer == "flat" and os.environ.get("VITRES_OPT_IN_GRAPH", "1") != "0"
         graphed = engine.GraphedTrainStep(model, crit, x, t, pt, "seq", split_for_sync=split,
                                           optimizer=opt if opt_in_graph else None)
 
@@ -612,7 +614,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": args.workload, "global_batch": B * world, "per_gpu_batch": B,
                    "example_per_arch": w["epa"], "epoch": 31, "drop_path": w["drop_path"], "parallelism": "dp%d" % world,
-                   "optimizer": "AdamW (vitres.optim.FlatAdamW: vr_adamw_flat)" if args.optimizer == "flat" else "AdamW(torch fused)", "hipgraph": graphed is not None, "host_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
+                   "optimizer": ("AdamW (vitres.optim.FlatAdamW: vr_adamw_flat%s)" % (", inside the graph, tail range beside the backward" if (graphed is not None and graphed.optimizer is not None) else "")) if args.optimizer == "flat" else "AdamW(torch fused)", "hipgraph": graphed is not None, "host_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
                    "grad_exchange": ("all-reduce of the flat fp32 gradient arena in %d ranges, each overlapped with the next backward graph" % split
                                      if (graphed is not None and graphed.graph_b is not None) else
                                      "1 all-reduce of the flat fp32 arena" if world > 1 else "none (1 rank)"),

@@ -216,6 +216,11 @@ int vr_adamw_flat(float* p, const float* g, float* m, float* v, void* shadow, fl
 int vr_adamw_flat_dev(float* p, const float* g, float* m, float* v, void* shadow, float* ema, float ema_decay,
                       const uint8_t* group_of_8, const vr_adamw_group* groups_dev, int32_t n_groups, int64_t n,
                       vr_stream_t stream);
+/* ... launched with at most max_blocks workgroups (0: the default grid): the update of a finished arena range that runs beside the
+ * rest of the backward on the weight gradients' stream (round 4). */
+int vr_adamw_flat_dev_capped(float* p, const float* g, float* m, float* v, void* shadow, float* ema, float ema_decay,
+                             const uint8_t* group_of_8, const vr_adamw_group* groups_dev, int32_t n_groups, int64_t n,
+                             int32_t max_blocks, vr_stream_t stream);
 
 
 /*

@@ -747,7 +747,8 @@ def test_single_stage_patch16_sibling_vs_reference_golden(mode, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,defer", [(torch.float32, "0"), (torch.bfloat16, "0"), (torch.bfloat16, "1"), (torch.float32, "1")])
+@pytest.mark.parametrize("dtype,defer", [(torch.float32, "0"), (torch.bfloat16, "0"), (torch.bfloat16, "1"), (torch.float32, "1"),
+                                         (torch.bfloat16, "overlap1"), (torch.bfloat16, "overlap2"), (torch.float32, "overlap2")])
 def test_optimizer_inside_the_graph_equals_step_after_the_graph(dtype, defer, monkeypatch):
     """GraphedTrainStep(optimizer=FlatAdamW): the AdamW update captured into the step's hipGraph (hyper-parameters read from device
     memory that prepare_step() rewrites per step) walks the same parameter trajectory as graph replay + optimizer.step(),
@@ -757,7 +758,13 @@ def test_optimizer_inside_the_graph_equals_step_after_the_graph(dtype, defer, mo
     from vitres import engine
     from vitres.optim import FlatAdamW
     from vitres.losses import SoftTargetCrossEntropy
+    # overlapN (round 4): the N ranges at the arena's end are updated on the weight gradients' stream as soon as the backward
+    # part that completes them is through, by a capped launch, beside the rest of the backward
+    overlap = defer[len("overlap"):] if defer.startswith("overlap") else "0"
+    defer = "0" if defer.startswith("overlap") else defer
     monkeypatch.setenv("VITRES_OPT_DEFER", defer)
+    monkeypatch.setenv("VITRES_OPT_OVERLAP", overlap)
+    monkeypatch.setenv("VITRES_OPT_OVERLAP_BLOCKS", "8")
     crit = SoftTargetCrossEntropy()
     x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1))
     runs = []

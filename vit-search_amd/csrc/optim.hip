@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 static int adamw_launch(float* p, const float* g, float* m, float* v, void* shadow, float* ema, float ema_decay,
                         const uint8_t* group_of_8, const vr_adamw_group* groups, bool on_device, int32_t n_groups, int64_t n,
-                        vr_stream_t stream) {
+                        vr_stream_t stream, int32_t max_blocks = 0) {
     if (!p || !g || !m || !v || !group_of_8 || !groups || n <= 0 || n_groups <= 0) return VR_EINVAL;
     if (n_groups > VR_ADAMW_MAX_GROUPS) return VR_EUNSUPPORTED;
     if (n % 8 || ((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) || ((uintptr_t)v & 15) ||
@@ -87,7 +87,7 @@ static int adamw_launch(float* p, const float* g, float* m, float* v, void* shad
     const long long n8 = n / 8;
     long long blocks = (n8 + 255) / 256;
     static const int knob_blocks = std::getenv("VITRES_ADAMW_BLOCKS") ? std::atoi(std::getenv("VITRES_ADAMW_BLOCKS")) : 0;
-    const long long cap = knob_blocks > 0 ? knob_blocks : 8192;
+    const long long cap = max_blocks > 0 ? max_blocks : (knob_blocks > 0 ? knob_blocks : 8192);
     if (blocks > cap) blocks = cap;
     if (on_device)
         hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow,
@@ -109,4 +109,13 @@ extern "C" int vr_adamw_flat_dev(float* p, const float* g, float* m, float* v, v
                                  const uint8_t* group_of_8, const vr_adamw_group* groups_dev, int32_t n_groups, int64_t n,
                                  vr_stream_t stream) {
     return adamw_launch(p, g, m, v, shadow, ema, ema_decay, group_of_8, groups_dev, true, n_groups, n, stream);
+}
+
+// The same launch capped at `max_blocks` resident workgroups (grid-stride): an update of a finished arena range that runs on the
+// weight gradients' stream beside the rest of the backward must not take the chip (engine.GraphedTrainStep, VITRES_OPT_OVERLAP).
+extern "C" int vr_adamw_flat_dev_capped(float* p, const float* g, float* m, float* v, void* shadow, float* ema, float ema_decay,
+                                        const uint8_t* group_of_8, const vr_adamw_group* groups_dev, int32_t n_groups, int64_t n,
+                                        int32_t max_blocks, vr_stream_t stream) {
+    if (max_blocks < 0) return VR_EINVAL;
+    return adamw_launch(p, g, m, v, shadow, ema, ema_decay, group_of_8, groups_dev, true, n_groups, n, stream, max_blocks);
 }

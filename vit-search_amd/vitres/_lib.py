@@ -71,6 +71,7 @@ SYMBOLS = {
     "vr_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "vr_adamw_flat": [c_void_p] * 6 + [c_float, c_void_p, c_void_p, c_int32, c_int64, c_void_p],
     "vr_adamw_flat_dev": [c_void_p] * 6 + [c_float, c_void_p, c_void_p, c_int32, c_int64, c_void_p],
+    "vr_adamw_flat_dev_capped": [c_void_p] * 6 + [c_float, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p],
     "vr_cast_transpose_batch": [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p],
     "vr_ln_fwd": [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_float, c_int32, c_void_p],
     "vr_ln_bwd": [c_void_p] * 13 + [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p],

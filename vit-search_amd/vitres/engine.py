@@ -367,12 +367,22 @@ class GraphedTrainStep:
             if self.optimizer is not None:
                 self.optimizer.prepare_step()                      # allocates / fills the device hyper-parameters (not captured)
                 self.optimizer._step -= 1
-                # VITRES_OPT_TAIL_OVERLAP=1: update the arena tail on the side stream beside the rest of the backward (measured
-                # slower: the 2 GB optimizer pass takes HBM bandwidth from the critical chain, 8.93 -> 9.43 ms)
-                opt_cut = model.split_plan() if os.environ.get("VITRES_OPT_TAIL_OVERLAP", "0") != "0" else None
-                if opt_cut is not None:
-                    model._bwd_split = opt_cut[0]
-                    model._bwd_join_parts = False                  # the second part follows in the same capture
+                # VITRES_OPT_OVERLAP = number of arena ranges updated EARLY (0 off, 1 (default): head + last stage, 2: + the stage
+                # before; measured round 4: 7.47 -> 7.36 - 7.39 ms with 1 or 2, profiles/r04_optimizer_overlap.txt):
+                # the backward is cut in front of the spatial reductions (model.split_plan) and the range a part completes is
+                # updated on the weight gradients' side stream -- IN ORDER with the groups there: a third branch would land on
+                # their hardware queue in front of them (round 4) -- by at most VITRES_OPT_OVERLAP_BLOCKS resident workgroups
+                # (256: one per CU; the uncapped update took the chip and cost more than it hid in rounds 1 - 3), beside the rest
+                # of the backward; what is left (the first stage + embedding) follows the backward at full width.
+                n_early = int(os.environ.get("VITRES_OPT_OVERLAP", "1"))
+                opt_cut = None
+                if n_early > 0:
+                    oc = model.split_plan(parts=max(n_early + 1, 3))
+                    oc = oc[:n_early] if isinstance(oc, list) else None
+                    if oc:
+                        opt_cut = oc
+                        model._bwd_split = [c for c, _ in oc]
+                        model._bwd_join_parts = False              # the next part follows in the same capture
             if self.defer is not None:
                 opt_cut = None
                 model._deferred_update = (self.optimizer, self.defer)
@@ -385,13 +395,17 @@ class GraphedTrainStep:
                     from . import functional as Fn
                     n_arena = model._arena["flat"].numel()
                     if opt_cut is not None and getattr(model, "_bwd_state", None) is not None:
-                        lo = opt_cut[1]
-                        if Fn.OVERLAP:
-                            Fn.on_side(lambda: self.optimizer.step_device(lo, n_arena))
-                        else:
-                            self.optimizer.step_device(lo, n_arena)
-                        model.resume_backward()
-                        self.optimizer.step_device(0, lo)
+                        cap = int(os.environ.get("VITRES_OPT_OVERLAP_BLOCKS", "256"))
+                        hi = n_arena
+                        for _, lo in opt_cut:                          # ranges complete from the arena's end backwards
+                            if Fn.OVERLAP:
+                                Fn.on_side(lambda lo=lo, hi=hi: self.optimizer.step_device(lo, hi, max_blocks=cap))
+                            else:
+                                self.optimizer.step_device(lo, hi)
+                            hi = lo
+                            if getattr(model, "_bwd_state", None) is not None:
+                                model.resume_backward()
+                        self.optimizer.step_device(0, hi)
                     else:
                         self.optimizer.step_device(0, n_arena)
             while getattr(model, "_bwd_state", None) is not None:

@@ -117,8 +117,9 @@ class FlatAdamW(torch.optim.Optimizer):
         self._hp_dev.copy_(host, non_blocking=True)
 
     @torch.no_grad()
-    def step_device(self, lo=0, hi=None):
-        """AdamW over the arena range [lo, hi) (multiples of 8) with the hyper-parameters prepare_step() uploaded: capturable."""
+    def step_device(self, lo=0, hi=None, max_blocks=0):
+        """AdamW over the arena range [lo, hi) (multiples of 8) with the hyper-parameters prepare_step() uploaded: capturable.
+        max_blocks > 0: launched with at most that many workgroups (an update that runs beside other work)."""
         a = self._bind()
         g = a.get("gcur")
         if g is None or getattr(self, "_hp_dev", None) is None:
@@ -133,10 +134,10 @@ class FlatAdamW(torch.optim.Optimizer):
 
         def at(t, esz):
             return None if t is None else t.data_ptr() + lo * esz
-        _lib.check(_lib.lib().vr_adamw_flat_dev(at(a["flat"], 4), at(g, 4), at(st["m"], 4), at(st["v"], 4), at(shadow, 2),
-                                                at(st["ema"], 4), float(self.ema_decay or 0.0), st["gid"].data_ptr() + lo // 8,
-                                                _p(self._hp_dev), len(self.param_groups), hi - lo, _stream()),
-                   "vr_adamw_flat_dev")
+        _lib.check(_lib.lib().vr_adamw_flat_dev_capped(at(a["flat"], 4), at(g, 4), at(st["m"], 4), at(st["v"], 4), at(shadow, 2),
+                                                       at(st["ema"], 4), float(self.ema_decay or 0.0), st["gid"].data_ptr() + lo // 8,
+                                                       _p(self._hp_dev), len(self.param_groups), hi - lo, int(max_blocks), _stream()),
+                   "vr_adamw_flat_dev_capped")
         if shadow is not None:
             a["shadow_ok"] = True
 
