@@ -10,7 +10,22 @@ dis = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
 scols = [r[1] for r in cur.execute("pragma table_info(%s)" % sym)]
 namecol = "display_name" if "display_name" in scols else "kernel_name"
 rows = list(cur.execute("select s.%s, d.start, d.end, d.queue_id from %s d join %s s on d.kernel_id = s.id order by d.start" % (namecol, dis, sym)))
-marks = [r[1] for r in rows if "adamw_kernel" in r[0]]
+
+
+def step_marks(rows):
+    """Indices of the adamw dispatch that CLOSES a step.  With the optimizer inside the graph (round 4) a step has an early, capped
+    update of the arena's tail beside the backward as well: that one is followed at once by backward kernels, the closing one by
+    the next step's gather / copies."""
+    ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[0]]
+    out = []
+    for i in ad:
+        nxt = [r[0] for r in rows[i + 1:i + 4]]
+        if any(("nt_kernel" in n or "tn_group_kernel" in n or "ntln_kernel" in n or "vr_attn_mfma" in n or "ln_bwd" in n) for n in nxt):
+            continue
+        out.append(i)
+    return out if len(out) >= 3 else ad
+
+marks = [rows[i][1] for i in step_marks(rows)]
 t0, t1 = marks[-2], marks[-1]
 step = [r for r in rows if t0 <= r[1] < t1]
 print("step span %.3f ms, %d kernels" % ((t1 - t0) / 1e6, len(step)))

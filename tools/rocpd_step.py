@@ -10,7 +10,22 @@ dis = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
 scols = [r[1] for r in cur.execute("pragma table_info(%s)" % sym)]
 namecol = "display_name" if "display_name" in scols else "kernel_name"
 rows = list(cur.execute("select s.%s, d.start, d.end, d.queue_id from %s d join %s s on d.kernel_id = s.id order by d.start" % (namecol, dis, sym)))
-ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[0]]
+
+
+def step_marks(rows):
+    """Indices of the adamw dispatch that CLOSES a step.  With the optimizer inside the graph (round 4) a step has an early, capped
+    update of the arena's tail beside the backward as well: that one is followed at once by backward kernels, the closing one by
+    the next step's gather / copies."""
+    ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[0]]
+    out = []
+    for i in ad:
+        nxt = [r[0] for r in rows[i + 1:i + 4]]
+        if any(("nt_kernel" in n or "tn_group_kernel" in n or "ntln_kernel" in n or "vr_attn_mfma" in n or "ln_bwd" in n) for n in nxt):
+            continue
+        out.append(i)
+    return out if len(out) >= 3 else ad
+
+ad = step_marks(rows)
 a, b = ad[-kth - 1], ad[-kth]
 step = rows[a + 1:b + 1]
 t0 = step[0][1]
