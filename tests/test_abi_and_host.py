@@ -168,3 +168,49 @@ def test_cosine_scheduler_known_answers():
     s2.load_state_dict(sd)
     s2.step(60)
     assert abs(opt2.param_groups[1]["lr"] - want[60]) < 1e-12
+
+
+def test_sync_ranges_tile_the_gradient_arena_for_every_shipped_network():
+    """the arena ranges of `split_for_sync=3` (engine.GraphedTrainStep: range k is all-reduced after backward
+    part k) tile the flat gradient arena exactly -- no gap, no overlap, every parameter in exactly one range -- for the five
+    shipped networks (reference main.py:366-367: DDP reduces every gradient once)."""
+    import importlib.util
+    import vitres
+    from vitres import supernet_config
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    nets = [("flexible_vit_sr_patch14_224_patch_output", dict(network_def=bench.REF_TINY_DEF))]
+    for space in ("sr_tiny", "sr_tiny_mh", "sr_small", "sr_small_mh"):
+        sp = getattr(supernet_config, space)
+        nets.append(("flexible_vit_sr_patch14_224_patch_output_supernet",
+                     dict(network_def=sp.network_def, num_channels_to_keep=sp.num_channels_to_keep, example_per_arch=8,
+                          num_warmup_epochs=30)))
+    for name, kw in nets:
+        model = vitres.create_model(name, num_classes=1000, **kw)
+        model._ensure_arena(torch.device("cpu"))
+        a = model._arena
+        n = a["flat"].numel()
+        cuts = model.split_plan(parts=3)
+        assert cuts and len(cuts) == 2, (name, cuts)
+        starts = [s for _, s in cuts]                       # descending: range k = [starts[k], starts[k - 1])
+        assert n > starts[0] > starts[1] > 0
+        ranges = [(starts[0], n), (starts[1], starts[0]), (0, starts[1])]
+        assert sorted(ranges)[0][0] == 0 and sorted(ranges)[-1][1] == n
+        for (lo0, hi0), (lo1, hi1) in zip(sorted(ranges)[:-1], sorted(ranges)[1:]):
+            assert hi0 == lo1                               # no gap, no overlap
+        covered = 0
+        for p, (off, cnt) in zip(a["params"], a["offsets"]):
+            inside = [lo <= off and off + p.numel() <= hi for lo, hi in ranges]
+            assert sum(inside) == 1, (name, off)            # no parameter straddles a cut
+            covered += p.numel()
+        assert covered == sum(p.numel() for p in model.parameters()) <= n
+        # the blocks behind a cut are exactly the parameters of its range
+        blocks = list(model.blocks)
+        for (cut, start) in cuts:
+            for m in blocks[cut:]:
+                for p in m.parameters():
+                    assert a["offsets"][a["index"][id(p)]][0] >= start
+            for m in blocks[:cut]:
+                for p in m.parameters():
+                    assert a["offsets"][a["index"][id(p)]][0] < start

@@ -748,7 +748,8 @@ def test_single_stage_patch16_sibling_vs_reference_golden(mode, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,defer", [(torch.float32, "0"), (torch.bfloat16, "0"), (torch.bfloat16, "1"), (torch.float32, "1"),
-                                         (torch.bfloat16, "overlap1"), (torch.bfloat16, "overlap2"), (torch.float32, "overlap2")])
+                                         (torch.bfloat16, "overlap1"), (torch.bfloat16, "overlap2"), (torch.float32, "overlap2"),
+                                         (torch.float32, "overlap2s2"), (torch.bfloat16, "overlap2s2")])
 def test_optimizer_inside_the_graph_equals_step_after_the_graph(dtype, defer, monkeypatch):
     """GraphedTrainStep(optimizer=FlatAdamW): the AdamW update captured into the step's hipGraph (hyper-parameters read from device
     memory that prepare_step() rewrites per step) walks the same parameter trajectory as graph replay + optimizer.step(),
@@ -760,6 +761,13 @@ def test_optimizer_inside_the_graph_equals_step_after_the_graph(dtype, defer, mo
     from vitres.losses import SoftTargetCrossEntropy
     # overlapN (round 4): the N ranges at the arena's end are updated on the weight gradients' stream as soon as the backward
     # part that completes them is through, by a capped launch, beside the rest of the backward
+    # ...s2: two side streams -- the weight-gradient groups go round-robin over them, the early update has to be
+    # ordered behind BOTH (functional.on_side(after_all_sides=True))
+    from vitres import functional as Fn
+    if defer.endswith("s2"):
+        defer = defer[:-2]
+        monkeypatch.setattr(Fn, "N_SIDE", 2)
+        monkeypatch.setattr(Fn, "_side_streams", {})
     overlap = defer[len("overlap"):] if defer.startswith("overlap") else "0"
     defer = "0" if defer.startswith("overlap") else defer
     monkeypatch.setenv("VITRES_OPT_DEFER", defer)

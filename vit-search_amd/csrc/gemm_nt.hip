@@ -65,7 +65,9 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     constexpr int A_BYTES = BM * BK * 2, AP = MI;     // A slice bytes, LDS-DMA pieces of A per wave
     constexpr int B_BYTES = BN * BK * 2, BP = NJ;     // same for the weight slice
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    __shared__ __attribute__((aligned(1024))) char smem[STAGES * STAGE_BYTES];   // ring of [A slice][B slice]; epilogue: 4 x 4 KB
+    constexpr int NBUF = STAGES > 10 ? STAGES - 10 : STAGES;      // STAGES = 10 + R: ring of R buffers, R - 1 slices in flight
+    constexpr bool RING = STAGES == 3 || STAGES > 10;
+    __shared__ __attribute__((aligned(1024))) char smem[NBUF * STAGE_BYTES];   // ring of [A slice][B slice]; epilogue: 4 x 4 KB
     __shared__ RowMeta rowmeta[BM];
     const int t = threadIdx.x, lane = t & 63;
     NT_STAMP(0);
@@ -298,24 +300,35 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
             }
         }
     } else {
+        static_assert(RING && NBUF >= 3 && NBUF <= 5, "ring depth");
         fill_rowmeta();              // its global loads complete (the compiler waits for them) before any LDS-DMA is issued
-        int c0 = live.take();
-        int c1 = live.take();
-        if (c0 < ntiles) issue(c0, 0);
-        if (c1 < ntiles) issue(c1, 1);
+        // ring of NBUF buffers: slice c[0] is multiplied while c[1] .. c[NBUF - 2] are in flight (counted s_waitcnt vmcnt -- the
+        // LDS-DMA pieces retire in issue order -- and a raw s_barrier: __syncthreads would drain the queue)
+        int c[NBUF - 1];
+#pragma unroll
+        for (int q = 0; q < NBUF - 1; ++q) {
+            c[q] = live.take();
+            if (c[q] < ntiles) issue(c[q], q);
+        }
         int buf = 0;
-        while (c0 < ntiles) {
-            // slice c0 has landed when at most the pieces of the younger slice c1 are outstanding
-            if (c1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");
+        while (c[0] < ntiles) {
+            // slice c[0] has landed when at most the pieces of the younger slices are outstanding
+            int younger = 0;
+#pragma unroll
+            for (int q = 1; q < NBUF - 1; ++q) younger += c[q] < ntiles ? 1 : 0;
+            if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (AP + BP)) : "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AP + BP)) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();         // every wave has also finished reading the buffer re-filled next
-            const int c2 = live.take();
-            const int nb = buf == 0 ? 2 : buf - 1;      // (buf + 2) % 3
-            if (c2 < ntiles) issue(c2, nb);
+            const int cn = live.take();
+            const int nb = buf == 0 ? NBUF - 1 : buf - 1;      // (buf + NBUF - 1) % NBUF: the buffer multiplied last round
+            if (cn < ntiles) issue(cn, nb);
             compute(buf);
-            c0 = c1;
-            c1 = c2;
-            buf = buf == 2 ? 0 : buf + 1;
+#pragma unroll
+            for (int q = 0; q < NBUF - 2; ++q) c[q] = c[q + 1];
+            c[NBUF - 2] = cn;
+            buf = buf == NBUF - 1 ? 0 : buf + 1;
         }
         __syncthreads();
     }
@@ -459,6 +472,16 @@ template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t 
         if ((a.sched & 64) && S == 0 && t128 <= 2048 && a.K >= 2 * BK &&
             (long long)SPLIT_TICKET_BYTES + t128 * 2 * (128LL * 128 * 4) <= a.ws_bytes) { S = 2; stages = (a.sched & 1) ? 2 : 1; }   // forced (tests)
         if (S >= 2 && (stages == 2 ? launch_split<TO, EPI, 2>(a, stream, S) : launch_split<TO, EPI, 1>(a, stream, S))) return;
+    }
+    // VITRES_NT_RING (round 5 experiment): ring-pipelined tiles for grids that leave a CU one or two workgroups and walk >= 8 slices
+    //   1: 64 x 128 tiles, ring of 3 (72 KB, two per CU) where the pair form runs today;  2: 128 x 128, ring of 3 (96 KB, one per CU);
+    //   3: 128 x 128, ring of 4 (128 KB);  4: 64 x 128, ring of 4 (96 KB)
+    static const int knob_ring = std::getenv("VITRES_NT_RING") ? std::atoi(std::getenv("VITRES_NT_RING")) : 0;
+    if (knob_ring && !knob && t128 < 2LL * n_cu && a.K >= 8 * BK) {
+        if (knob_ring == 1 && tile == 2) return launch2<TO, EPI, 2, 4, 3>(a, stream, fast);
+        if (knob_ring == 4 && tile == 2) return launch2<TO, EPI, 2, 4, 14>(a, stream, fast);
+        if (knob_ring == 2) return launch2<TO, EPI, 4, 4, 13>(a, stream, fast);
+        if (knob_ring == 3) return launch2<TO, EPI, 4, 4, 14>(a, stream, fast);
     }
     if (tile == 1) launch2<TO, EPI, 4, 4>(a, stream, fast);
     else if (tile == 2) {

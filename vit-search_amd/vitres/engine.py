@@ -146,9 +146,11 @@ class GradSync:
 
     def finish(self, works, average=True):
         """Wait for all_reduce_range handles and apply the 1/world averaging (average=False leaves the SUM: an optimizer
-        that scales gradients itself -- vitres.optim.FlatAdamW.grad_scale -- saves the extra pass over the arena)."""
+        that scales gradients itself -- vitres.optim.FlatAdamW.grad_scale -- saves the extra pass over the arena).  The ranges of
+        `works` must cover every gradient the optimizer consumes (bf16 wire: only the exchanged ranges are copied back / averaged)."""
         if self.world == 1:
             return
+        works = list(works)                    # (a generator would be exhausted by the waits below)
         for w in works:
             if w is not None:
                 w.wait()
@@ -399,7 +401,7 @@ class GraphedTrainStep:
                         hi = n_arena
                         for _, lo in opt_cut:                          # ranges complete from the arena's end backwards
                             if Fn.OVERLAP:
-                                Fn.on_side(lambda lo=lo, hi=hi: self.optimizer.step_device(lo, hi, max_blocks=cap))
+                                Fn.on_side(lambda lo=lo, hi=hi: self.optimizer.step_device(lo, hi, max_blocks=cap), after_all_sides=True)
                             else:
                                 self.optimizer.step_device(lo, hi)
                             hi = lo

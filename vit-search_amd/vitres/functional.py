@@ -110,35 +110,49 @@ def _run_side(side, fn):
         fn()
 
 
+def _wait_other_sides(side):
+    # (N_SIDE > 1 only) work that consumes what EVERY side stream produced -- the in-graph AdamW range update reads gradients whose
+    # weight-gradient groups went round-robin over the side streams -- is ordered behind all of them, not just its own stream
+    for other in _side_streams.get(side.device, ()):
+        if other is not side:
+            side.wait_stream(other)
+
+
 def flush_side():
     while _deferred:
-        ev, side, fn = _deferred.pop(0)
+        ev, side, fn, after_all = _deferred.pop(0)
         side.wait_event(ev)
+        if after_all:
+            _wait_other_sides(side)
         _run_side(side, fn)
 
 
-def on_side(fn, *keepalive, defer=True):
+def on_side(fn, *keepalive, defer=True, after_all_sides=False):
     """Run fn() on a side stream after everything queued so far on the current stream; the tensors it reads are kept
     alive (so the caching allocator cannot hand them out again) until join_side().  defer=False: launch at once (callers whose
-    fn() must have RUN on the host when on_side returns, or with no main kernel following before the join)."""
+    fn() must have RUN on the host when on_side returns, or with no main kernel following before the join).
+    after_all_sides: fn() also waits for everything already issued on the OTHER side streams (VITRES_SIDE_STREAMS > 1)."""
     main = torch.cuda.current_stream()
     sides = _sides(main.device)
     side = sides[_rr[0] % len(sides)]
     _rr[0] += 1
     if SIDE_DEFER and defer:
         flush_side()                       # the previous one: at least one main kernel has been enqueued since
-        _deferred.append((main.record_event(), side, fn))
+        _deferred.append((main.record_event(), side, fn, after_all_sides))
     else:
         flush_side()
         side.wait_stream(main)
+        if after_all_sides:
+            _wait_other_sides(side)
         _run_side(side, fn)
     _pending.extend(keepalive)
 
 
 # Auxiliary streams (round 4): named branches besides the weight-gradient side stream -- "tail": the patch-embedding weight
 # gradient and the small reductions that close a backward run beside the first block's weight-gradient group instead of behind
-# one another on the main queue.  (Measured and dropped: AdamW over finished arena ranges on an "opt" stream beside the rest of
-# the backward -- 7.52 -> 7.98 ms however the update was throttled, DESIGN.md section 7c.)
+# one another on the main queue.  (Measured and dropped: AdamW over finished arena ranges on an "opt" stream OF ITS OWN beside the
+# rest of the backward -- 7.52 -> 7.98 ms however the update was throttled.  What ships is the same update issued IN ORDER on the
+# weight gradients' side stream: engine.GraphedTrainStep, VITRES_OPT_OVERLAP, 7.47 -> 7.37 ms.)
 _aux_streams = {}
 _aux_used = set()
 _AUX_ROLE = {}           # stream-K workspace role of each auxiliary stream (kernels.ws_role)
