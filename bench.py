@@ -448,6 +448,9 @@ def main():
     if step_probe:
         print("step probe (ms, from the first warm-up step): " + " ".join("%.2f" % a.elapsed_time(b) for a, b in step_probe),
               file=sys.stderr)
+    if graphed is not None and getattr(graphed, "_gap_probe", None):
+        print("gap probe 2 (GPU ms: plan copy | gather + target copies | graph replay | between calls): %s" % graphed.gap_report(),
+              file=sys.stderr)
     if gap_probe:
         inside = sum(a.elapsed_time(b) for a, b in gap_probe) / len(gap_probe)
         between = sum(gap_probe[i][1].elapsed_time(gap_probe[i + 1][0]) for i in range(len(gap_probe) - 1)) / max(len(gap_probe) - 1, 1)

@@ -1135,3 +1135,72 @@ def test_fused_mlp_forward(B, N, C, F, masked, mapped):
     assert relerr(out, ref) < 1e-4
     if mapped:
         assert torch.equal(out[:, 0], x[:, 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K_,rows_in", [(2176, 1024, 3072, 17), (8320, 512, 1536, 65), (1300, 320, 640, 65), (2176, 768, 1024, 17),
+                                            (4 * 257, 1536, 512, 257), (33 * 256, 256, 768, 256), (5 * 257, 776, 256, 257)])
+@pytest.mark.parametrize("variant", ["fwd", "gelu", "res", "dgrad", "dmul"])
+def test_gemm_lean_loop(M, N, K_, rows_in, variant):
+    """gemm_ntk.hip (round 5: buffer-addressed LDS-DMA, live-slice bit mask, 1 / 2 / 3 slices in flight) in every tile x depth
+    combination (sched bits 0x1800 / 0x600) against the emulation and against gemm_nt.hip's kernel (sched 0x100): prefix masks on
+    both sides, ragged row and column tiles, launch after launch beside a busy second stream."""
+    a, b, out, kw = _wide_case(M, N, K_, variant, rows_in)
+    ref = E.gemm(a, b, out.clone(), **{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+    kw_d = {k: to(v) for k, v in kw.items()}
+    ad, bd = a.to(DEV), b.to(DEV)
+    t_ = 1e-4 if out.dtype == torch.float32 else 8e-3
+    old = K.gemm(ad, bd, torch.full_like(out, float("nan")).to(DEV), sched=0x100, **kw_d).clone()
+    assert relerr(old, ref) < t_
+    side = torch.cuda.Stream()
+    busy = torch.randn(4096, 4096, device=DEV)
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            busy = torch.tanh(busy @ busy * 1e-2)
+    for tile in (1, 2, 3):
+        for nbuf in (1, 2, 3):
+            sched = (tile << 11) | (nbuf << 9)
+            for rep in range(2):
+                real = K.gemm(ad, bd, torch.full_like(out, float("nan")).to(DEV), sched=sched, **kw_d)
+                torch.cuda.synchronize()
+                assert relerr(real, ref) < t_, (variant, tile, nbuf, rep, relerr(real, ref))
+                # same products, same summation order per output as the old kernel of the same tile would use: tight agreement
+                assert relerr(real, old) < (2e-5 if out.dtype == torch.float32 else 8e-3)
+            if variant == "gelu":
+                ref2 = torch.zeros(M, N, dtype=torch.bfloat16)
+                kw2 = dict(kw); kw2["out2"] = ref2
+                E.gemm(a, b, out.clone(), **kw2)
+                assert relerr(kw_d["out2"], ref2) < t_
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbuf", [1, 2, 3])
+def test_gemm_lean_loop_periodic_masks_and_rowmaps(nbuf):
+    """Lean-loop kernel with the per-head (periodic) k masks of the attention projection's data gradient -- live slices that are not
+    a prefix, slice 0 dead for some tiles -- fully masked samples, and mapped token rows (cls / patch rows of the embedding)."""
+    B, Nt, H, D, C = 6, 65, 4, 64, 256
+    HD, M = H * D, B * Nt
+    sched = (1 << 11) | (nbuf << 9)
+    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+    ek = torch.tensor([256, 160, 256, 64, 192, 160], dtype=torch.int32)
+    for ak in (torch.tensor([256, 128, 64, 192, 128, 256], dtype=torch.int32), torch.tensor([0, 0, 0, 0, 0, 0], dtype=torch.int32),
+               torch.tensor([64, 64, 64, 64, 64, 64], dtype=torch.int32)):
+        cols = torch.arange(3 * HD) % HD
+        dqkv = (rnd(M, 3 * HD, seed=4) * (cols[None, :] < ak.long().repeat_interleave(Nt)[:, None])).to(torch.bfloat16)
+        w = rnd(3 * HD, C, seed=2, scale=C ** -0.5).to(torch.bfloat16)
+        kw = dict(M=M, N=C, K=3 * HD, lda=3 * HD, ldb=C, ldc=C, b_trans=True, rows_in=Nt, keep_k=ak, k_period=HD, keep_n=ek)
+        ref = E.gemm(dqkv, w, torch.zeros(M, C, dtype=torch.bfloat16), **kw)
+        real = K.gemm(dqkv.to(DEV), w.to(DEV), torch.full((M, C), 7.0, dtype=torch.bfloat16, device=DEV), sched=sched,
+                      **{k: to(v) for k, v in kw.items()})
+        assert relerr(real, ref) < tol(torch.bfloat16)
+    # periodic masks whose first slice is dead: period 128, keep 0 in the first half is impossible for a prefix -- use a row map
+    # instead: rows gathered through a_map / scattered through c_map
+    rpi, rps = 64, 65                                                    # patch rows of [B, 65, C]: skip the cls row of every sample
+    Mp = B * rpi
+    x = rnd(B * rps, C, seed=9).to(torch.bfloat16)
+    w2 = rnd(512, C, seed=10, scale=C ** -0.5).to(torch.bfloat16)
+    kw = dict(M=Mp, N=512, K=C, lda=C, ldb=C, ldc=512, bias=rnd(512, seed=11), a_map=(rpi, rps, 1), rows_in=rpi)
+    ref = E.gemm(x, w2, torch.zeros(Mp, 512, dtype=torch.bfloat16), **kw)
+    real = K.gemm(x.to(DEV), w2.to(DEV), torch.zeros(Mp, 512, dtype=torch.bfloat16, device=DEV), sched=sched, **{k: to(v) for k, v in kw.items()})
+    assert relerr(real, ref) < tol(torch.bfloat16)

@@ -67,6 +67,8 @@ STAGES = {
            (32896, 256, 768, "dgrad"), (32896, 768, 256, "dmul")],
     # 256 tiles of 256 x 256 (1024 of 128 x 128): one / four per CU exactly -- time = fixed cost per tile + slices x slope
     "probe": [(8192, 2048, k, kind) for kind in ("fwd", "res", "gelu", "dgrad") for k in (128, 256, 512, 1024, 2048, 4096)],
+    # one 128 x 128 tile per CU (two 64 x 128): time = fixed cost + slices x slope
+    "kprobe": [(8192, 512, k, kind) for kind in ("fwd", "res", "dgrad") for k in (128, 256, 512, 1024, 2048, 4096)],
     "skp": [(8320, 512, 1536, "res"), (8320, 512, 1536, "dgrad"), (2176, 1024, 3072, "res"), (2176, 1024, 2304, "dgrad"), (8320, 512, 512, "res")],
     "small": [(4160, 1920, 640, "fwd"), (4160, 640, 1920, "res"), (1088, 3840, 1280, "gelu"), (1088, 1280, 3840, "res"),
               (16448, 960, 320, "gelu"), (16448, 320, 960, "res")],

@@ -505,10 +505,13 @@ template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t 
 // experimental/gemm_ntw.hip (only in `make EXPERIMENTAL=1` builds: a weak reference, null in the default library)
 __attribute__((weak)) bool vr_gemm_ntw_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu, int mode);
 
+bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);      // gemm_ntk.hip: the lean-loop kernels
+
 // Called by vr_gemm after validation.  Returns false when the form is not covered here.
 bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_nt;
     if (a.in_dtype != VR_BF16 || a.a_trans || a.atomic || a.split_k > 1 || a.bias_grad) return false;
+    if (vr_gemm_ntk_launch(a, stream, n_cu)) return true;
     const bool of32 = a.out_dtype == VR_F32;
     if (a.b_trans) {
         // B = W [K][N] row-major (the forward's weight): plain data gradients with a bf16 result (optionally times gelu'), 16-byte

@@ -1,0 +1,397 @@
+// bf16 forward / data-gradient GEMM, lean K loop:  C[M,N] = epilogue(A[M,K] * B[N,K]^T)   (or B = W [K][N] k-major, b_trans)
+//
+// Same tiles, LDS images and epilogue as gemm_nt.hip (reference nets/supernet_blocks.py:37-52,102-119: every nn.Linear of a
+// transformer block and its data gradient) -- what changes is the instruction stream around the MFMAs.  Round-5 counters on the
+// stage 2 / 3 GEMMs (profiles/r05_gemm_issue_bound.txt): L2 hit rate 73 %, 18 read requests in flight per CU on average, TA busy
+// 12 %, yet every 64-wide slice cost 1.4 - 1.9 us whether one, two or three slices were in flight -- and the waves spent 41 % of
+// their cycles ISSUING: gemm_nt.hip's loop is ~280 instructions per slice and wave around 32 MFMAs (64-bit address arithmetic
+// and zero-page selects per LDS-DMA piece, the live-slice cursor's branches, accumulator copies around conditional blocks).
+// With one or two workgroups per CU (the grids of stages 2 and 3) nothing overlaps that serial stream.  Here:
+//
+//   * operand slices move with `buffer_load_dwordx4 ... lds`: the per-lane byte offset of a piece (row, swizzled k-chunk) is a
+//     32-bit VGPR computed ONCE per tile, a slice advances the scalar offset -- one s_mov m0 + one load per piece, no vector
+//     arithmetic in the loop.  Rows past the matrix edge are clamped (their products reach no stored output); column chunks of a
+//     k-major weight slice past the row's end get an offset beyond the descriptor's range and read as zeros;
+//   * the slices with kept k are one 64-bit mask, made once per tile (prefix masks: a count; periodic masks: one scalar pass),
+//     walked with s_ff1: no per-slice modulo, no cursor state;
+//   * NBUF = 1: one slice buffer, several workgroups per CU overlap each other (the first stage's grids);
+//     NBUF = 2 / 3: slice i + 1 (and i + 2) are in flight while slice i is multiplied -- one s_barrier per slice, counted vmcnt.
+//
+// Covered: FAST epilogue forms (N, ldc, ldu, n_period multiples of 8), K a multiple of 64 and at most 4096, FEAT 0 - 3 (no
+// positional embedding), operands below 4 GB.  Everything else stays with gemm_nt.hip / gemm.hip (vr_gemm_ntk_launch returns false).
+#include <cstdlib>
+
+#include "gemm_nt_parts.h"
+
+namespace vr_gemm_nt {
+
+constexpr int KTHR = 256;
+typedef __attribute__((address_space(3))) char lds_char_k;
+typedef int v4i_k __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (gfx950): base, stride 0, num_records bytes, 32-bit data format
+__device__ __forceinline__ v4i_k make_rsrc(const void* ptr, unsigned num_records) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)ptr;
+    v4i_k r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)num_records);
+    r.w = 0x00020000;
+    return r;
+}
+// one LDS-DMA piece: 64 lanes x 16 bytes from descriptor + voff (per lane) + soff (scalar) to LDS bytes [lds, lds + 1024)
+__device__ __forceinline__ void dma16(unsigned lds, unsigned voff, v4i_k rsrc, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+__device__ __forceinline__ int interleave_groups32(int p, int n, int G) {      // gemm_shared.h interleave_groups in 32-bit arithmetic
+    if (G <= 1 || n < 2 * G) return p;
+    const int t = n / G;
+    if (p < t * G) {
+        const int g = p % G, r = p / G;
+        return (int)((unsigned)g * (unsigned)n / (unsigned)G) + r;
+    }
+    int k = p - t * G;
+    for (int g = 0; g < G; ++g) {
+        const int s0 = (int)((unsigned)g * (unsigned)n / (unsigned)G), s1 = (int)((unsigned)(g + 1) * (unsigned)n / (unsigned)G);
+        if (s1 - s0 > t) {
+            if (k == 0) return s0 + t;
+            --k;
+        }
+    }
+    return p;
+}
+
+// largest keep[s], s in [s_lo, s_hi]: the lanes of a wave load in parallel, the scalar unit folds the (few) values
+__device__ __forceinline__ int max_keep_wave(const int* keep, int s_lo, int s_hi, int lane) {
+    int mk = 0;
+    for (int s0 = s_lo; s0 <= s_hi; s0 += 64) {
+        const int s = s0 + lane;
+        const int v = s <= s_hi ? keep[s] : 0;
+        const int cnt = min(64, s_hi - s0 + 1);
+        for (int i = 0; i < cnt; ++i) mk = max(mk, __builtin_amdgcn_readlane(v, i));
+    }
+    return mk;
+}
+
+template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM>
+__global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gemm_args p) {
+    constexpr int BM = 32 * MI, WROWS = 16 * MI;
+    constexpr int BN = 32 * NJ, WCOLS = 16 * NJ;
+    constexpr int A_BYTES = BM * BK * 2, AP = MI;
+    constexpr int B_BYTES = BN * BK * 2, BP = NJ;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int META_OFF = NBUF * STAGE_BYTES;
+    static_assert(META_OFF >= 4 * 4096, "epilogue park area");
+    // ONE shared array (slice ring | row metadata): a second __shared__ object makes hipcc drain the DMA queue before LDS reads
+    __shared__ __attribute__((aligned(1024))) char smem[META_OFF + BM * (int)sizeof(RowMeta)];
+    RowMeta* rowmeta = reinterpret_cast<RowMeta*>(smem + META_OFF);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int total = tiles_n * tiles_m;
+    int tile = blockIdx.x;
+    if (total >= 16) {       // workgroup ids go round-robin to the 8 XCDs: an XCD owns one contiguous run of the n-fastest order
+        const int xq = total >> 3, xr = total & 7, x = tile & 7;
+        tile = x * xq + min(x, xr) + (tile >> 3);
+    }
+    const int tn = tile % tiles_n, tm = interleave_groups32(tile / tiles_n, tiles_m, p.m_groups);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-lane byte offsets of this wave's LDS-DMA pieces (constant over the K loop) ----
+    unsigned voffA[AP], voffB[BP];
+    {
+        const RowMap amap = {p.a_map.rpi, p.a_map.rps, p.a_map.off};
+        const int ra = wave * (8 * AP) + (lane >> 3);
+#pragma unroll
+        for (int h = 0; h < AP; ++h) {
+            const int r = ra + 8 * h;
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            const int ma = min(m0 + r, p.M - 1);
+            voffA[h] = (unsigned)((map_row(amap, ma) * (long long)p.lda + c * 8) * 2);
+        }
+        if constexpr (BKM) {
+            typedef KMajor<BN> G;
+#pragma unroll
+            for (int h = 0; h < BP; ++h) {
+                const int tk = (wave * BP + h) * G::TPP + lane / G::SLOTS;
+                const int c = (lane % G::SLOTS) ^ G::swz(tk);
+                const bool bok = n0 + c * 8 + 8 <= p.ldb;          // chunks past the row's readable width read as zeros
+                voffB[h] = bok ? (unsigned)((tk * p.ldb + n0 + c * 8) * 2) : 0xfffffff0u;
+            }
+        } else {
+            const RowMap bmap = {p.b_map.rpi, p.b_map.rps, p.b_map.off};
+            const int rb = wave * (8 * BP) + (lane >> 3);
+#pragma unroll
+            for (int h = 0; h < BP; ++h) {
+                const int r = rb + 8 * h;
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                const int nb = min(n0 + r, p.N - 1);
+                voffB[h] = (unsigned)((map_row(bmap, nb) * (long long)p.ldb + c * 8) * 2);
+            }
+        }
+    }
+    // descriptors: rows are clamped, so every A / row-major B address is inside the operand; the k-major weight's descriptor ends
+    // with the matrix (K rows of ldb): offsets >= its size -- the 0xfffffff0 above -- return zeros without an access
+    const v4i_k rsA = make_rsrc(p.A, 0xffffff00u);
+    const v4i_k rsB = make_rsrc(p.B, BKM ? (unsigned)((long long)p.K * p.ldb * 2) : 0xffffff00u);
+    const int stepB = BKM ? BK * p.ldb * 2 : BK * 2;               // bytes a slice advances the weight operand by
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_char_k*)smem;  // LDS byte address of the ring
+
+    // The loads are inline asm (M0 = LDS destination of the piece, written in the same statement): hipcc waits vmcnt(0) in front
+    // of the first LDS read that follows a `raw_ptr_buffer_load_lds` BUILTIN -- the slices in flight would be drained every
+    // round.  Hidden from its bookkeeping they are counted by hand below (s_waitcnt vmcnt(N) + s_barrier before any read).
+    auto issue = [&](int kt, int buf) {
+        const int sa = kt * (BK * 2), sb = kt * stepB;
+        const unsigned dst = lds0 + buf * STAGE_BYTES + wave * (AP * 1024);
+        const unsigned dstb = lds0 + buf * STAGE_BYTES + A_BYTES + wave * (BP * 1024);
+#pragma unroll
+        for (int h = 0; h < AP; ++h) dma16(dst + h * 1024, voffA[h], rsA, sa);
+#pragma unroll
+        for (int h = 0; h < BP; ++h) dma16(dstb + h * 1024, voffB[h], rsB, sb);
+    };
+
+    // ---- the first slice leaves before the masks are known (slice 0 is live whenever anything is) ----
+    const int ntiles = p.K / BK;
+    issue(0, 0);
+
+    // ---- masked-work skipping: live slices as a bit mask ----
+    unsigned long long live = ntiles >= 64 ? ~0ull : ((1ull << ntiles) - 1ull);
+    if (p.keep_k || p.keep_n) {
+        int s_lo = 0, s_hi = 0;
+        if (p.rows_in > 0) { s_lo = m0 / p.rows_in; s_hi = (min(m0 + BM, p.M) - 1) / p.rows_in; }
+        bool any = true;
+        if (p.keep_n) any = range_has_kept(n0, BN, p.n_period, max_keep_wave(p.keep_n, s_lo, s_hi, lane));
+        if (p.keep_k) {
+            const int kmax = max_keep_wave(p.keep_k, s_lo, s_hi, lane);
+            if (kmax <= 0) any = false;
+            else if (p.k_period <= 0) {                                  // plain prefix: the slices below kmax
+                const int nl = min(ntiles, (kmax + BK - 1) / BK);
+                live = nl >= 64 ? ~0ull : ((1ull << nl) - 1ull);
+            } else if (p.k_period >= BK) {                              // periodic prefix (per-head widths): one scalar pass
+                unsigned long long m = 0;
+                int nr = 0;
+                for (int kt = 0; kt < ntiles; ++kt) {
+                    if (nr < kmax || nr + BK > p.k_period) m |= 1ull << kt;
+                    nr += BK;
+                    if (nr >= p.k_period) nr -= p.k_period;
+                }
+                live = m;
+            }
+        }
+        if (!any) live = 0;
+    }
+    if (t < BM) {                        // per-row epilogue metadata (its loads overlap the first slice)
+        const int m = m0 + t;
+        RowMeta rm;
+        rm.keep = 1 << 30; rm.scale = 1.0f; rm.orow = -1; rm.mloc = 0;
+        if (m < p.M) {
+            const int sample = p.rows_in > 0 ? m / p.rows_in : 0;
+            rm.mloc = p.rows_in > 0 ? m - sample * p.rows_in : m;
+            rm.orow = (int)map_row({p.c_map.rpi, p.c_map.rps, p.c_map.off}, m);
+            if (p.scale) rm.scale = p.scale[sample];
+            if (p.keep_n) rm.keep = p.keep_n[sample];
+        }
+        rowmeta[t] = rm;
+    }
+
+    // ---- fragment read offsets: lane -> row (lane & 15) of a 16-row group, k-chunk 4 s + (lane >> 4) ----
+    const int frow = lane & 15, fswz = (frow >> 1) & 7;
+    const int slot0 = (((lane >> 4)) ^ fswz) << 4, slot1 = ((4 + (lane >> 4)) ^ fswz) << 4;
+    const char* As = smem + (wm * WROWS + frow) * 128;
+    const char* Bs = smem + A_BYTES + (wn * WCOLS + frow) * 128;
+    int offB[NJ];
+    if constexpr (BKM) {
+        typedef KMajor<BN> G;
+        const int li = lane & 15, g4 = lane >> 4;
+        const int xr2 = G::swz(8 * g4 + (li >> 2));
+        const int rowoff = (8 * g4 + (li >> 2)) * G::ROWB + (li & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) offB[j] = A_BYTES + rowoff + ((((BN / 16) * wn + 2 * j + ((li & 3) >> 1)) ^ xr2) * 16);
+    }
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const char* Ab = As + buf * STAGE_BYTES;
+        const char* Bb = Bs + buf * STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int so = s == 0 ? slot0 : slot1;
+            bfv8 a[MI], b[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bfv8*>(Ab + i * 2048 + so);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (BKM) b[j] = tr_frag<KMajor<BN>::ROWB>(smem + buf * STAGE_BYTES + offB[j] + s * 32 * KMajor<BN>::ROWB);
+                else b[j] = *reinterpret_cast<const bfv8*>(Bb + j * 2048 + so);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // slice 0 went out unconditionally: with nothing live it is drained and dropped
+    const bool first_live = (live & 1ull) != 0;
+    live &= ~1ull;
+    if constexpr (NBUF == 1) {
+        bool have = first_live;
+        if (!first_live && live) {                    // (periodic masks can skip slice 0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int kt = __builtin_ctzll(live);
+            live &= live - 1;
+            issue(kt, 0);
+            have = true;
+        }
+        while (have) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+            have = live != 0;
+            if (have) {
+                const int kt = __builtin_ctzll(live);
+                live &= live - 1;
+                issue(kt, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        // ring of NBUF buffers: the slice multiplied this round was requested NBUF - 1 rounds ago.  in_flight = slices issued and not
+        // yet multiplied (the head one is the oldest); a dead slice 0 is multiplied too (zero weight would be wrong: it is real data
+        // of masked channels) -- so it is waited for and skipped instead.
+        int pending = 1;                              // slices in flight
+        int head = 0, tail = 1;                       // ring positions: head = buffer of the oldest slice in flight
+        bool skip_head = !first_live;
+#pragma unroll 1
+        while (pending > 0 || live) {
+            // top up the ring
+            while (pending < NBUF - 1 && live) {
+                const int kt = __builtin_ctzll(live);
+                live &= live - 1;
+                issue(kt, tail);
+                tail = tail + 1 == NBUF ? 0 : tail + 1;
+                ++pending;
+            }
+            // the head slice has landed when at most the younger slices' pieces are outstanding
+            if (pending >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AP + BP)) : "memory");
+            else if (pending == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();             // every wave's pieces of the head slice are in LDS; the buffer multiplied last
+                                                      // round is free for the refill below
+            if (live) {
+                const int kt = __builtin_ctzll(live);
+                live &= live - 1;
+                issue(kt, tail);
+                tail = tail + 1 == NBUF ? 0 : tail + 1;
+                ++pending;
+            }
+            if (!skip_head) compute(head);
+            skip_head = false;
+            head = head + 1 == NBUF ? 0 : head + 1;
+            --pending;
+        }
+        __syncthreads();
+    }
+
+    epilogue<TO, EPI, true, MI, NJ, FEAT>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wm * WROWS, n0 + wn * WCOLS,
+                                         lane);
+}
+
+template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM> void klaunch(const vr_gemm_args& a, hipStream_t stream) {
+    const long long total = (long long)((a.M + 32 * MI - 1) / (32 * MI)) * ((a.N + 32 * NJ - 1) / (32 * NJ));
+    hipLaunchKernelGGL((ntk_kernel<TO, EPI, MI, NJ, NBUF, FEAT, BKM>), dim3((unsigned)total), dim3(KTHR), 0, stream, a);
+}
+
+template <typename TO, int EPI, int FEAT, bool BKM> void ktile(const vr_gemm_args& a, hipStream_t stream, int tile, int nbuf) {
+    if (tile == 1) {
+        if (nbuf == 1) klaunch<TO, EPI, 4, 4, 1, FEAT, BKM>(a, stream);
+        else if (nbuf == 2) klaunch<TO, EPI, 4, 4, 2, FEAT, BKM>(a, stream);
+        else klaunch<TO, EPI, 4, 4, 3, FEAT, BKM>(a, stream);
+    } else if (tile == 2) {
+        if (nbuf == 1) klaunch<TO, EPI, 2, 4, 1, FEAT, BKM>(a, stream);
+        else if (nbuf == 2) klaunch<TO, EPI, 2, 4, 2, FEAT, BKM>(a, stream);
+        else klaunch<TO, EPI, 2, 4, 3, FEAT, BKM>(a, stream);
+    } else {
+        if (nbuf == 1) klaunch<TO, EPI, 2, 2, 1, FEAT, BKM>(a, stream);
+        else if (nbuf == 2) klaunch<TO, EPI, 2, 2, 2, FEAT, BKM>(a, stream);
+        else klaunch<TO, EPI, 2, 2, 3, FEAT, BKM>(a, stream);
+    }
+}
+
+}  // namespace vr_gemm_nt
+
+// Called by vr_gemm_nt_launch in front of gemm_nt.hip's own kernels.  Returns false when the form is not covered here.
+bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
+    using namespace vr_gemm_nt;
+    static const int knob = std::getenv("VITRES_NTK") ? std::atoi(std::getenv("VITRES_NTK")) : 1;
+    if (!knob) return false;
+    if (a.sched & (8 | 16 | 32 | 64 | 0x100)) return false;          // forms of gemm_nt.hip forced by the caller (tests, measurement aids)
+    if (a.in_dtype != VR_BF16 || a.a_trans || a.atomic || a.split_k > 1 || a.bias_grad || a.pos) return false;
+    if (a.K % BK || a.K > 64 * BK || a.K < BK) return false;
+    const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);
+    if (!fast || a.lda % 8 || a.ldb % 8 || ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return false;
+    if (a.k_period > 0 && a.k_period < BK) return false;
+    // 32-bit byte offsets: the furthest row an operand reaches (mapped rows included) must stay below 4 GB
+    auto reach = [](const vr_rowmap& m, long long rows, long long ld) {
+        const long long last = m.rpi == 0 ? rows - 1 : ((rows - 1) / m.rpi) * (long long)m.rps + m.off + (rows - 1) % m.rpi;
+        return (last + 1) * ld * 2;
+    };
+    if (reach(a.a_map, a.M, a.lda) >= 0xfff00000LL) return false;
+    if (a.b_trans ? (long long)a.K * a.ldb * 2 >= 0xfff00000LL : reach(a.b_map, a.N, a.ldb) >= 0xfff00000LL) return false;
+    const bool of32 = a.out_dtype == VR_F32;
+    int feat = -1;
+    if (!a.bias && !a.resid && !a.scale) feat = 0;
+    else if (a.bias && !a.resid && !a.scale) feat = 1;
+    else if (a.bias && a.resid && !a.scale) feat = 2;
+    else if (a.bias && a.resid && a.scale) feat = 3;
+    if (feat < 0) return false;
+    const bool gelu = a.act == 1 || a.act == 3 || (a.act == 2 && !a.dact_u);
+    // tile by grid size (gemm_nt.hip's measured crossovers); slices in flight by how many workgroups a CU gets
+    const long long tn = (a.N + 127) / 128;
+    const long long t128 = (long long)((a.M + 127) / 128) * tn, t64 = (long long)((a.M + 63) / 64) * tn;
+    static const int knob_tile = std::getenv("VITRES_NTK_TILE") ? std::atoi(std::getenv("VITRES_NTK_TILE")) : 0;
+    static const int knob_buf = std::getenv("VITRES_NTK_BUF") ? std::atoi(std::getenv("VITRES_NTK_BUF")) : 0;
+    // sched bits 0x1800: tile override (1: 128 x 128, 2: 64 x 128, 3: 64 x 64), bits 0x600: slices-in-flight override (tests)
+    const int s_tile = (a.sched >> 11) & 3, s_buf = (a.sched >> 9) & 3;
+    const int tile = s_tile ? s_tile : knob_tile ? knob_tile : (t128 >= 2LL * n_cu ? 1 : (t64 >= 2LL * n_cu ? 2 : 3));
+    const long long wgs = tile == 1 ? t128 : (tile == 2 ? t64 : (long long)((a.M + 63) / 64) * ((a.N + 63) / 64));
+    int nbuf = s_buf ? s_buf : knob_buf ? knob_buf : (wgs >= 3LL * n_cu || a.K < 4 * BK ? 1 : (a.K >= 8 * BK ? 3 : 2));
+    if (a.b_trans) {
+        if (of32 || feat != 0 || gelu || a.b_map.rpi != 0 || a.ldb < (a.N + 7) / 8 * 8) return false;
+        if (a.dact_u) {
+            if (a.act != 2) return false;
+            ktile<bf16_t, EPI_DMUL, 0, true>(a, stream, tile, nbuf);
+        } else {
+            ktile<bf16_t, EPI_STORE, 0, true>(a, stream, tile, nbuf);
+        }
+        return true;
+    }
+    if (a.dact_u) return false;
+    if (gelu) {
+        if (of32 || feat != 1 || a.act == 3) return false;
+        ktile<bf16_t, EPI_GELU, 1, false>(a, stream, tile, nbuf);
+        return true;
+    }
+    if (of32) {
+        if (feat == 3) ktile<float, EPI_STORE, 3, false>(a, stream, tile, nbuf);
+        else if (feat == 2) ktile<float, EPI_STORE, 2, false>(a, stream, tile, nbuf);
+        else if (feat == 1) ktile<float, EPI_STORE, 1, false>(a, stream, tile, nbuf);
+        else return false;
+        return true;
+    }
+    if (feat == 1) ktile<bf16_t, EPI_STORE, 1, false>(a, stream, tile, nbuf);
+    else if (feat == 0) ktile<bf16_t, EPI_STORE, 0, false>(a, stream, tile, nbuf);
+    else return false;
+    return true;
+}

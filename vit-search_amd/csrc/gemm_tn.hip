@@ -96,11 +96,14 @@ __device__ __forceinline__ void tn_body(const vr_gemm_args& p, const int bid) {
     int ntiles = kbeg < kend ? (kend - kbeg + BT - 1) / BT : 0;
     // masked-work skipping: keep_k bounds the kept output rows (dY channels), keep_n the kept columns (X channels) of
     // the samples this token range touches; a tile without kept rows or columns adds exactly zero
+    // (kmax / nmax also bound what the epilogue adds: rows / columns beyond the largest kept prefix of this token range hold exact
+    // zeros -- round 5: fp32 atomics run at ~1.1 TB/s of payload, 40 - 55 % of a group launch's time, profiles/r05_wgrad_atomics.txt)
+    int kmax = 1 << 30, nmax = 1 << 30;
     if ((p.keep_k || p.keep_n) && ntiles > 0) {
         int s_lo = 0, s_hi = 0;
         if (p.rows_in > 0) { s_lo = kbeg / p.rows_in; s_hi = (kend - 1) / p.rows_in; }
-        const int kmax = max_keep(p.keep_k, s_lo, s_hi, 1 << 30);
-        const int nmax = max_keep(p.keep_n, s_lo, s_hi, 1 << 30);
+        kmax = max_keep(p.keep_k, s_lo, s_hi, 1 << 30);
+        nmax = max_keep(p.keep_n, s_lo, s_hi, 1 << 30);
         if (!range_has_kept(n0, TW, p.n_period, nmax) || !range_has_kept(m0, TW, p.k_period, kmax)) ntiles = 0;
     }
     // atomic == 2 (store form, split_k == 1): the tile's one workgroup OVERWRITES the gradient -- no zero-filled destination, no
@@ -194,6 +197,8 @@ __device__ __forceinline__ void tn_body(const vr_gemm_args& p, const int bid) {
             }
         }
     };
+    const int dbg = (p.sched >> 13) & 3;         // measurement aid (VITRES_DBG_TN; wrong results): 1 no epilogue, 2 no K loop
+    if (dbg == 2) ntiles = 0;
     if constexpr (STAGES == 1) {
         for (int kt = 0; kt < ntiles; ++kt) {
             issue(kt, 0);
@@ -218,19 +223,32 @@ __device__ __forceinline__ void tn_body(const vr_gemm_args& p, const int bid) {
 
     // ---- epilogue: lane holds C[m = 16 i + 4 (lane >> 4) + r][n = 16 j + (lane & 15)]: 16 consecutive columns (64 B)
     //      of 4 rows per atomic instruction ----
+    if (dbg == 1) {
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = 1.f;      // (keeps the loop alive)
+        return;
+    }
     float* C = reinterpret_cast<float*>(p.C);
     const RowMap cm = {p.c_map.rpi, p.c_map.rps, p.c_map.off};
+    // masked rows / columns are exact zeros: the atomic form leaves them alone (the store form must write them)
+    const bool skipz = !store && !(p.sched & 0x8000);                       // (sched bit 0x8000: add the zeros too -- A/B aid)
+    bool ncol[F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) {
+        const int n = n0 + wn * (TW / 2) + 16 * j + li;
+        ncol[j] = n < p.N && (!skipz || kept_col(n, p.n_period, nmax));
+    }
 #pragma unroll
     for (int i = 0; i < F; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + wm * (TW / 2) + 16 * i + 4 * g + r;
             if (m >= p.M) continue;
+            if (skipz && !kept_col(m, p.k_period, kmax)) continue;
             float* crow = C + map_row(cm, m) * (long long)p.ldc;
 #pragma unroll
             for (int j = 0; j < F; ++j) {
                 const int n = n0 + wn * (TW / 2) + 16 * j + li;
-                if (n < p.N) {
+                if (ncol[j]) {
                     if (store) crow[n] = acc[i][j][r];
                     else atomicAdd(crow + n, acc[i][j][r]);
                 }
@@ -322,8 +340,11 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
     TnGroup g;
     g.count = count;
     int next = 0;
+    static const int knob_dbg = std::getenv("VITRES_DBG_TN") ? std::atoi(std::getenv("VITRES_DBG_TN")) : 0;
     for (int i = 0; i < count; ++i) {
         g.a[i] = args[i];
+        g.a[i].sched |= (knob_dbg & 3) << 13;
+        if (knob_dbg & 4) g.a[i].sched |= 0x8000;               // VITRES_DBG_TN=4: add the masked zeros too
         const long long slices = (args[i].K + BT - 1) / BT;
         const long long tiles = (long long)((args[i].M + TWv - 1) / TWv) * ((args[i].N + TWv - 1) / TWv);
         long long split = args[i].atomic == 2 ? 1 : (slices + spw - 1) / spw;       // store form: one workgroup per tile

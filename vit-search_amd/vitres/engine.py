@@ -466,6 +466,10 @@ class GraphedTrainStep:
         plan = self.model.sample_plan(samples.shape[0])
         if rng is not None:
             torch.random.set_rng_state(rng)
+        probe = self._gap_probe
+        if probe is not None:                                      # dev aid (VITRES_DBG_GAP2): GPU time of the phases of one call
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
         if self.keep_static is not None:
             flat, _ = self.model.plan_host_buffer(plan)
             slot = self._stage[self._stage_i % len(self._stage)]
@@ -476,6 +480,8 @@ class GraphedTrainStep:
             self.keep_static.copy_(slot[0], non_blocking=True)
             slot[1] = torch.cuda.Event()
             slot[1].record()
+        if probe is not None:
+            ev[1].record()
         if self.col_static is not None:
             self._gather(samples, plan)                           # reads the caller's tensor directly
         elif samples.data_ptr() != self.x.data_ptr():
@@ -494,16 +500,21 @@ class GraphedTrainStep:
         if RUN_AHEAD > 0:
             if len(self._inflight) >= RUN_AHEAD:
                 self._inflight.pop(0).synchronize()
+        if probe is not None:
+            ev[2].record()
         self.graph.replay()
         self.model._stem_fold = None                               # (stem.drop_fold: the replay moved BatchNorm's running statistics)
         for k, g in enumerate(self.more_graphs):
             if self._sync is not None:                            # the arena range of the part just replayed is final: exchange it now
                 self._works.append(self._sync.all_reduce_range(*self.ranges[k]))
             g.replay()
+        if probe is not None:
+            ev[3].record()
+            probe.append(ev)
         if RUN_AHEAD > 0:
-            ev = torch.cuda.Event()
-            ev.record()
-            self._inflight.append(ev)
+            e_done = torch.cuda.Event()
+            e_done.record()
+            self._inflight.append(e_done)
         return self.loss
 
     def finish_update(self):
@@ -515,6 +526,17 @@ class GraphedTrainStep:
 
     _sync, _works = None, ()
     _inflight = None
+    _gap_probe = [] if os.environ.get("VITRES_DBG_GAP2") else None
+
+    def gap_report(self, skip=10):
+        """VITRES_DBG_GAP2: average GPU ms of [plan copy | gather + target copies | graph replay | end of a call -> start of the next]."""
+        pr = self._gap_probe[skip:] if self._gap_probe else []
+        if len(pr) < 2:
+            return None
+        n = len(pr)
+        seg = [sum(e[k].elapsed_time(e[k + 1]) for e in pr) / n for k in range(3)]
+        seg.append(sum(pr[i][3].elapsed_time(pr[i + 1][0]) for i in range(n - 1)) / (n - 1))
+        return [round(v, 4) for v in seg]
 
     def step_with_sync(self, grad_sync, samples, targets, patch_targets=None, average=True, **kw):
         """Replay + data-parallel gradient exchange: with split_for_sync the all-reduce of the last stage's gradients
