@@ -99,12 +99,13 @@ typedef struct vr_gemm_args {
     int32_t sched;       /* scheduling hints (bit mask, 0 = default): 1 = launched beside another kernel on a second stream (general
                             kernel: 128x128 tile, one workgroup per tile instead of persistent workgroups); 2 = keep the hardware's
                             round-robin workgroup -> XCD order (default: tiles remapped so that an XCD owns a contiguous run);
-                            4 = always use the general kernel (gemm.hip) -- measurement aid; 8 = 8-wave stream-K kernel (gemm_ntw.hip) wherever it
-                            is admissible; 16 = never; 64 = split-K form of the 4-wave kernel (gemm_nt.hip: shares of a tile's K
-                            slices on several workgroups, fp32 slabs in ws, the last arriver runs the epilogue) wherever a cut
-                            exists; 128 (vr_gemm_group, first problem) = the group may fill the chip (default: capped at two resident workgroups
-                            per CU, VITRES_TN_GROUP_CAP).  vr_gemm_ln: 8 = the one-workgroup-per-CU form (gemm_nt_lnw.hip) whenever
-                            N <= 256, 16 = never (default: for M >= 64 rows per CU) */
+                            4 = always use the general kernel (gemm.hip) -- measurement aid; 64 = split-K form of the 4-wave kernel
+                            (gemm_nt.hip: shares of a tile's K slices on several workgroups, fp32 slabs in ws, the last arriver runs the
+                            epilogue) wherever a cut exists; 128 (vr_gemm_group, first problem) = the group may fill the chip (default:
+                            capped at two resident workgroups per CU, VITRES_TN_GROUP_CAP); 0x100 = gemm_nt.hip's kernels instead of the
+                            lean-loop ones (gemm_ntk.hip); 0x600 / 0x1800 = slices in flight (1 - 3) / tile (1: 128 x 128, 2: 64 x 128,
+                            3: 64 x 64) of the lean-loop kernels instead of their grid-size rule (tests); 8, 16, 32: measurement aids of
+                            gemm_nt.hip (force its kernels, record stamps) */
     vr_rowmap a_map;     /* remap of A's token rows (M index if a_trans==0, K index if a_trans==1) */
     vr_rowmap b_map;     /* remap of B's token rows (only meaningful when b_trans==1 && a_trans==1) */
     vr_rowmap c_map;     /* remap of output rows */
@@ -113,18 +114,15 @@ typedef struct vr_gemm_args {
                             (engine.py:119-165, channel_drop.py:101-105).  Pure scheduling hint: the kernels interleave the groups'
                             row tiles (wgrad: token splits) in their XCD-contiguous workgroup order, so that no XCD is dealt only
                             the sparsest (or only the densest) architecture; 0 / 1: one group */
-    void* ws;            /* optional workspace of the stream-K forward / data-gradient kernel (gemm_ntw.hip): output tiles that do
-                            not fill a round of the chip are shared slice-wise between workgroups, which exchange fp32 partial
-                            accumulators through it.  >= vr_gemm_ws_bytes() bytes, 16-byte aligned, ZERO before its first use (the
-                            kernels leave its tickets at zero), never shared by launches that may run concurrently (one per
+    void* ws;            /* optional workspace of the split-K form (sched 64, VITRES_NT_SPLIT): the workgroups that share a tile exchange
+                            fp32 partial accumulators through it.  >= vr_gemm_ws_bytes() bytes, 16-byte aligned, ZERO before its first
+                            use (the kernels leave its tickets at zero), never shared by launches that may run concurrently (one per
                             stream).  NULL: every tile is computed by one workgroup. */
     int64_t ws_bytes;
 } vr_gemm_args;
 
 /* bytes of vr_gemm_args.ws that enable tile sharing on the current device */
 int vr_gemm_ws_bytes(void);
-/* 1 when the library was built with `make EXPERIMENTAL=1` (the kernel forms of csrc/experimental/, include/vitres_hip_experimental.h) */
-int vr_experimental(void);
 
 int vr_gemm(const vr_gemm_args* args, vr_stream_t stream);
 
@@ -148,8 +146,7 @@ int vr_gemm_group(const vr_gemm_args* args, int32_t count, vr_stream_t stream);
  *       C = (resid ? resid : 0) + dLN/dx(dy);  dw += sum dy*xhat;  db += sum dy;
  *       gt_out[m,c] = c < gt_keep[s] ? C[m,c] * gt_scale[s] : 0 (bf16, optional)  exactly vr_ln_bwd on a fp32 dy
  *     (args.bias / scale / keep_n must be NULL; keep_k / k_period / rows_in keep their vr_gemm meaning).
- * Two kernels stand behind it with the same results: 64 x 256 / 32 x 512 tiles sharing a CU (gemm_nt_ln.hip), and for N <= 256
- * and long M one eight-wave workgroup per CU that owns an equal share of the 16-row blocks (gemm_nt_lnw.hip; args.sched 8 / 16).
+ * Kernel: 64 x 256 / 64 x 320 / 32 x 512 tiles, two or three workgroups per CU (gemm_nt_ln.hip).
  */
 typedef struct vr_ln_epilogue {
     int32_t mode;

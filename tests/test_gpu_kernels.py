@@ -134,61 +134,6 @@ def test_gemm_split_k(M, N, K_, rows_in, variant, sched):
     assert relerr(plain, ref) < t_
 
 
-def need_experimental():
-    """Kernel forms quarantined in vit-search_amd/csrc/experimental/ (measured slower inside the workloads): present only in
-    `make -C vit-search_amd/csrc EXPERIMENTAL=1 LIB=../lib/libvitres_hip_exp.so` builds -- run these tests with
-    VITRES_LIB=vit-search_amd/lib/libvitres_hip_exp.so."""
-    from vitres import _lib
-    if not _lib.experimental():
-        pytest.skip("needs an EXPERIMENTAL=1 build of the library (VITRES_LIB=.../libvitres_hip_exp.so)")
-
-
-@pytest.mark.parametrize("M,N,K_,rows_in", [(2176, 1024, 3072, 17), (8320, 512, 1536, 65), (1300, 320, 640, 65), (2176, 768, 1024, 17),
-                                            (4 * 257, 1536, 512, 257), (33 * 256, 256, 768, 256), (32896, 1024, 256, 257)])
-@pytest.mark.parametrize("variant", ["fwd", "gelu", "res", "dgrad", "dmul"])
-def test_gemm_wide_streamk(M, N, K_, rows_in, variant):
-    need_experimental()
-    if M > 30000 and variant not in ("fwd", "res"):
-        pytest.skip("the 516-tile case (whole rounds + shared tiles in one launch) runs two forms")
-    """8-wave ring-pipelined kernel with tiles shared slice-wise between workgroups (gemm_ntw.hip, sched bit 8) against the
-    emulation: fp32 outputs to 1e-4 (bf16-rounded inputs, fp32 accumulation: only the summation order differs), bf16 outputs
-    to bf16 rounding; and against the 4-wave kernels (bit 16) launch after launch -- the tickets must come back to zero."""
-    a, b, out, kw = _wide_case(M, N, K_, variant, rows_in)
-    ref = E.gemm(a, b, out.clone(), **{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
-    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
-    kw_d = {k: to(v) for k, v in kw.items()}
-    ad, bd = a.to(DEV), b.to(DEV)
-    t_ = 1e-4 if out.dtype == torch.float32 else 8e-3          # bf16 outputs: one ulp (2^-7 of the largest value) where a sum rounds the other way
-    for rep in range(3):
-        real = K.gemm(ad, bd, torch.full_like(out, float("nan")).to(DEV), sched=8, **kw_d)
-        torch.cuda.synchronize()
-        assert relerr(real, ref) < t_, (variant, rep, relerr(real, ref))
-    if variant == "gelu":
-        ref2 = torch.zeros(M, N, dtype=torch.bfloat16)
-        kw2 = dict(kw); kw2["out2"] = ref2
-        E.gemm(a, b, out.clone(), **kw2)
-        assert relerr(kw_d["out2"], ref2) < t_
-    narrow = K.gemm(ad, bd, torch.zeros_like(out).to(DEV), sched=16, **kw_d)
-    assert relerr(narrow, ref) < t_
-    # uneven load: another stream keeps some CUs busy while a burst of wide launches runs back to back on fresh operands
-    side = torch.cuda.Stream()
-    busy = torch.randn(4096, 4096, device=DEV)
-    outs = []
-    with torch.cuda.stream(side):
-        for _ in range(4):
-            busy = torch.tanh(busy @ busy * 1e-2)
-    for rep in range(6):
-        a2 = (ad.float() * (1.0 + 0.25 * rep)).to(torch.bfloat16)
-        o_w = K.gemm(a2, bd, torch.full_like(out, float("nan")).to(DEV), sched=8, **kw_d)
-        o_n = K.gemm(a2, bd, torch.zeros_like(out).to(DEV), sched=16, **kw_d)
-        outs.append((o_w, o_n))
-    torch.cuda.synchronize()
-    for o_w, o_n in outs:
-        assert relerr(o_w, o_n) < (2e-5 if out.dtype == torch.float32 else 8e-3), (variant, relerr(o_w, o_n))
-    ws = K._workspace(torch.device(DEV, torch.cuda.current_device()))
-    assert int(ws[: 4096 * 4].view(torch.int32).abs().sum()) == 0           # every ticket is back at zero
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_rowmaps_and_pos(dtype):
     B, P, C, Kd = 3, 16, 64, 592
@@ -264,12 +209,12 @@ def test_gemm_group_interleaved_tile_order_changes_nothing(groups):
                 K.M_GROUPS[0] = g_
                 try:
                     res.append(K.gemm(a.to(DEV), b.to(DEV), torch.full_like(out, float("nan")).to(DEV), sched=16, **kw_d).clone())
-                    if g_ > 1:
-                        res.append(K.gemm(a.to(DEV), b.to(DEV), torch.full_like(out, float("nan")).to(DEV), sched=8, **kw_d).clone())
+                    if g_ > 1:                                # the lean-loop kernel (gemm_ntk.hip: the default path), three slices in flight
+                        res.append(K.gemm(a.to(DEV), b.to(DEV), torch.full_like(out, float("nan")).to(DEV), sched=3 << 9, **kw_d).clone())
                 finally:
                     K.M_GROUPS[0] = 1
             assert torch.equal(res[0], res[1]), (M, N, K_, variant)
-            assert relerr(res[2], res[0]) < (2e-5 if out.dtype == torch.float32 else 8e-3)      # (8-wave kernel: another summation order)
+            assert relerr(res[2], res[0]) < (2e-5 if out.dtype == torch.float32 else 8e-3)      # (same products; bf16 outputs may round the other way)
         # weight gradient: token splits interleaved
         T = M
         dy, x = rnd(T, N, seed=3).to(torch.bfloat16).to(DEV), rnd(T, K_, seed=4).to(torch.bfloat16).to(DEV)
@@ -878,16 +823,12 @@ def _bf(t):
     return t.to(torch.bfloat16)
 
 
-# sched 8: the one-workgroup-per-CU form (gemm_nt_lnw.hip, opt-in); 16: never.
-# (130 x 257: not a multiple of 16 rows, 8 or 9 blocks per workgroup; 150 x 257: two tiles per workgroup)
+# (130 x 257: not a multiple of 16 rows; sched is passed through -- vr_gemm_ln has one kernel)
 @pytest.mark.parametrize("B,Nt,C,Kd,masked,sched", [
     (6, 257, 256, 768, True, 16), (4, 65, 512, 1536, True, 0), (3, 50, 192, 256, False, 16), (5, 17, 448, 128, True, 0),
     (2, 33, 8, 72, False, 16), (5, 257, 320, 1280, True, 0), (3, 70, 296, 320, False, 0),
-    (6, 257, 256, 768, True, 8), (3, 50, 192, 256, False, 8), (2, 33, 8, 72, False, 8), (21, 257, 248, 200, True, 8),
-    (130, 257, 256, 768, True, 8), (150, 257, 256, 256, True, 8), (130, 257, 256, 768, True, 0)])
+    (21, 257, 248, 200, True, 0), (150, 257, 256, 256, True, 0), (130, 257, 256, 768, True, 0)])
 def test_gemm_ln_forward(B, Nt, C, Kd, masked, sched):
-    if sched == 8:
-        need_experimental()
     """mode 0 == vr_gemm (residual epilogue) followed by vr_ln_fwd: same residual stream bit for bit (same MFMA order is not
     required: compared with tolerance), LayerNorm output / statistics within bf16 / fp32 rounding."""
     M = B * Nt
@@ -925,12 +866,8 @@ def test_gemm_ln_forward(B, Nt, C, Kd, masked, sched):
     (6, 257, 256, 768, True, True, 16), (4, 65, 512, 1536, True, True, 0), (3, 50, 192, 256, False, False, 16),
     (5, 17, 448, 192, True, False, 0), (2, 33, 8, 72, False, True, 16), (5, 257, 320, 960, True, True, 0),
     (3, 70, 296, 320, False, False, 0),
-    (6, 257, 256, 768, True, True, 8), (3, 50, 192, 256, False, False, 8), (2, 33, 8, 72, False, True, 8),
-    (21, 257, 248, 200, True, True, 8), (130, 257, 256, 768, True, True, 8), (150, 257, 256, 256, True, False, 8),
-    (130, 257, 256, 768, True, True, 0)])
+    (21, 257, 248, 200, True, True, 0), (150, 257, 256, 256, True, False, 0), (130, 257, 256, 768, True, True, 0)])
 def test_gemm_ln_backward(B, Nt, C, Kd, masked, nxt, sched):
-    if sched == 8:
-        need_experimental()
     """mode 1 == data-gradient GEMM (fp32 result) followed by vr_ln_bwd."""
     M = B * Nt
     du, wt = _bf(rnd(M, Kd, seed=1)), _bf(rnd(C, Kd, seed=2, scale=Kd ** -0.5))
@@ -1096,45 +1033,6 @@ def test_gemm_saved_gelu_derivative_pair(M, C, F):
     du = torch.empty(M, F, dtype=dt, device=DEV)
     K.gemm(cu(gt), cu(w2t), du, dact_u=d, act=2, **{k: cu(v) for k, v in kw2.items()})
     assert relerr(du, du_ref) < 2e-2, relerr(du, du_ref)
-
-
-@pytest.mark.parametrize("B,N,C,F,masked,mapped", [(4, 257, 320, 960, True, True), (3, 65, 64, 192, True, False), (16, 257, 256, 768, False, True),
-                                                   (2, 300, 320, 1280, True, False), (5, 17, 128, 96, True, False), (9, 129, 192, 384, False, True)])
-def test_fused_mlp_forward(B, N, C, F, masked, mapped):
-    need_experimental()
-    """vr_mlp_fwd (one kernel, hidden tensor never written) against the two-GEMM form it replaces (vr_gemm act = 1, then
-    vr_gemm with scale / keep / residual): the same bf16 rounding of the hidden activations, fp32 summation order differs.
-    mapped: the patch rows of every sample through a row map (the class-token row is left untouched)."""
-    gen = torch.Generator().manual_seed(B * 1000 + C)
-    T = 1 if mapped else 0
-    P = N - T
-    y = _bf(rnd(B, N, C, seed=1)).to(DEV)
-    w1 = _bf(rnd(F, C, seed=2, scale=C ** -0.5)).to(DEV)
-    w2 = _bf(rnd(C, F, seed=3, scale=F ** -0.5)).to(DEV)
-    b1, b2 = rnd(F, seed=4).to(DEV), rnd(C, seed=5).to(DEV)
-    x = rnd(B, N, C, seed=6).to(DEV)
-    kin = khid = kout = scale = None
-    if masked:
-        kin = torch.randint(C // 2, C + 1, (B,), generator=gen).int().to(DEV)
-        khid = torch.randint(1, F + 1, (B,), generator=gen).int().to(DEV)
-        kout = kin.clone()
-        scale = (torch.rand(B, generator=gen) + 0.5).to(DEV)
-        y = y * (torch.arange(C, device=DEV)[None, None, :] < kin[:, None, None])       # the LayerNorm output is zero beyond its keep
-    # reference: the two-GEMM path on the same rows
-    ref = x.clone()
-    h = torch.empty(B * P, F, dtype=torch.bfloat16, device=DEV)
-    amap = (P, N, T) if mapped else None
-    K.gemm(y, w1, h, M=B * P, N=F, K=C, lda=C, ldb=C, ldc=F, bias=b1, act=1, keep_n=khid, rows_in=P, keep_k=kin, a_map=amap)
-    K.gemm(h, w2, ref, M=B * P, N=C, K=F, lda=F, ldb=F, ldc=C, bias=b2, scale=scale, keep_n=kout, resid=x, rows_in=P, keep_k=khid,
-           c_map=amap)
-    out = x.clone() if mapped else torch.empty_like(x)
-    assert K.mlp_fwd_supported(y, C, F)
-    K.mlp_fwd(y, w1, b1, w2, b2, x, out, M=B * P, C=C, F=F, ldw1=C, ldw2=F, rows_in=P, scale=scale, keep_in=kin, keep_hid=khid,
-              keep_out=kout, row_map=amap)
-    torch.cuda.synchronize()
-    assert relerr(out, ref) < 1e-4
-    if mapped:
-        assert torch.equal(out[:, 0], x[:, 0])
 
 
 @pytest.mark.gpu

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """A/B of the forward / data-gradient GEMM kernels on the block Linears of the step (dev tool; run on the GPU box).
 
-Every shape is timed with the 4-wave kernels (sched bit 16), the 8-wave stream-K kernel forced (bit 8) and the library's own
-choice; `python tools/gemm_wide_bench.py [stage ...]`.  Operands are standard-normal bf16 (never zeros: DVFS)."""
+Every shape is timed with gemm_nt.hip's kernels (sched bit 0x100), the lean-loop kernels with three slices in flight (gemm_ntk.hip,
+sched 3 << 9) and the library's own choice; `python tools/gemm_wide_bench.py [stage ...]`.  Operands are standard-normal bf16 (never zeros: DVFS)."""
 import os
 import sys
 
@@ -77,12 +77,12 @@ ROWS = {8320: 65, 2176: 17, 32896: 257, 4160: 65, 1088: 17, 16448: 257, 8192: 64
 
 def main():
     which = sys.argv[1:] or ["s2", "s3", "s1"]
-    print("%-30s %9s %9s %9s   %s" % ("M N K kind", "4-wave us", "wide us", "auto us", "dense TF/s (4-wave / wide / auto)"))
+    print("%-30s %9s %9s %9s   %s" % ("M N K kind", "old us", "lean3 us", "auto us", "dense TF/s (old / lean3 / auto)"))
     for st in which:
         for M, N, Kd, kind in STAGES[st]:
             x, w, out, kw = case(M, N, Kd, kind, ROWS[M])
             ts = []
-            for sched in (16, 8, 0):
+            for sched in (0x100, 3 << 9, 0):
                 ts.append(timeit(lambda: K.gemm(x, w, out, sched=sched, **kw)))
             fl = 2.0 * M * N * Kd
             print("%-30s %9.1f %9.1f %9.1f   %6.0f / %6.0f / %6.0f" % ("%d %d %d %s" % (M, N, Kd, kind), ts[0] * 1e6, ts[1] * 1e6,

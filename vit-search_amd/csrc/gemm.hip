@@ -796,11 +796,8 @@ static int gemm_validate(vr_gemm_args& a) {
     return VR_OK;
 }
 
-// tickets (16 KB) + two 256 x 128 fp32 slabs per CU: what the split-K form of gemm_nt.hip and the experimental stream-K kernel share
+// tickets (16 KB) + four 128 x 128 fp32 slabs per CU: the workspace of gemm_nt.hip's split-K form (pick_split)
 extern "C" int vr_gemm_ws_bytes(void) { return (int)(4096 * 4 + (size_t)cu_count() * 2 * (256 * 128) * sizeof(float)); }
-// 1 when the library was built with `make EXPERIMENTAL=1` (csrc/experimental/: kernel forms that lost inside the training step)
-__attribute__((weak)) bool vr_gemm_ntw_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu, int mode);
-extern "C" int vr_experimental(void) { return vr_gemm_ntw_launch ? 1 : 0; }
 
 extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
     if (!args) return VR_EINVAL;

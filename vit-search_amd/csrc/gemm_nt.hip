@@ -502,9 +502,6 @@ template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t 
 
 }  // namespace vr_gemm_nt
 
-// experimental/gemm_ntw.hip (only in `make EXPERIMENTAL=1` builds: a weak reference, null in the default library)
-__attribute__((weak)) bool vr_gemm_ntw_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu, int mode);
-
 bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);      // gemm_ntk.hip: the lean-loop kernels
 
 // Called by vr_gemm after validation.  Returns false when the form is not covered here.
@@ -522,14 +519,6 @@ bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
             a.b_map.rpi != 0 || !fast || a.ldb % 8 || ((uintptr_t)a.B & 15) || a.ldb < (a.N + 7) / 8 * 8)
             return false;
     }
-    // 8-wave ping-pong / stream-K kernel (experimental/gemm_ntw.hip, EXPERIMENTAL builds only): sched bit 8, VITRES_NT_WIDE=1 / 2.  Measured round 3: its
-    // main loop runs at 0.75 us per 256 x 128 x 64 slice (57 % of the MFMA rate of a CU, against 46 % for four co-resident
-    // workgroups of this file's kernel), but with one workgroup per CU nothing overlaps a tile's prologue latency, its epilogue
-    // burst (every workgroup stores at the same moment) and the 148 KB of LDS keep the weight-gradient stream off the CU:
-    // alone it is within +-10 % of these kernels on the step's shapes, inside the step it costs 6 %.
-    static const int knob_wide = std::getenv("VITRES_NT_WIDE") ? std::atoi(std::getenv("VITRES_NT_WIDE")) : 0;
-    const int wide = (a.sched & 16) ? 0 : ((a.sched & 8) ? 2 : knob_wide);
-    if (wide && vr_gemm_ntw_launch && vr_gemm_ntw_launch(a, stream, n_cu, wide)) return true;
     if (a.act == 1 || a.act == 3 || (a.act == 2 && !a.dact_u)) {
         if (of32) return false;
         launch1<bf16_t, EPI_GELU>(a, stream, n_cu);

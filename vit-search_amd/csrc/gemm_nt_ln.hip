@@ -423,9 +423,6 @@ template <int MI, int NJ> int launch(const vr_gemm_args& a, const vr_ln_epilogue
 
 }  // namespace vr_gemm_ntln
 
-// experimental/gemm_nt_lnw.hip (EXPERIMENTAL builds only: weak reference)
-__attribute__((weak)) bool vr_gemm_lnw_launch(const vr_gemm_args& a, const vr_ln_epilogue& f, hipStream_t stream);
-
 extern "C" int vr_gemm_ln_supported(int32_t N) { return N > 0 && N % 8 == 0 && N <= 512; }
 
 extern "C" int vr_gemm_ln(const vr_gemm_args* g, const vr_ln_epilogue* ln, vr_stream_t stream) {
@@ -442,10 +439,6 @@ extern "C" int vr_gemm_ln(const vr_gemm_args* g, const vr_ln_epilogue* ln, vr_st
         if (!ln->x || !ln->mean || !ln->rstd || !ln->dw || !ln->db || a.bias || a.scale || a.keep_n) return VR_EINVAL;
     } else {
         return VR_EINVAL;
-    }
-    if (vr_gemm_lnw_launch && vr_gemm_lnw_launch(a, *ln, (hipStream_t)stream)) {               // long and narrow: one workgroup per CU, three-stage ring
-        VR_CHECK_LAUNCH();
-        return VR_OK;
     }
     if (a.N <= 256) return launch<4, 4>(a, *ln, (hipStream_t)stream);
     if (a.N <= 320) return launch<4, 5>(a, *ln, (hipStream_t)stream);      // sr_small's first stage: 64 x 320 tiles

@@ -237,6 +237,8 @@ __device__ __forceinline__ void tn_body(const vr_gemm_args& p, const int bid) {
         const int n = n0 + wn * (TW / 2) + 16 * j + li;
         ncol[j] = n < p.N && (!skipz || kept_col(n, p.n_period, nmax));
     }
+    // (rotating the row order by the split index -- the splits of a tile finish together and add to the same rows -- changes
+    // nothing: the atomics are bound by their volume, ~1.1 TB/s of payload, not by same-line contention; round 5)
 #pragma unroll
     for (int i = 0; i < F; ++i)
 #pragma unroll
@@ -281,14 +283,14 @@ struct TnGroup {
 // 680 - 1280 workgroups that live 25 - 50 us each: as the short-lived workgroups of the main chain's kernel retire, the group's
 // pending ones take their slots -- up to all four per CU -- and the kernel the group runs beside is left a third of the chip
 // (stage-1 data gradients 28.6 -> 51.8 us, LayerNorm backward 16.5 -> 31.7 us: profiles/r04_wgrad_contention.txt).
-template <bool MAPPED, int TW>
+template <bool MAPPED, int TW, int STAGES = 1>
 __global__ __launch_bounds__(NTHR, 4) void tn_group_kernel(const TnGroup g) {
     for (int bid = (int)blockIdx.x; bid < g.first[MAXG]; bid += (int)gridDim.x) {
         int k = 0;
 #pragma unroll
         for (int i = 1; i < MAXG; ++i)
             if (i < g.count && bid >= g.first[i]) k = i;
-        tn_body<true, MAPPED, TW, 1>(g.a[k], bid - g.first[k]);
+        tn_body<true, MAPPED, TW, STAGES>(g.a[k], bid - g.first[k]);
     }
 }
 
@@ -331,10 +333,12 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
     bool all_store = true;
     for (int i = 0; i < count; ++i) all_store = all_store && args[i].atomic == 2;
     static const int knob_stw = std::getenv("VITRES_TN_STORE_TW") ? std::atoi(std::getenv("VITRES_TN_STORE_TW")) : 64;
-    const int TWv = (all_store && knob_stw == 64) ? 64 : 128;
+    static const int knob_gtw = std::getenv("VITRES_TN_GROUP_TW") ? std::atoi(std::getenv("VITRES_TN_GROUP_TW")) : 128;
+    static const int knob_gst = std::getenv("VITRES_TN_GROUP_STAGES") ? std::atoi(std::getenv("VITRES_TN_GROUP_STAGES")) : 1;
+    const int TWv = ((all_store && knob_stw == 64) || knob_gtw == 64) ? 64 : 128;
     long long work = 0;
     for (int i = 0; i < count; ++i)
-        work += (long long)((args[i].M + 127) / 128) * ((args[i].N + 127) / 128) * ((args[i].K + BT - 1) / BT);
+        work += (long long)((args[i].M + TWv - 1) / TWv) * ((args[i].N + TWv - 1) / TWv) * ((args[i].K + BT - 1) / BT);
     long long spw = work / ((long long)knob_fill * n_cu);
     spw = spw < 8 ? 8 : (spw > knob_s ? knob_s : spw);
     TnGroup g;
@@ -360,7 +364,10 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
         const int lim = (knob_cap * n_cu / 10 + 7) / 8 * 8;
         grid = next < lim ? next : lim;
     }
-    if (TWv == 64) hipLaunchKernelGGL((tn_group_kernel<false, 64>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
+    if (knob_gst == 3) {
+        if (TWv == 64) hipLaunchKernelGGL((tn_group_kernel<false, 64, 3>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
+        else hipLaunchKernelGGL((tn_group_kernel<false, 128, 3>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
+    } else if (TWv == 64) hipLaunchKernelGGL((tn_group_kernel<false, 64>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
     else hipLaunchKernelGGL((tn_group_kernel<false, 128>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
     return true;
 }

@@ -304,12 +304,6 @@ extern "C" int vr_ln_fwd(const float* x, const float* w, const float* b, void* y
     return VR_OK;
 }
 
-// experimental/ln_bwd_forms.hip (EXPERIMENTAL builds only: weak reference)
-__attribute__((weak)) bool vr_ln_bwd_col_launch(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                                                const int32_t* keep, const float* dx_in, float* dx_out, float* dw, float* db, void* gt_out,
-                                                const float* gt_scale, const int32_t* gt_keep, int32_t M, int32_t C, int32_t rows_per_sample,
-                                                int32_t dy_dtype, int32_t copies, int32_t knob_rows, hipStream_t stream);
-
 extern "C" int vr_ln_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
                          const int32_t* keep, const float* dx_in, float* dx_out, float* dw, float* db, void* gt_out,
                          const float* gt_scale, const int32_t* gt_keep, int32_t M, int32_t C, int32_t rows_per_sample,
@@ -327,15 +321,6 @@ extern "C" int vr_ln_bwd(const void* dy, const float* x, const float* w, const f
                                        : (M >= 32768 ? 64 : (M >= 8192 ? 32 : (M >= 2048 ? 8 : 4)));
     dim3 grid((M + BWD_ROWS - 1) / BWD_ROWS);
     const int nv = (C + 255) / 256;
-    // VITRES_LN_BWD_FORM=col (EXPERIMENTAL builds): the column-owned kernel of experimental/ln_bwd_forms.hip -- 1.4x faster alone,
-    // 5 % slower inside the training step
-    static const bool knob_col = std::getenv("VITRES_LN_BWD_FORM") && std::getenv("VITRES_LN_BWD_FORM")[0] == 'c';
-    if (knob_col && vr_ln_bwd_col_launch &&
-        vr_ln_bwd_col_launch(dy, x, w, mean, rstd, keep, dx_in, dx_out, dw, db, gt_out, gt_scale, gt_keep, M, C, rows_per_sample, dy_dtype,
-                             copies, knob_rows, (hipStream_t)stream)) {
-        VR_CHECK_LAUNCH();
-        return VR_OK;
-    }
 #define VR_LN_BWD(NV)                                                                                                  \
     if (dy_dtype == VR_F32)                                                                                            \
         hipLaunchKernelGGL((ln_bwd_kernel<float, NV>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, x, w, \

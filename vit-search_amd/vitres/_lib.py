@@ -40,13 +40,6 @@ class LnEpilogue(ctypes.Structure):
                 ("gt_out", c_void_p), ("gt_scale", c_void_p), ("gt_keep", c_void_p), ("grad_copies", c_int32)]
 
 
-class MlpArgs(ctypes.Structure):
-    _fields_ = [("y", c_void_p), ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p), ("resid", c_void_p),
-                ("out", c_void_p), ("scale", c_void_p), ("keep_in", c_void_p), ("keep_hid", c_void_p), ("keep_out", c_void_p),
-                ("M", c_int32), ("C", c_int32), ("F", c_int32), ("ldy", c_int32), ("ldw1", c_int32), ("ldw2", c_int32),
-                ("ldo", c_int32), ("rows_in", c_int32), ("map", RowMap)]
-
-
 MAX_ZERO_RANGES = 24
 
 
@@ -67,7 +60,6 @@ SYMBOLS = {
     "vr_gemm_ln": [ctypes.POINTER(GemmArgs), ctypes.POINTER(LnEpilogue), c_void_p],
     "vr_gemm_ln_supported": [c_int32],
     "vr_gemm_ws_bytes": [],
-    "vr_experimental": [],
     "vr_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "vr_adamw_flat": [c_void_p] * 6 + [c_float, c_void_p, c_void_p, c_int32, c_int64, c_void_p],
     "vr_adamw_flat_dev": [c_void_p] * 6 + [c_float, c_void_p, c_void_p, c_int32, c_int64, c_void_p],
@@ -115,12 +107,6 @@ SYMBOLS = {
     "vr_conv3x3_res_patch": [c_void_p] * 4 + [c_int32] * 7 + [c_void_p],
 }
 
-# include/vitres_hip_experimental.h: present only in `make EXPERIMENTAL=1` builds (VITRES_LIB=.../libvitres_hip_exp.so)
-EXPERIMENTAL_SYMBOLS = {
-    "vr_mlp_fwd": [ctypes.POINTER(MlpArgs), c_void_p],
-    "vr_mlp_fwd_supported": [c_int32, c_int32],
-}
-
 _lib = None
 
 
@@ -140,18 +126,8 @@ def lib():
                 raise RuntimeError("libvitres_hip.so does not export %s" % name) from e
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
-        if L.vr_experimental():
-            for name, argtypes in EXPERIMENTAL_SYMBOLS.items():
-                fn = getattr(L, name)
-                fn.argtypes = argtypes
-                fn.restype = ctypes.c_int
         _lib = L
     return _lib
-
-
-def experimental():
-    """True when the loaded library carries the kernel forms of csrc/experimental/ (an EXPERIMENTAL=1 build)."""
-    return bool(lib().vr_experimental())
 
 
 _ERR = {-1: "VR_EINVAL (bad argument)", -2: "VR_EALIGN (pointer / leading-dimension alignment)",

@@ -403,11 +403,6 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     return out
 
 
-# VITRES_FUSED_MLP: 1 = forward-only MLPs of first-stage width (C <= 320) run as one vr_mlp_fwd launch unless the fc2 + LayerNorm
-# kernel applies (width <= 256); 2 = always where supported; 0 = never
-FUSED_MLP = int(_os.environ.get('VITRES_FUSED_MLP', '0'))
-
-
 def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save, pre=None, next_ln=None):
     B, N, C = x.shape
     M = B * N
@@ -421,24 +416,6 @@ def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save, pre=N
         u = torch.empty((B, N, F), dtype=dt, device=x.device)
         K.gemm(y, p["fc1"].w_c, u, out2=h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b,
                act=(2 if dt == torch.bfloat16 else 1), keep_n=mlp_keep, rows_in=N, keep_k=embed_keep)
-    elif FUSED_MLP and K.mlp_fwd_supported(y, C, F) and (FUSED_MLP >= 2 or not _ln_fusable(y, C, next_ln)):
-        # forward-only, first-stage widths: ONE kernel for fc1 -> GELU -> mask -> fc2 -> scale / mask / residual (vr_mlp_fwd); the
-        # hidden tensor is never written.  The kernel walks 128-row tiles with one workgroup per CU: a sample of 256 patch tokens
-        # + 1 class token would leave it a 129th-row tile per sample pair, so the class-token rows (one per sample) go through the
-        # two-GEMM form with row maps and the fused kernel sees B x 256 rows
-        x2 = torch.empty_like(x)
-        T = 1 if (N % 128 == 1 and B >= 8) else 0
-        P = N - T
-        K.mlp_fwd(y, p["fc1"].w_c, p["fc1"].b, p["fc2"].w_c, p["fc2"].b, x, x2, M=B * P, C=C, F=F, ldw1=p["fc1"].ld,
-                  ldw2=p["fc2"].ld, rows_in=P, scale=scale, keep_in=embed_keep, keep_hid=mlp_keep, keep_out=out_keep,
-                  row_map=(P, N, T) if T else None)
-        if T:
-            ht = torch.empty((B * T, F), dtype=dt, device=x.device)
-            K.gemm(y, p["fc1"].w_c, ht, M=B * T, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b, act=1,
-                   keep_n=mlp_keep, rows_in=T, keep_k=embed_keep, a_map=(T, N, 0))
-            K.gemm(ht, p["fc2"].w_c, x2, M=B * T, N=C, K=F, lda=F, ldb=p["fc2"].ld, ldc=C, bias=p["fc2"].b, scale=scale,
-                   keep_n=out_keep, resid=x, rows_in=T, keep_k=mlp_keep, c_map=(T, N, 0))
-        return x2, None, None
     else:                                       # forward-only: the pre-activation is not kept, fc1 writes gelu(u) alone
         u = None
         K.gemm(y, p["fc1"].w_c, h, M=M, N=F, K=C, lda=C, ldb=p["fc1"].ld, ldc=F, bias=p["fc1"].b, act=1,

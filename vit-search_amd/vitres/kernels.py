@@ -47,13 +47,13 @@ def _rm(m):
     return RowMap(*(m or IDENT))
 
 
-# Workspaces of the stream-K GEMM (vr_gemm_args.ws): one per (device, role).  A role is a chain of launches that never overlap
+# Workspaces of the split-K GEMM form (vr_gemm_args.ws): one per (device, role).  A role is a chain of launches that never overlap
 # one another: 0 = the main stream, 1.. = the side streams of vitres.functional (which switches the role around what it runs
 # there).  Created zeroed on first use -- outside graph capture (engine.GraphedTrainStep calls ensure_workspaces first): a launch
 # that finds none while capturing simply runs without tile sharing.
 _WS = {}
 _WS_ROLE = [0]
-_WIDE_ON = __import__("os").environ.get("VITRES_NT_WIDE", "0") != "0" or __import__("os").environ.get("VITRES_NT_SPLIT", "0") != "0"
+_WIDE_ON = __import__("os").environ.get("VITRES_NT_SPLIT", "0") != "0"      # the split-K form of gemm_nt.hip (opt-in) needs the workspace
 
 
 class ws_role:
@@ -96,8 +96,8 @@ def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=Fals
                scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
                a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0, ws="auto"):
     args = GemmArgs()
-    if isinstance(ws, str):         # "auto": the role's workspace, when the 8-wave stream-K kernel can be chosen at all (opt-in)
-        ws = _workspace(a.device) if ((_WIDE_ON or (sched & (8 | 32 | 64))) and not a_trans and a.dtype == torch.bfloat16 and a.is_cuda and
+    if isinstance(ws, str):         # "auto": the role's workspace, when the split-K form can be chosen at all (opt-in)
+        ws = _workspace(a.device) if ((_WIDE_ON or (sched & (32 | 64))) and not a_trans and a.dtype == torch.bfloat16 and a.is_cuda and
                                       M >= 256 and K >= 128) else None
     if ws is not None:
         args.ws, args.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
@@ -114,37 +114,6 @@ def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=Fals
     args.act, args.atomic, args.split_k, args.rows_in = act, int(atomic), split_k, rows_in
     args.a_map, args.b_map, args.c_map = _rm(a_map), _rm(b_map), _rm(c_map)
     return args
-
-
-def mlp_fwd_supported(y, C, F):
-    """vr_mlp_fwd covers this MLP (bf16 activations, first-stage widths; EXPERIMENTAL builds of the library only)."""
-    return y.dtype == torch.bfloat16 and y.is_cuda and _lib.experimental() and bool(_lib.lib().vr_mlp_fwd_supported(C, F))
-
-
-def mlp_fwd(y, w1, b1, w2, b2, resid, out, *, M, C, F, ldw1, ldw2, rows_in=0, scale=None, keep_in=None, keep_hid=None,
-            keep_out=None, row_map=None):
-    """out = resid + scale * mask_out(mask_hid(gelu(y W1^T + b1)) W2^T + b2)  (vr_mlp_fwd: forward-only fused MLP; the hidden
-    tensor is never written).  y bf16 [rows, C]; resid / out fp32 [rows, C]; row_map: the M rows of the problem among them."""
-    a = _lib.MlpArgs()
-    a.y, a.w1, a.b1, a.w2, a.b2 = _p(y), _p(w1), _p(b1), _p(w2), _p(b2)
-    a.resid, a.out, a.scale = _p(resid), _p(out), _p(scale)
-    a.keep_in, a.keep_hid, a.keep_out = _p(keep_in), _p(keep_hid), _p(keep_out)
-    a.M, a.C, a.F, a.ldy, a.ldw1, a.ldw2, a.ldo, a.rows_in = M, C, F, C, ldw1, ldw2, C, rows_in
-    a.map = _rm(row_map)
-    assert w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and resid.dtype == torch.float32 and out.dtype == torch.float32
-    ev = None
-    if PROFILE is not None:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
-    _lib.check(_lib.lib().vr_mlp_fwd(ctypes.byref(a), _stream()), "vr_mlp_fwd")
-    if ev is not None:
-        ev[1].record()
-        fl = _kept_flops(M, F, C, rows_in, keep_in, keep_hid) + _kept_flops(M, C, F, rows_in, keep_hid, keep_out)
-        by = M * C * (2 + 4 + 4) + 2 * F * C * 2
-        PROFILE.append(("mlp_fwd", fl, 4.0 * M * C * F, by, ev[0], ev[1]))
-        if PROFILE_DESC is not None:
-            PROFILE_DESC.append("mlp_fwd M%d C%d F%d" % (M, C, F))
-    return out
 
 
 def gemm_ln_supported(a, N, ldc):
