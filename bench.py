@@ -224,6 +224,7 @@ def run_evo_eval(args, rank, world, device):
     roof = None
     if args.profile_steps > 0:
         K.PROFILE = []
+        K.PROFILE_ATTN = []
         K.PROFILE_DESC = [] if args.launch_table else None
         for i in range(args.profile_steps):
             torch.cuda.synchronize()
@@ -479,6 +480,7 @@ def main():
     roof = None
     if args.profile_steps > 0:
         K.PROFILE = []
+        K.PROFILE_ATTN = []
         K.PROFILE_DESC = [] if args.launch_table else None
         for i in range(args.profile_steps):
             # eager launches are host-bound (~10 us of Python per kernel): with an idle GPU every event pair would also time the
@@ -500,6 +502,18 @@ def main():
             a[3] += 1
             a[4] += dense
         K.PROFILE = None
+        # SURVEY 8d "MFMA utilisation on the transformer blocks": kept FLOPs of every block Linear (forward, data gradient, weight
+        # gradient, LayerNorm-fused forms: the launches without row maps) and of the attention kernels over the time of exactly those
+        # launches, against the dense bf16 MFMA peak
+        blk_fl = sum(v[1] for k, v in agg.items() if k[3] != 1) + sum(f for f, _, _ in K.PROFILE_ATTN)
+        blk_s = sum(v[0] for k, v in agg.items() if k[3] != 1) + sum(a.elapsed_time(b) * 1e-3 for _, a, b in K.PROFILE_ATTN)
+        blocks_util = {"value": round(blk_fl / blk_s / (MFMA_PEAK[args.dtype] * 1e12), 4) if blk_s > 0 else None,
+                       "kept_gflop_per_step": round(blk_fl / args.profile_steps / 1e9, 1),
+                       "kernel_ms_per_step": round(blk_s / args.profile_steps * 1e3, 3), "target": 0.40,
+                       "note": "kept FLOPs of the transformer blocks' GEMMs (forward, data and weight gradients) and attention kernels / "
+                               "(sum of their eager launch times x dense MFMA peak); launches on two streams overlap in the step, so the "
+                               "step-level figure is higher: kept_gflop_per_step / ms_per_step"}
+        K.PROFILE_ATTN = None
         def kname(k):
             dt_, at, bt, mapped = k
             if mapped == 2:
@@ -575,6 +589,7 @@ def main():
                         "on) around every vr_gemm launch of %d extra eager steps after the timed region, each queued behind a 40 ms GPU spin so that "
                         "the pairs time the GPU, not the host's launch gaps (roofline.graph has the replayed graph's "
                         "averages)" % args.profile_steps,
+                "blocks_mfma_util": blocks_util,
                 "all_gemm_ms_per_step": round(gemm_sec * 1e3, 3),
                 "all_gemm_kinds": {k: {
                     "tflops_kept": round(v[1] / v[0] / 1e12, 2), "tflops_dense_equiv": round(v[4] / v[0] / 1e12, 2),

@@ -235,3 +235,52 @@ def test_c5_sr_small_candidates_on_resident_supernet_match_sliced_subnets():
             assert rel(got, want) < tol, (ci, dt, rel(got, want))
     scores = evo_eval.score_population(sup, cands, [(x.to(DEV), labels.to(DEV))])
     assert len(scores) == 8 and all(0.0 <= s_ <= 100.0 for s_ in scores)
+
+
+def test_full_size_bf16_step_trains_like_the_fp32_step():
+    """the BENCHED configuration -- sr_tiny supernet, B = 128, example_per_arch 64, drop_path 0.2, hipGraph
+    replay + FlatAdamW -- as a training run in both precisions from ONE state: 20 optimisation steps on one batch with hard targets,
+    a different pair of sub-networks every step (the same in both runs), the same DropPath draws.  The fp32 kernels are the path
+    that meets the 1e-3 gate against the reference (test_full_size_fp32_logits_loss_masks above); the bf16 path (bf16 operands, fp32
+    accumulation / residual stream / LayerNorm / softmax / loss / master weights) must follow its loss trajectory step by step at
+    C = 1024 / K = 3072, where the micro supernet's trajectory test says nothing.  Band: see the assert (measured values printed)."""
+    from vitres import engine
+    from vitres.optim import FlatAdamW
+    from vitres.losses import SoftTargetCrossEntropy
+    crit = SoftTargetCrossEntropy()
+    B = 128
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 3, 224, 224, generator=g).to(DEV)
+    labels = torch.randint(0, 1000, (B,), generator=g)
+    t = torch.nn.functional.one_hot(labels, 1000).float().to(DEV)
+    pt = t[:, None, :].repeat(1, 16, 1).contiguous()
+    traj = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        prod = make(recipe.SR_TINY_DEF, "sr_tiny", 0.2, epa=64)
+        sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in prod.state_dict().items()], 4343)
+        prod.load_state_dict(sd)
+        prod = prod.to(DEV).set_compute_dtype(dtype)
+        prod.train()
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+        opt = FlatAdamW(prod, engine.param_groups_weight_decay(prod, 0.05), lr=5e-4)
+        if dtype == torch.bfloat16:
+            opt.own_shadow()
+        prod.drop_path_generator(seed=5)
+        step = engine.GraphedTrainStep(prod, crit, x, t, pt, "seq")
+        losses = []
+        for it in range(20):
+            torch.manual_seed(9000 + it)                            # the same architectures in both runs
+            losses.append(step(x, t, pt, epoch=31, train_iter=it, arch_sample="multi").clone())
+            opt.step()
+        traj[dtype] = torch.stack(losses).cpu().double()
+        del step, opt, prod
+        torch.cuda.empty_cache()
+    f, b = traj[torch.float32], traj[torch.bfloat16]
+    rel_ = ((b - f).abs() / f.abs())
+    msg = "fp32 %s | bf16 %s | max rel %.4f, mean rel %.4f" % (" ".join("%.3f" % v for v in f), " ".join("%.3f" % v for v in b),
+                                                             rel_.max(), rel_.mean())
+    print(msg)
+    assert torch.isfinite(f).all() and torch.isfinite(b).all(), msg
+    assert f[-1] < 0.9 * f[0] and b[-1] < 0.9 * b[0], msg          # both runs learn the batch
+    assert rel_.max() < 5e-3 and rel_.mean() < 2e-3, msg          # (measured round 5: 1e-4 / 3e-5)

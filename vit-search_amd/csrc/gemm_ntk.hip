@@ -364,7 +364,18 @@ bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     static const int knob_buf = std::getenv("VITRES_NTK_BUF") ? std::atoi(std::getenv("VITRES_NTK_BUF")) : 0;
     // sched bits 0x1800: tile override (1: 128 x 128, 2: 64 x 128, 3: 64 x 64), bits 0x600: slices-in-flight override (tests)
     const int s_tile = (a.sched >> 11) & 3, s_buf = (a.sched >> 9) & 3;
-    const int tile = s_tile ? s_tile : knob_tile ? knob_tile : (t128 >= 2LL * n_cu ? 1 : (t64 >= 2LL * n_cu ? 2 : 3));
+    // (in-graph sweep of all nine tile x depth combinations, profiles/r05_ntk_policy_sweep.txt: 64 x 128 tiles for the forms with a
+    // bf16 side operand or two outputs once the 128 x 128 grid is below four / six per CU -- they run beside the weight-gradient
+    // group's resident workgroups, which leave room for three 25 KB workgroups but only two 34 KB ones --, and 64 x 64 only when
+    // even the 64 x 128 grid leaves CUs empty)
+    static const int knob_pol = std::getenv("VITRES_NTK_POLICY") ? std::atoi(std::getenv("VITRES_NTK_POLICY")) : 1;
+    int auto_tile = t128 >= 2LL * n_cu ? 1 : (t64 >= 2LL * n_cu ? 2 : 3);
+    if (knob_pol) {
+        if (auto_tile == 3 && t64 >= n_cu) auto_tile = 2;
+        if (auto_tile == 1 && a.dact_u && a.b_trans) auto_tile = 2;                       // fc2 data gradient (times the saved gelu')
+        if (auto_tile == 1 && gelu && t128 < 4LL * n_cu) auto_tile = 2;                   // fc1 forward of the second stage
+    }
+    const int tile = s_tile ? s_tile : knob_tile ? knob_tile : auto_tile;
     const long long wgs = tile == 1 ? t128 : (tile == 2 ? t64 : (long long)((a.M + 63) / 64) * ((a.N + 63) / 64));
     int nbuf = s_buf ? s_buf : knob_buf ? knob_buf : (wgs >= 3LL * n_cu || a.K < 4 * BK ? 1 : (a.K >= 8 * BK ? 3 : 2));
     if (a.b_trans) {

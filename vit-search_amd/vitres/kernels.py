@@ -16,6 +16,7 @@ IDENT = (0, 0, 0)
 # bench.py instrumentation: when a list, every vr_gemm launch is bracketed by HIP events on torch's current stream
 # (the stream the kernel is launched on) and (kind, flops, bytes, ev0, ev1) is appended.
 PROFILE = None
+PROFILE_ATTN = None       # with PROFILE: (kept FLOPs, event, event) per attention launch
 PROFILE_DESC = None       # with PROFILE: one description per entry (tools/gemm_launches.py)
 
 
@@ -379,19 +380,37 @@ def ln_grad_reduce(slots, copies):
     _lib.check(_lib.lib().vr_ln_grad_reduce(arr, len(slots), copies, _stream()), "vr_ln_grad_reduce")
 
 
+def _attn_profiled(call, keep_hd, B, N, H, D, passes):
+    """bench.py's `roofline.blocks_mfma_util`: kept FLOPs (4 N^2 per kept head channel and pass pair) and HIP events of one launch."""
+    kept = float(keep_hd.sum().item()) if keep_hd is not None else float(B * H * D)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call()
+    e1.record()
+    PROFILE_ATTN.append((passes * 2.0 * N * N * kept, e0, e1))
+
+
 def attn_fwd(qkv, keep_hd, B, N, H, D, scale):
     o = torch.empty((B, N, H * D), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-    _lib.check(_lib.lib().vr_attn_fwd(_p(qkv), _p(o), _p(lse), _p(keep_hd), B, N, H, D, scale, _dt(qkv), _stream()),
-               "vr_attn_fwd")
+    call = lambda: _lib.check(_lib.lib().vr_attn_fwd(_p(qkv), _p(o), _p(lse), _p(keep_hd), B, N, H, D, scale, _dt(qkv), _stream()),
+                              "vr_attn_fwd")
+    if PROFILE_ATTN is None:
+        call()
+    else:
+        _attn_profiled(call, keep_hd, B, N, H, D, 2)                # Q K^T and P V
     return o, lse
 
 
 def attn_bwd(qkv, o, d_o, lse, keep_hd, B, N, H, D, scale):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-    _lib.check(_lib.lib().vr_attn_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), _p(delta), _p(dqkv), _p(keep_hd), B, N, H, D,
-                                      scale, _dt(qkv), _stream()), "vr_attn_bwd")
+    call = lambda: _lib.check(_lib.lib().vr_attn_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), _p(delta), _p(dqkv), _p(keep_hd), B, N, H, D,
+                                                     scale, _dt(qkv), _stream()), "vr_attn_bwd")
+    if PROFILE_ATTN is None:
+        call()
+    else:
+        _attn_profiled(call, keep_hd, B, N, H, D, 5)                # S recomputed, dP, dV, dQ, dK
     return dqkv
 
 
