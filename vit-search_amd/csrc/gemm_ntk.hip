@@ -19,6 +19,7 @@
 //
 // Covered: FAST epilogue forms (N, ldc, ldu, n_period multiples of 8), K a multiple of 64 and at most 4096, FEAT 0 - 3 (no
 // positional embedding), operands below 4 GB.  Everything else stays with gemm_nt.hip / gemm.hip (vr_gemm_ntk_launch returns false).
+#include <algorithm>
 #include <cstdlib>
 
 #include "gemm_nt_parts.h"
@@ -373,11 +374,21 @@ bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     if (knob_pol) {
         if (auto_tile == 3 && t64 >= n_cu) auto_tile = 2;
         if (auto_tile == 1 && a.dact_u && a.b_trans) auto_tile = 2;                       // fc2 data gradient (times the saved gelu')
-        if (auto_tile == 1 && gelu && t128 < 4LL * n_cu) auto_tile = 2;                   // fc1 forward of the second stage
+        if (auto_tile == 1 && gelu && a.C2 && t128 < 4LL * n_cu) auto_tile = 2;           // fc1 forward (training: two outputs) of the second stage
     }
     const int tile = s_tile ? s_tile : knob_tile ? knob_tile : auto_tile;
     const long long wgs = tile == 1 ? t128 : (tile == 2 ? t64 : (long long)((a.M + 63) / 64) * ((a.N + 63) / 64));
-    int nbuf = s_buf ? s_buf : knob_buf ? knob_buf : (wgs >= 3LL * n_cu || a.K < 4 * BK ? 1 : (a.K >= 8 * BK ? 3 : 2));
+    // slices in flight: as many as LDS allows WITHOUT lowering the number of workgroups the grid gives a CU (a 96 KB ring that leaves
+    // a CU one workgroup where three single-buffer ones would run loses: candidate scoring, M4352 N2304 K1280 36 -> 44 us)
+    int auto_buf = 1;
+    if (a.K >= 4 * BK) {
+        const int stage_kb = tile == 1 ? 32 : (tile == 2 ? 24 : 16);
+        const int per_cu = (int)std::max<long long>(1, (2 * wgs + n_cu) / (2LL * n_cu));          // workgroups per CU, rounded
+        const int want = std::min(per_cu, tile == 1 ? 4 : 5);
+        for (int nb = (a.K >= 8 * BK ? 3 : 2); nb >= 1; --nb)
+            if (160 / (nb * stage_kb + 2) >= want) { auto_buf = nb; break; }
+    }
+    int nbuf = s_buf ? s_buf : knob_buf ? knob_buf : auto_buf;
     if (a.b_trans) {
         if (of32 || feat != 0 || gelu || a.b_map.rpi != 0 || a.ldb < (a.N + 7) / 8 * 8) return false;
         if (a.dact_u) {
