@@ -473,16 +473,6 @@ template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t 
             (long long)SPLIT_TICKET_BYTES + t128 * 2 * (128LL * 128 * 4) <= a.ws_bytes) { S = 2; stages = (a.sched & 1) ? 2 : 1; }   // forced (tests)
         if (S >= 2 && (stages == 2 ? launch_split<TO, EPI, 2>(a, stream, S) : launch_split<TO, EPI, 1>(a, stream, S))) return;
     }
-    // VITRES_NT_RING (round 5 experiment): ring-pipelined tiles for grids that leave a CU one or two workgroups and walk >= 8 slices
-    //   1: 64 x 128 tiles, ring of 3 (72 KB, two per CU) where the pair form runs today;  2: 128 x 128, ring of 3 (96 KB, one per CU);
-    //   3: 128 x 128, ring of 4 (128 KB);  4: 64 x 128, ring of 4 (96 KB)
-    static const int knob_ring = std::getenv("VITRES_NT_RING") ? std::atoi(std::getenv("VITRES_NT_RING")) : 0;
-    if (knob_ring && !knob && t128 < 2LL * n_cu && a.K >= 8 * BK) {
-        if (knob_ring == 1 && tile == 2) return launch2<TO, EPI, 2, 4, 3>(a, stream, fast);
-        if (knob_ring == 4 && tile == 2) return launch2<TO, EPI, 2, 4, 14>(a, stream, fast);
-        if (knob_ring == 2) return launch2<TO, EPI, 4, 4, 13>(a, stream, fast);
-        if (knob_ring == 3) return launch2<TO, EPI, 4, 4, 14>(a, stream, fast);
-    }
     if (tile == 1) launch2<TO, EPI, 4, 4>(a, stream, fast);
     else if (tile == 2) {
         // every tile resident at three workgroups per CU and >= 8 slices: two slices per round (STAGES = 2)

@@ -23,27 +23,14 @@
 #include <cstdlib>
 
 #include "gemm_nt_parts.h"
+#include "lds_dma.h"
 
 namespace vr_gemm_nt {
 
 constexpr int KTHR = 256;
-typedef __attribute__((address_space(3))) char lds_char_k;
-typedef int v4i_k __attribute__((ext_vector_type(4)));
-
-// raw buffer descriptor (gfx950): base, stride 0, num_records bytes, 32-bit data format
-__device__ __forceinline__ v4i_k make_rsrc(const void* ptr, unsigned num_records) {
-    const unsigned long long a = (unsigned long long)(uintptr_t)ptr;
-    v4i_k r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
-    r.z = __builtin_amdgcn_readfirstlane((int)num_records);
-    r.w = 0x00020000;
-    return r;
-}
-// one LDS-DMA piece: 64 lanes x 16 bytes from descriptor + voff (per lane) + soff (scalar) to LDS bytes [lds, lds + 1024)
-__device__ __forceinline__ void dma16(unsigned lds, unsigned voff, v4i_k rsrc, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
+using vr_dma::dma16;
+using vr_dma::make_rsrc;
+typedef vr_dma::v4i v4i_k;
 
 __device__ __forceinline__ int interleave_groups32(int p, int n, int G) {      // gemm_shared.h interleave_groups in 32-bit arithmetic
     if (G <= 1 || n < 2 * G) return p;
@@ -138,7 +125,7 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
     const v4i_k rsA = make_rsrc(p.A, 0xffffff00u);
     const v4i_k rsB = make_rsrc(p.B, BKM ? (unsigned)((long long)p.K * p.ldb * 2) : 0xffffff00u);
     const int stepB = BKM ? BK * p.ldb * 2 : BK * 2;               // bytes a slice advances the weight operand by
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_char_k*)smem;  // LDS byte address of the ring
+    const unsigned lds0 = vr_dma::lds_addr(smem);  // LDS byte address of the ring
 
     // The loads are inline asm (M0 = LDS destination of the piece, written in the same statement): hipcc waits vmcnt(0) in front
     // of the first LDS read that follows a `raw_ptr_buffer_load_lds` BUILTIN -- the slices in flight would be drained every
