@@ -272,6 +272,7 @@ def train_step(model, criterion, optimizer, samples, targets, patch_targets=None
 
 
 RUN_AHEAD = int(os.environ.get("VITRES_RUN_AHEAD", "2"))
+PLAN_COPY_KERNEL = os.environ.get("VITRES_PLAN_COPY", "kernel") == "kernel"     # the per-step plan buffer: kernel reading pinned memory / memcpy
 
 
 class GraphedTrainStep:
@@ -477,7 +478,11 @@ class GraphedTrainStep:
             if slot[1] is not None:
                 slot[1].synchronize()                             # the host runs ahead of the device: the block's last copy is done?
             slot[0].numpy()[:] = flat
-            self.keep_static.copy_(slot[0], non_blocking=True)
+            if PLAN_COPY_KERNEL:
+                from . import kernels as K
+                K.copy_i32_from_pinned(slot[0], self.keep_static.view(-1))
+            else:
+                self.keep_static.copy_(slot[0], non_blocking=True)
             slot[1] = torch.cuda.Event()
             slot[1].record()
         if probe is not None:

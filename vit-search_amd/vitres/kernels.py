@@ -319,6 +319,15 @@ def relayout(src, dst, A, B, C, dst_ld=None, src_ld=None):
     return dst
 
 
+def copy_i32_from_pinned(host, dst):
+    """dst (device int32) = host (pinned int32) by a KERNEL on the current stream -- vr_relayout reading the mapped host pages -- instead
+    of a hipMemcpyAsync: the copy engine's hand-off to and from the compute queue cost ~25 us of idle GPU per training step."""
+    assert host.is_pinned() and host.dtype == torch.int32 and dst.dtype == torch.int32 and dst.is_cuda and host.numel() == dst.numel()
+    n = host.numel()
+    _lib.check(_lib.lib().vr_relayout(host.data_ptr(), dst.data_ptr(), 1, 1, n, n, n, VR_F32, VR_F32, _stream()), "vr_relayout")
+    return dst
+
+
 def cast_bf16(src, dst):
     _lib.check(_lib.lib().vr_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "vr_cast_f32_bf16")
     return dst
