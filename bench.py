@@ -44,9 +44,9 @@ MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}      # dense TFLOP/s, /opt/skills/gui
 
 
 def load_traffic(workload, batch, dtype):
-    """PMC traffic of this workload (tools/traffic_run.sh -> profiles/r04_traffic_<workload>.json), used only when the file was
+    """PMC traffic of this workload (tools/traffic_run.sh -> profiles/r05_traffic_<workload>.json), used only when the file was
     measured on the same workload, per-GPU batch and dtype as this run (its "key"); otherwise `traffic` stays null."""
-    name = "r04_traffic_%s.json" % workload
+    name = "r05_traffic_%s.json" % workload
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
     try:
         tj = json.load(open(path))
@@ -519,7 +519,7 @@ def main():
             if mapped == 2:
                 return "vr_gemm_ntln::ntln_kernel (Linear + LayerNorm epilogue)"
             if dt_ == "bf16" and not at:         # (b_trans data gradients run on the same kernel since round 2: BKM)
-                return "vr_gemm_nt::nt_kernel (forward+dgrad)"
+                return "vr_gemm_nt::nt_kernel (forward+dgrad: gemm_ntk.hip lean-loop kernels + gemm_nt.hip forms)"
             if dt_ == "bf16" and at and bt:
                 return "vr_gemm_tn::tn_group_kernel / tn_kernel (wgrad)"
             if at:
@@ -573,7 +573,7 @@ def main():
         # the same family inside the replayed graph (rocprofv3 trace of this workload, tools/prof_step.sh): eager launches run ~10 %
         # slower than the graph's, so `frac` above is the pessimistic figure
         try:
-            gj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_graph_kernels_%s.json" % args.workload)))
+            gj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_graph_kernels_%s.json" % args.workload)))
         except (OSError, ValueError):
             gj = None
         if gj and gj.get("key") == {"workload": args.workload, "batch": int(B), "dtype": args.dtype}:
@@ -583,7 +583,7 @@ def main():
                 gb_ = roof["algorithmic_bytes_per_launch"] / us / 1e3
                 roof["graph"] = {"avg_launch_us": round(us, 2), "achieved_GBps": round(gb_, 1), "frac_hbm": round(gb_ / HBM_PEAK, 4),
                                  "achieved_TFLOPs_kept": round(roof["flops_per_launch"] / us / 1e6, 2),
-                                 "source": "profiles/r04_graph_kernels_%s.json: %s" % (args.workload, gj["source"])}
+                                 "source": "profiles/r05_graph_kernels_%s.json: %s" % (args.workload, gj["source"])}
         roof.update({
                 "note": "FLOPs and bytes = kept (un-masked) sub-problems only; HIP events (recorded on the stream each kernel is launched "
                         "on) around every vr_gemm launch of %d extra eager steps after the timed region, each queued behind a 40 ms GPU spin so that "
