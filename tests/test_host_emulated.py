@@ -475,3 +475,43 @@ def test_emulated_drop_path_wiring_matches_reference(monkeypatch, et):
         assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
         for n, p in prod.named_parameters():
             assert rel(p.grad, torch.from_numpy(g["grad." + n])) < 5e-4, (n, use_fused)
+
+
+def test_second_model_forward_between_the_parts_of_a_split_backward(monkeypatch):
+    """the pending LayerNorm folds / collected weight-gradient calls are module-global; a training-mode forward of a
+    SECOND model between the parts of another model's split backward must leave them alone (it used to clear them: the first model
+    then lost gradients without an error)."""
+    emu_kernels.install(monkeypatch)
+    from vitres import functional as Fn
+    prod, orc, sd = build_pair(0, "multi", 100)
+    other, _, sd2 = build_pair(0, "multi", 101)
+    for m in (prod, other):
+        m.set_compute_dtype(torch.float32)
+        m.train()
+        m.set_epoch(31)
+        m._ensure_arena(torch.device("cpu"))
+    x, t, pt, _ = recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1)
+    cut, start = prod.split_plan()
+
+    def run(intrude):
+        torch.manual_seed(5)
+        prod.zero_grad(set_to_none=True)
+        cls, pat = prod(x, patch_output_type="seq")
+        prod._bwd_split = cut
+        (O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)).backward()
+        prod._bwd_split = None
+        assert prod._bwd_state is not None
+        if intrude:
+            sentinel = ("sentinel",)                               # (on the CPU emulation the lists are empty between the parts: stand-in entry)
+            Fn._ln_pending.append(sentinel)
+            torch.manual_seed(6)
+            other(x, patch_output_type="seq")                      # training-mode forward of another model
+            assert Fn._ln_pending and Fn._ln_pending[-1] is sentinel
+            Fn._ln_pending.remove(sentinel)
+            # ... while the owner's own next forward, or anybody's once the owner is through, does clear leftovers
+            Fn._ln_pending.append(sentinel)
+            assert Fn.reset_ln_grads(prod) is True and not Fn._ln_pending
+        prod.resume_backward()
+        assert prod._bwd_state is None
+        return prod._arena["gcur"].clone()
+    assert torch.equal(run(True), run(False))

@@ -64,10 +64,24 @@ def flush_ln_grads():
         K.ln_grad_reduce(slots, slots[0][0].shape[0])
 
 
-def reset_ln_grads():
+_pending_owner = [None]          # weakref of the model whose backward filled _ln_pending / _block_wgrads last
+
+
+def claim_pending(model):
+    """Called at the start of a model's backward: the module-global pending lists are its own from here on."""
+    import weakref
+    _pending_owner[0] = weakref.ref(model)
+
+
+def reset_ln_grads(model=None):
     """Drop slots left behind by a backward that raised; returns True if there were any (their rows need re-zeroing).  The
     weight-gradient calls collected for a block that was never flushed go with them: launched by the next backward they
-    would add a dead step's gradients and keep its tensors alive."""
+    would add a dead step's gradients and keep its tensors alive.  The lists are shared by every model of the process: when they
+    belong to ANOTHER model that is between the parts of a split backward (engine.GraphedTrainStep(split_for_sync), resume_backward),
+    they are that model's live state and are left alone."""
+    owner = _pending_owner[0]() if _pending_owner[0] is not None else None
+    if model is not None and owner is not None and owner is not model and getattr(owner, "_bwd_state", None) is not None:
+        return False
     dirty = bool(_ln_pending)
     _ln_pending.clear()
     del _block_wgrads[:]

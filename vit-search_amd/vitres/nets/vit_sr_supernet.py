@@ -758,7 +758,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
 
     def _run_forward(self, x, plan, with_patch, save):
         a = self._arena
-        if save and Fn.reset_ln_grads() and a.get("ln_parts_flat") is not None:      # (a backward died: see _run_backward)
+        if save and Fn.reset_ln_grads(self) and a.get("ln_parts_flat") is not None:      # (a backward died: see _run_backward)
             a["ln_parts_flat"].zero_()
         # engine.GraphedTrainStep(optimizer=..., deferred): the PREVIOUS replay's AdamW update opens this forward -- the head of the
         # arena (tokens, positional embedding, patch embedding, first stage) here, the rest (most parameters) on the side stream
@@ -899,7 +899,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         a["gzeroed"] = False
         # leftovers of a backward that raised: weight-gradient calls collected for a block and never launched (join_side would
         # launch them first -- into the arena just zeroed) and LayerNorm partial rows never folded
-        stale = Fn.reset_ln_grads()
+        stale = Fn.reset_ln_grads(self)
+        Fn.claim_pending(self)
         Fn.join_side()                     # transposed weight shadows (issued beside the forward)
         if Fn.LN_COPIES > 1:
             self._ln_parts()
