@@ -62,7 +62,7 @@ __device__ __forceinline__ int max_keep_wave(const int* keep, int s_lo, int s_hi
     return mk;
 }
 
-template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM>
+template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM, bool DEEP_EPI = false>
 __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gemm_args p) {
     constexpr int BM = 32 * MI, WROWS = 16 * MI;
     constexpr int BN = 32 * NJ, WCOLS = 16 * NJ;
@@ -292,12 +292,23 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
         __syncthreads();
     }
 
-    epilogue<TO, EPI, true, MI, NJ, FEAT>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wm * WROWS, n0 + wn * WCOLS,
-                                         lane);
+    // side operands of the epilogue (fp32 residual rows, saved gelu'): with two 16-row rounds per wave all of them are requested up
+    // front (DEPTH = MI: 32 / 16 registers) -- one exposed HBM latency per tile instead of one per round
+    constexpr int EDEPTH = (MI == 2 && DEEP_EPI) ? 2 : 1;
+    epilogue<TO, EPI, true, MI, NJ, FEAT, EDEPTH>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wm * WROWS, n0 + wn * WCOLS,
+                                                 lane);
 }
 
 template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM> void klaunch(const vr_gemm_args& a, hipStream_t stream) {
     const long long total = (long long)((a.M + 32 * MI - 1) / (32 * MI)) * ((a.N + 32 * NJ - 1) / (32 * NJ));
+    static const int knob_deep = std::getenv("VITRES_NTK_DEEP") ? std::atoi(std::getenv("VITRES_NTK_DEEP")) : 1;
+    constexpr bool SIDE = (EPI == EPI_STORE && FEAT >= 2) || EPI == EPI_DMUL;
+    if constexpr (MI == 2 && SIDE) {
+        if (knob_deep) {
+            hipLaunchKernelGGL((ntk_kernel<TO, EPI, MI, NJ, NBUF, FEAT, BKM, true>), dim3((unsigned)total), dim3(KTHR), 0, stream, a);
+            return;
+        }
+    }
     hipLaunchKernelGGL((ntk_kernel<TO, EPI, MI, NJ, NBUF, FEAT, BKM>), dim3((unsigned)total), dim3(KTHR), 0, stream, a);
 }
 
