@@ -383,8 +383,11 @@ bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
         const int stage_kb = tile == 1 ? 32 : (tile == 2 ? 24 : 16);
         const int per_cu = (int)std::max<long long>(1, (2 * wgs + n_cu) / (2LL * n_cu));          // workgroups per CU, rounded
         const int want = std::min(per_cu, tile == 1 ? 4 : 5);
+        // data gradients run beside the weight-gradient group, whose two resident workgroups hold 64 KB of a CU's LDS
+        static const int knob_bwd_kb = std::getenv("VITRES_NTK_BWD_LDS_KB") ? std::atoi(std::getenv("VITRES_NTK_BWD_LDS_KB")) : 96;
+        const int lds_kb = a.b_trans ? knob_bwd_kb : 160;
         for (int nb = (a.K >= 8 * BK ? 3 : 2); nb >= 1; --nb)
-            if (160 / (nb * stage_kb + 2) >= want) { auto_buf = nb; break; }
+            if (lds_kb / (nb * stage_kb + 2) >= want) { auto_buf = nb; break; }
     }
     int nbuf = s_buf ? s_buf : knob_buf ? knob_buf : auto_buf;
     if (a.b_trans) {
