@@ -110,6 +110,8 @@ __device__ __forceinline__ void tn_body(const vr_gemm_args& p, const int bid) {
     // read-modify-write; a fully masked tile must then write its zeros instead of leaving
     const bool store = p.atomic == 2;
     if (ntiles == 0 && !store) return;
+    const bool nochunk = (p.sched & 0x8000) != 0;                                // (sched 0x8000 / VITRES_DBG_TN=4: A/B aid)
+    const bool skipm = nochunk || !p.keep_k || (p.k_period > 0 && (p.k_period & 7)), skipn = nochunk || !p.keep_n || (p.n_period > 0 && (p.n_period & 7));
 
     // ---- LDS-DMA source addressing: piece h of this wave = slice tokens (wave*PPW + h)*TPP .. ; lane -> (token, slot) ----
     const char* gA[PPW];
@@ -123,7 +125,11 @@ __device__ __forceinline__ void tn_body(const vr_gemm_args& p, const int bid) {
         const int c = (lane % SLOTS) ^ G::swz(tk);
         // channel chunks past the matrix edge read the row's own padding (lda, ldb >= roundup(M / N, 8)) or, past that,
         // the zero page; their products only reach outputs that are not stored
-        const bool aok = m0 + c * 8 + 8 <= p.lda, bok = n0 + c * 8 + 8 <= p.ldb;
+        // ... and so do the chunks beyond the largest kept prefix of this token range (round 5): they hold exact zeros by the
+        // contract of keep_k / keep_n, and a tile that straddles the prefix would stream them from HBM (a width of 160 kept of 256
+        // read as 256: reads were 1.8x the kept-width bytes).  Periods that are not multiples of 8 keep every chunk.
+        const bool ak = skipm || kept_col(m0 + c * 8, p.k_period, kmax), bk = skipn || kept_col(n0 + c * 8, p.n_period, nmax);
+        const bool aok = m0 + c * 8 + 8 <= p.lda && ak, bok = n0 + c * 8 + 8 <= p.ldb && bk;
         tok[h] = tk;
         const long long ra = MAPPED ? 0 : (long long)(kbeg + tk) * p.lda, rb = MAPPED ? 0 : (long long)(kbeg + tk) * p.ldb;
         gA[h] = aok ? reinterpret_cast<const char*>(p.A) + (ra + m0 + c * 8) * 2 : nullptr;
