@@ -55,6 +55,8 @@ def trunc_normal_(t, std):
     return nn.init.trunc_normal_(t, mean=0., std=std, a=-2., b=2.)
 
 
+_SKIP_DROPPED = __import__("os").environ.get("VITRES_SKIP_DROPPED_LAYERS", "1") != "0"
+
 class BypassBlock(nn.Module):
     """Removed transformer block (exists == 0): identity, resets the layer mask (reference :50-56)."""
 
@@ -495,6 +497,14 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                     cur = embed_keep if cur is None else gmin(cur, embed_keep)
                 km = samp(cd_m, fo)
                 dp = tr and has_dp
+                # a dropped layer (layer keep 0 for an architecture group, supernet_blocks.py:243,251: both branch outputs are
+                # multiplied by the layer mask) contributes exactly nothing -- no output, no parameter gradient: its attention / MLP
+                # widths are zeroed in the rows the KERNELS read (the sampled values, `groups`, are untouched), so that the masked-work
+                # rules skip the qkv / fc1 GEMMs, the attention cores and their backward for those samples instead of computing
+                # values the layer mask then discards (VITRES_SKIP_DROPPED_LAYERS=0: compute them)
+                if _SKIP_DROPPED and cur is not None and ka is not None and km is not None and np.any(np.asarray(cur) == 0):
+                    ka = np.where(np.asarray(cur) > 0, ka, 0)
+                    km = np.where(np.asarray(cur) > 0, km, 0)
                 plan.layers.append({"embed": e_idx, "attn": add(ka), "mlp": add(km), "out": add(cur),
                                     "dp": (n_dp if dp else None)})
                 n_dp += 2 if dp else 0
