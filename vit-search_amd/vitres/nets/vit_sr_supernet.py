@@ -610,6 +610,15 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             if plan.scales_host is None:
                 plan.scales_host = self._dp_scales_host(plan)
             flat[nk:] = plan.scales_host.reshape(-1).view(np.int32)
+            # a sample whose branch DropPath dropped (scale 0: nets/drop.py:21-26 multiplies the branch output by it) gets nothing
+            # from that branch and gives its parameters no gradient: the attention / MLP width the KERNELS read for it is zeroed, so
+            # that its attention cores (and the GEMM tiles that hold only such samples) are skipped instead of computed and discarded
+            if _SKIP_DROPPED and nk and self.training and not getattr(plan, "_dp_folded", False):
+                kh = flat[:nk].reshape(plan.keeps_host.shape)
+                for L in plan.layers:
+                    if L is not None and L.get("dp") is not None and L.get("attn") is not None and L.get("mlp") is not None:
+                        kh[L["attn"]][plan.scales_host[L["dp"]] == 0] = 0
+                        kh[L["mlp"]][plan.scales_host[L["dp"] + 1] == 0] = 0
         return flat, nk
 
     def attach_plan_buffer(self, plan, dev_flat, nk):
