@@ -16,6 +16,7 @@ from .nets.supernet_blocks import Block
 from .nets.vit_sr_supernet import SpatialReductionPatchEmbedding, _Plan
 
 _T_TRANS, _T_SR = 1, 3
+_SKIP_REMOVED = __import__("os").environ.get("VITRES_SKIP_DROPPED_LAYERS", "1") != "0"
 
 
 def plan_for_subnet(model, sub_network_def, batch):
@@ -45,7 +46,10 @@ def plan_for_subnet(model, sub_network_def, batch):
             cur = embed_keep if exists else 0                    # removed block == layer keep 0 (BypassBlock)
             if layer_keep is not None and blk.layer_drop is not None:
                 cur = min(cur, layer_keep)
-            plan.layers.append({"embed": e_idx, "attn": row(hd), "mlp": row(hidden), "out": row(cur), "dp": None})
+            # (a removed block's branches are multiplied by layer keep 0: the widths the kernels read for it are 0 as well, so that its
+            # qkv / fc1 GEMMs and attention cores are skipped instead of computed at the supernet's full width and discarded)
+            skip = (not exists) and _SKIP_REMOVED
+            plan.layers.append({"embed": e_idx, "attn": row(0 if skip else hd), "mlp": row(0 if skip else hidden), "out": row(cur), "dp": None})
             # reference semantics: BypassBlock / blocks without layer_drop reset the layer mask to the embed mask
             layer_keep = None
         elif isinstance(blk, SpatialReductionPatchEmbedding):
