@@ -98,7 +98,7 @@ class SpatialReductionPatchEmbedding(nn.Module):
 class _Plan:
     """Host-side description of one forward: which keep vector / drop-path scale each layer uses."""
     __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch", "n_dp", "order", "dp_noise", "host", "embed_col", "groups",
-                 "keeps_host", "scales_host", "embed_map", "want_tape")
+                 "keeps_host", "scales_host", "embed_map", "want_tape", "dead_blocks")
 
     def __init__(self):
         self.rows, self.layers, self.keep_dev, self.head, self.scales, self.batch, self.n_dp = [], [], None, None, None, 0, 0
@@ -109,6 +109,7 @@ class _Plan:
         self.keeps_host = self.scales_host = None
         self.want_tape = True    # False under torch.no_grad(): the forward keeps nothing for a backward
         self.embed_map = None    # int64 device map: internal sample -> caller's sample, consumed by the type-0 patch gather
+        self.dead_blocks = None  # forward-only: indices of the blocks whose layer keep is 0 for every sample (left out on the host)
         self.embed_col = None    # type-0 patch embedding: the patchify operand already gathered (engine.GraphedTrainStep)
 
     def add(self, keep):
@@ -851,8 +852,23 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         hcfg = {"dtype": self.compute_dtype, "eps": 1e-6, "classes": self.num_classes, "tokens": self.num_tokens}
         hk = plan.k(plan.head)
         seq = []
-        for blk, L in zip(self.blocks, plan.layers[1:]):
+        # forward-only (evaluation, candidate scoring): a block whose layer keep is 0 for EVERY sample -- a removed block of the
+        # candidate -- is the identity (supernet_blocks.py:243,251) and is left out on the host: no launch at all; the LayerNorm its
+        # predecessor fuses is then the one of the next block that runs
+        dead = plan.dead_blocks if not save else None
+        if not save and dead is None and _SKIP_DROPPED:
+            dead = set()
+            rows_h = plan.rows if plan.rows else None
+            for j, L in enumerate(plan.layers[1:]):
+                if L is not None and L.get("out") is not None and rows_h is not None and L["out"] < len(rows_h):
+                    r_ = rows_h[L["out"]]
+                    if not getattr(r_, "is_cuda", False) and bool((torch.as_tensor(r_) == 0).all()):
+                        dead.add(j)
+            plan.dead_blocks = dead
+        for j, (blk, L) in enumerate(zip(self.blocks, plan.layers[1:])):
             if L is None:
+                continue
+            if dead and j in dead and isinstance(blk, Block):
                 continue
             lazy = isinstance(blk, SpatialReductionPatchEmbedding) and save      # its weights are re-laid out by side_prep
             seq.append((blk, L, None if lazy else self._layer_params(blk), self._layer_cfg(blk, grid)))
