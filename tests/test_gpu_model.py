@@ -930,3 +930,56 @@ def test_opt_in_forms_at_model_level(tmp_path):
         assert abs(got["loss"] - ref["loss"]) < 2e-3 * abs(ref["loss"]), env_s
         worst = max(rel(g, ref["grads"][n]) for n, g in got["grads"].items())
         assert worst < 2e-2, (env_s, worst)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dropped_layers_and_dropped_samples_are_skipped_exactly(dtype, monkeypatch):
+    """Round 5: a dropped layer (layer keep 0 for an architecture group) and a DropPath-dropped sample zero the attention / MLP widths
+    the KERNELS read (vit_sr_supernet.sample_plan / plan_host_buffer), so that their qkv / fc1 GEMMs, attention cores and backward are
+    skipped instead of computed and multiplied by zero.  Results -- loss, logits, every parameter gradient -- must be those of the
+    computing path (VITRES_SKIP_DROPPED_LAYERS=0), and the sampled keeps reported to the caller must be untouched."""
+    from vitres.nets import vit_sr_supernet as V
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(7, 8, recipe.MICRO_IMG, recipe.MICRO_CLASSES, 1))
+    out = {}
+    hit_layer = hit_dp = False
+    for skip in (False, True):
+        monkeypatch.setattr(V, "_SKIP_DROPPED", skip)
+        prod = vitres.create_model("flexible_vit_sr_patch14_224_patch_output_supernet", img_size=recipe.MICRO_IMG,
+                                   num_classes=recipe.MICRO_CLASSES, network_def=recipe.MICRO_DEFS[0], drop_path_rate=0.5,
+                                   num_channels_to_keep=recipe.micro_keep_config(), example_per_arch=2, num_warmup_epochs=30)
+        sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in prod.state_dict().items()], 100)
+        prod.load_state_dict(sd)
+        prod = prod.to(DEV).set_compute_dtype(dtype)
+        prod.train()
+        prod.set_epoch(31)
+        prod.load_state_dict(sd)
+        res = []
+        for seed in range(6):                                      # several architecture draws: dropped layers occur in some of them
+            torch.manual_seed(700 + seed)
+            prod.drop_path_generator(seed=seed)
+            prod.zero_grad(set_to_none=True)
+            plan = prod.sample_plan(8)
+            keeps = [k.clone() for k in prod.last_keeps]
+            if skip:
+                flat, nk = prod.plan_host_buffer(plan)
+                kh = flat[:nk].reshape(plan.keeps_host.shape)
+                for L in plan.layers:
+                    if L is not None and L.get("out") is not None and L.get("attn") is not None:
+                        dead = plan.keeps_host[L["out"]] == 0
+                        if dead.any():
+                            hit_layer = True
+                            assert (kh[L["attn"]][dead] == 0).all() and (kh[L["mlp"]][dead] == 0).all()
+                        if L.get("dp") is not None and (plan.scales_host[L["dp"]] == 0).any():
+                            hit_dp = True
+                            assert (kh[L["attn"]][plan.scales_host[L["dp"]] == 0] == 0).all()
+            loss = prod.loss_and_grad(x, t, pt, "seq", plan=plan)
+            torch.cuda.synchronize()
+            res.append((float(loss), keeps, torch.cat([p.grad.reshape(-1).float() for p in prod.parameters()]).cpu()))
+        out[skip] = res
+    assert hit_layer and hit_dp                                    # the draws did exercise both kinds of skipping
+    for (l0, k0, g0), (l1, k1, g1) in zip(out[False], out[True]):
+        assert all(torch.equal(a, b) for a, b in zip(k0, k1))      # the reported samples are the reference protocol's, untouched
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        assert abs(l0 - l1) <= tol * abs(l0), (l0, l1)
+        assert rel(g1, g0) < (1e-5 if dtype == torch.float32 else 3e-2), rel(g1, g0)
