@@ -164,14 +164,14 @@ def gemm_ln_supported(a, N, ldc):
 
 
 def gemm_ln_fwd(a, b, out, ln_w, ln_b, ln_keep, eps, *, M, N, K, lda, ldb, ldc, bias=None, scale=None, keep_n=None,
-                resid=None, rows_in=0, keep_k=None, k_period=0):
+                resid=None, rows_in=0, keep_k=None, k_period=0, sched=0):
     gemm(a, b, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, bias=bias, scale=scale, keep_n=keep_n, resid=resid,
          rows_in=rows_in, keep_k=keep_k, k_period=k_period)
     return ln_fwd(out, ln_w, ln_b, ln_keep, rows_in or M, eps, torch.bfloat16)
 
 
 def gemm_ln_bwd(du, wt, x, ln_w, mean, rstd, ln_keep, dx_in, dw, db, next_cast=None, *, M, N, K, lda, ldb, rows_in=0,
-                keep_k=None, k_period=0, copies=1):
+                keep_k=None, k_period=0, copies=1, sched=0):
     dy = torch.empty(x.shape, dtype=torch.float32)
     gemm(du.float(), wt.float(), dy, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, rows_in=rows_in, keep_k=keep_k, k_period=k_period)
     out = ln_bwd(dy, x, ln_w, mean, rstd, ln_keep, rows_in or M, dx_in, dw, db, next_cast=next_cast, copies=copies)

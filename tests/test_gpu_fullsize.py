@@ -284,3 +284,67 @@ def test_full_size_bf16_step_trains_like_the_fp32_step():
     assert torch.isfinite(f).all() and torch.isfinite(b).all(), msg
     assert f[-1] < 0.9 * f[0] and b[-1] < 0.9 * b[0], msg          # both runs learn the batch
     assert rel_.max() < 5e-3 and rel_.mean() < 2e-3, msg          # (measured round 5: 1e-4 / 3e-5)
+
+
+@pytest.mark.parametrize("case", ["sr_tiny_g4", "sr_small_g4", "sr_tiny_g1", "sr_tiny_g2_graph"])
+def test_masked_tiles_left_unwritten_are_never_read(case, monkeypatch):
+    """Round 5: with one architecture per kernel tile (gemm_shared.h group_pure) the masked GEMMs leave fully masked output tiles --
+    hidden units / heads beyond an architecture's width, whole dropped layers -- UNWRITTEN (vr_gemm_args.sched bit 0x40000,
+    vit_sr_supernet._Plan.skip_writes).  At the real widths (C3 / C4 networks: 128-column tiles, short last row tile per group,
+    DropPath-dropped samples inside live groups) the step must give the loss and the gradients of the writing path, and must still
+    do so when every such output is filled with NaN first (kernels.DBG_POISON): a reader of an unwritten tile would turn the loss
+    or a gradient into NaN."""
+    from vitres.nets import vit_sr_supernet as V
+    from vitres import kernels as K
+    nd, space, B, epa = {"sr_tiny_g4": (recipe.SR_TINY_DEF, "sr_tiny", 32, 8), "sr_small_g4": (recipe.SR_SMALL_DEF, "sr_small", 24, 6),
+                         "sr_tiny_g1": (recipe.SR_TINY_DEF, "sr_tiny", 8, 8),
+                         "sr_tiny_g2_graph": (recipe.SR_TINY_DEF, "sr_tiny", 16, 8)}[case]
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(B, 3, 224, 224, generator=g).to(DEV)
+    t = torch.nn.functional.one_hot(torch.randint(0, 1000, (B,), generator=g), 1000).float().to(DEV)
+    pt = t[:, None, :].repeat(1, 16, 1).contiguous()
+    prod = make(nd, space, 0.4, epa=epa)
+    sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in prod.state_dict().items()], 4343)
+    prod.load_state_dict(sd)
+    prod = prod.to(DEV).set_compute_dtype(torch.bfloat16)
+    prod.train()
+    prod.set_epoch(31)
+    prod.load_state_dict(sd)
+    out = {}
+    for mode in ("write", "write again", "skip", "skip+poison"):
+        monkeypatch.setattr(V, "_SKIP_WRITES", not mode.startswith("write"))
+        monkeypatch.setattr(K, "DBG_POISON", [mode == "skip+poison"])
+        res = []
+        if case.endswith("graph"):
+            from vitres import engine
+            from vitres.losses import SoftTargetCrossEntropy
+            prod.drop_path_generator(seed=3)
+            step = engine.GraphedTrainStep(prod, SoftTargetCrossEntropy(), x, t, pt, "seq")
+            for it in range(3):
+                torch.manual_seed(300 + it)
+                loss = step(x, t, pt, epoch=31, train_iter=it, arch_sample="multi").clone()
+                torch.cuda.synchronize()
+                res.append((float(loss), torch.cat([p.grad.reshape(-1).float() for p in prod.parameters()]).cpu()))
+            del step
+        else:
+            for seed in range(3):
+                torch.manual_seed(800 + seed)
+                prod.drop_path_generator(seed=seed)
+                prod.zero_grad(set_to_none=True)
+                plan = prod.sample_plan(B)
+                assert plan.skip_writes == (not mode.startswith("write"))
+                loss = prod.loss_and_grad(x, t, pt, "seq", plan=plan)
+                torch.cuda.synchronize()
+                res.append((float(loss), torch.cat([p.grad.reshape(-1).float() for p in prod.parameters()]).cpu()))
+        out[mode] = res
+    # fp32 atomics (the loss's sum over the rows, every weight gradient): the order of the sums varies from run to run -- the band
+    # is what two runs of the WRITING path differ by (printed), with a floor
+    noise_l = max(abs(a[0] - b[0]) / abs(a[0]) for a, b in zip(out["write"], out["write again"]))
+    noise_g = max(rel(b[1], a[1]) for a, b in zip(out["write"], out["write again"]))
+    print("run-to-run: loss %.2e, gradients %.2e" % (noise_l, noise_g))
+    for mode in ("skip", "skip+poison"):
+        for (l0, g0), (l1, g1) in zip(out["write"], out[mode]):
+            assert l1 == l1 and bool(torch.isfinite(g1).all()), (case, mode)
+            print(mode, "loss %.2e, gradients %.2e" % (abs(l0 - l1) / abs(l0), rel(g1, g0)))
+            assert abs(l0 - l1) <= max(4 * noise_l, 2e-6) * abs(l0), (case, mode, l0, l1, noise_l)
+            assert rel(g1, g0) < max(4 * noise_g, 1e-4), (case, mode, rel(g1, g0), noise_g)

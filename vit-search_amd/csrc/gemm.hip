@@ -815,6 +815,8 @@ extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
         return VR_OK;
     }
     if (a.atomic == 2) return VR_EUNSUPPORTED;       // the store form exists on the bf16 LDS-DMA weight-gradient kernel only
+    // sched bit 0x80000 (masked tiles of the operands may be unwritten): only the group-pure bf16 kernels may read them
+    if ((a.sched & 0x80000) && a.m_groups > 1 && (a.keep_k || (a.a_trans && a.keep_n))) return VR_EUNSUPPORTED;
     if (a.in_dtype == VR_BF16) return launch<bf16_t>(a, (hipStream_t)stream);
     return launch<float>(a, (hipStream_t)stream);
 }

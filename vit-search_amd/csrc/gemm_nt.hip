@@ -499,6 +499,9 @@ bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_nt;
     if (a.in_dtype != VR_BF16 || a.a_trans || a.atomic || a.split_k > 1 || a.bias_grad) return false;
     if (vr_gemm_ntk_launch(a, stream, n_cu)) return true;
+    // sched bit 0x80000: the operand may hold unwritten (fully masked) tiles, readable only by the group-pure row tiling of
+    // gemm_ntk.hip -- the kernels below tile across architecture groups: refused (vr_gemm then fails loudly)
+    if ((a.sched & 0x80000) && a.keep_k && a.m_groups > 1) return false;
     const bool of32 = a.out_dtype == VR_F32;
     if (a.b_trans) {
         // B = W [K][N] row-major (the forward's weight): plain data gradients with a bf16 result (optionally times gelu'), 16-byte

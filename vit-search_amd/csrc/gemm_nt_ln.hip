@@ -61,14 +61,15 @@ __global__ __launch_bounds__(NTHR, NJ > 5 ? 2 : 3) void ntln_kernel(   // (32 x 
     __shared__ RowMeta rowmeta[BM];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_m = group_tiles(p.M, BM, p.m_groups);
     int tile = blockIdx.x;
     if (tiles_m >= 16) {                 // XCD-aware order (see gemm_nt.hip): an XCD owns a contiguous run of row tiles
         const int xq = tiles_m >> 3, xr = tiles_m & 7, x = tile & 7;
         tile = x * xq + min(x, xr) + (tile >> 3);
     }
-    tile = interleave_groups(tile, tiles_m, p.m_groups);      // every architecture group of a multi-arch batch on every XCD
-    const int m0 = tile * BM;
+    // every architecture group of a multi-arch batch on every XCD, and no tile with rows of two groups (gemm_shared.h): [m0, mend)
+    int m0, mend;
+    group_tile_rows(tile, p.M, BM, p.m_groups, m0, mend);
     const RowMap amap = {p.a_map.rpi, p.a_map.rps, p.a_map.off};
 
     // ---- masked-work skipping (rules of the general kernel) ----
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(NTHR, NJ > 5 ? 2 : 3) void ntln_kernel(   // (32 x 
     bool n_any = true;
     if (p.keep_k || p.keep_n) {
         int s_lo = 0, s_hi = 0;
-        if (p.rows_in > 0) { s_lo = m0 / p.rows_in; s_hi = (min(m0 + BM, p.M) - 1) / p.rows_in; }
+        if (p.rows_in > 0) { s_lo = m0 / p.rows_in; s_hi = (min(m0 + BM, mend) - 1) / p.rows_in; }
         kmax = max_keep(p.keep_k, s_lo, s_hi, 1 << 30);
         n_any = max_keep(p.keep_n, s_lo, s_hi, 1 << 30) > 0;
     }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(NTHR, NJ > 5 ? 2 : 3) void ntln_kernel(   // (32 x 
             }
         }
         const int ra = wave * (8 * AP) + (lane >> 3);
-        if (amap.rpi == 0 && m0 + BM <= p.M) {
+        if (amap.rpi == 0 && m0 + BM <= mend) {
             const char* a0 = reinterpret_cast<const char*>(p.A) + (long long)(m0 + ra) * p.lda * 2;
             const long long step = (long long)p.lda * 16;
 #pragma unroll
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(NTHR, NJ > 5 ? 2 : 3) void ntln_kernel(   // (32 x 
             for (int h = 0; h < AP; ++h) {
                 const int r = ra + h * 8;
                 const int c = (lane & 7) ^ ((r >> 1) & 7);
-                const int ma = min(m0 + r, p.M - 1);
+                const int ma = min(m0 + r, mend - 1);
                 gA[h] = reinterpret_cast<const char*>(p.A) + (map_row(amap, ma) * (long long)p.lda + c * 8) * 2;
                 chunkA[h] = c * 8;
             }
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(NTHR, NJ > 5 ? 2 : 3) void ntln_kernel(   // (32 x 
         const int m = m0 + t;
         RowMeta rm;
         rm.keep = 1 << 30; rm.scale = 1.0f; rm.orow = -1; rm.lnkeep = p.N; rm.mu = 0.f; rm.rs = 0.f;
-        if (m < p.M) {
+        if (m < mend) {
             const int sample = p.rows_in > 0 ? m / p.rows_in : 0;
             rm.orow = m;
             if (f.keep) rm.lnkeep = min(f.keep[sample], p.N);
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(NTHR, NJ > 5 ? 2 : 3) void ntln_kernel(   // (32 x 
 }
 
 template <int MI, int NJ> int launch(const vr_gemm_args& a, const vr_ln_epilogue& f, hipStream_t stream) {
-    const unsigned tiles = (unsigned)((a.M + 16 * MI - 1) / (16 * MI));
+    const unsigned tiles = (unsigned)vr_gemm_shared::group_tiles(a.M, 16 * MI, a.m_groups);
     const bool ktail = (a.K % BK) != 0;
     if (f.mode == 0) {
         if (ktail) hipLaunchKernelGGL((ntln_kernel<MI, NJ, 0, true>), dim3(tiles), dim3(NTHR), 0, stream, a, f);
@@ -433,6 +434,8 @@ extern "C" int vr_gemm_ln(const vr_gemm_args* g, const vr_ln_epilogue* ln, vr_st
         a.act || a.dact_u || a.pos || a.C2 || a.n_period > 0 || a.c_map.rpi != 0)
         return VR_EUNSUPPORTED;
     if (!vr_gemm_ln_supported(a.N) || a.ldc % 8 || a.lda % 8 || a.ldb % 8 || a.ldc < a.N) return VR_EUNSUPPORTED;
+    // sched bit 0x80000: masked tiles of A may be unwritten -- readable only when no row tile straddles two architecture groups
+    if ((a.sched & 0x80000) && a.keep_k && a.m_groups > 1 && !group_pure(a.M, a.m_groups)) return VR_EUNSUPPORTED;
     if (ln->mode == 0) {
         if (!ln->b || !ln->y || !ln->mean || !ln->rstd) return VR_EINVAL;
     } else if (ln->mode == 1) {

@@ -32,32 +32,20 @@ using vr_dma::dma16;
 using vr_dma::make_rsrc;
 typedef vr_dma::v4i v4i_k;
 
-__device__ __forceinline__ int interleave_groups32(int p, int n, int G) {      // gemm_shared.h interleave_groups in 32-bit arithmetic
-    if (G <= 1 || n < 2 * G) return p;
-    const int t = n / G;
-    if (p < t * G) {
-        const int g = p % G, r = p / G;
-        return (int)((unsigned)g * (unsigned)n / (unsigned)G) + r;
-    }
-    int k = p - t * G;
-    for (int g = 0; g < G; ++g) {
-        const int s0 = (int)((unsigned)g * (unsigned)n / (unsigned)G), s1 = (int)((unsigned)(g + 1) * (unsigned)n / (unsigned)G);
-        if (s1 - s0 > t) {
-            if (k == 0) return s0 + t;
-            --k;
-        }
-    }
-    return p;
-}
-
 // largest keep[s], s in [s_lo, s_hi]: the lanes of a wave load in parallel, the scalar unit folds the (few) values
-__device__ __forceinline__ int max_keep_wave(const int* keep, int s_lo, int s_hi, int lane) {
+// A negative value -(k + 2) is the host's mark for a sample that is masked ON ITS OWN (DropPath) in an architecture group of width
+// k: every kernel reads it as 0; gmax = the largest width with the marks decoded = what the sample's GROUP keeps.
+__device__ __forceinline__ int max_keep_wave(const int* keep, int s_lo, int s_hi, int lane, int& gmax) {
     int mk = 0;
     for (int s0 = s_lo; s0 <= s_hi; s0 += 64) {
         const int s = s0 + lane;
         const int v = s <= s_hi ? keep[s] : 0;
+        const int d = v < 0 ? -v - 2 : v;
         const int cnt = min(64, s_hi - s0 + 1);
-        for (int i = 0; i < cnt; ++i) mk = max(mk, __builtin_amdgcn_readlane(v, i));
+        for (int i = 0; i < cnt; ++i) {
+            mk = max(mk, __builtin_amdgcn_readlane(v, i));
+            gmax = max(gmax, __builtin_amdgcn_readlane(d, i));
+        }
     }
     return mk;
 }
@@ -74,18 +62,22 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
     // ONE shared array (slice ring | row metadata): a second __shared__ object makes hipcc drain the DMA queue before LDS reads
     __shared__ __attribute__((aligned(1024))) char smem[META_OFF + BM * (int)sizeof(RowMeta)];
     RowMeta* rowmeta = reinterpret_cast<RowMeta*>(smem + META_OFF);
+    // forms whose fully masked tiles hold nothing but zeros (bf16 result, no residual): see the write skipping below
+    constexpr bool SKIP_FORM = sizeof(TO) == 2 && ((EPI == EPI_STORE && FEAT <= 1) || EPI == EPI_GELU || EPI == EPI_DMUL);
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = group_tiles(p.M, BM, p.m_groups);
     const int total = tiles_n * tiles_m;
     int tile = blockIdx.x;
     if (total >= 16) {       // workgroup ids go round-robin to the 8 XCDs: an XCD owns one contiguous run of the n-fastest order
         const int xq = total >> 3, xr = total & 7, x = tile & 7;
         tile = x * xq + min(x, xr) + (tile >> 3);
     }
-    const int tn = tile % tiles_n, tm = interleave_groups32(tile / tiles_n, tiles_m, p.m_groups);
-    const int m0 = tm * BM, n0 = tn * BN;
+    // row tiles of a multi-architecture batch never straddle two groups (gemm_shared.h group_tile_rows): rows [m0, mend)
+    const int tn = tile % tiles_n, n0 = tn * BN;
+    int m0, mend;
+    group_tile_rows(tile / tiles_n, p.M, BM, p.m_groups, m0, mend);
 
     // ---- per-lane byte offsets of this wave's LDS-DMA pieces (constant over the K loop) ----
     unsigned voffA[AP], voffB[BP];
@@ -96,7 +88,7 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
         for (int h = 0; h < AP; ++h) {
             const int r = ra + 8 * h;
             const int c = (lane & 7) ^ ((r >> 1) & 7);
-            const int ma = min(m0 + r, p.M - 1);
+            const int ma = min(m0 + r, mend - 1);
             voffA[h] = (unsigned)((map_row(amap, ma) * (long long)p.lda + c * 8) * 2);
         }
         if constexpr (BKM) {
@@ -148,11 +140,27 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
     unsigned long long live = ntiles >= 64 ? ~0ull : ((1ull << ntiles) - 1ull);
     if (p.keep_k || p.keep_n) {
         int s_lo = 0, s_hi = 0;
-        if (p.rows_in > 0) { s_lo = m0 / p.rows_in; s_hi = (min(m0 + BM, p.M) - 1) / p.rows_in; }
+        if (p.rows_in > 0) { s_lo = m0 / p.rows_in; s_hi = (min(m0 + BM, mend) - 1) / p.rows_in; }
         bool any = true;
-        if (p.keep_n) any = range_has_kept(n0, BN, p.n_period, max_keep_wave(p.keep_n, s_lo, s_hi, lane));
+        if (p.keep_n) {
+            int gmax = 0;
+            any = range_has_kept(n0, BN, p.n_period, max_keep_wave(p.keep_n, s_lo, s_hi, lane, gmax));
+            // A tile whose columns are masked for every row would store zeros.  With sched bit 0x40000 the caller vouches that
+            // every reader of this output is one of the group-pure bf16 kernels (gemm_ntk / gemm_nt_ln / gemm_tn; the attention
+            // cores skip per sample) and reads, for these rows, only the channels their architecture GROUP keeps: a tile beyond
+            // the group's width (gmax) is then not written at all.  A sample masked on its own (DropPath) shares its group -- and
+            // a reader's tile -- with live rows: below the group's width its zeros ARE written.
+            if constexpr (SKIP_FORM) {
+                if (!any && !range_has_kept(n0, BN, p.n_period, gmax) && (p.sched & 0x40000) &&
+                    (p.m_groups <= 1 || group_pure(p.M, p.m_groups))) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // slice 0 is on its way into this workgroup's LDS
+                    return;
+                }
+            }
+        }
         if (p.keep_k) {
-            const int kmax = max_keep_wave(p.keep_k, s_lo, s_hi, lane);
+            int gk = 0;
+            const int kmax = max_keep_wave(p.keep_k, s_lo, s_hi, lane, gk);
             if (kmax <= 0) any = false;
             else if (p.k_period <= 0) {                                  // plain prefix: the slices below kmax
                 const int nl = min(ntiles, (kmax + BK - 1) / BK);
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
         const int m = m0 + t;
         RowMeta rm;
         rm.keep = 1 << 30; rm.scale = 1.0f; rm.orow = -1; rm.mloc = 0;
-        if (m < p.M) {
+        if (m < mend) {
             const int sample = p.rows_in > 0 ? m / p.rows_in : 0;
             rm.mloc = p.rows_in > 0 ? m - sample * p.rows_in : m;
             rm.orow = (int)map_row({p.c_map.rpi, p.c_map.rps, p.c_map.off}, m);
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
 }
 
 template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM> void klaunch(const vr_gemm_args& a, hipStream_t stream) {
-    const long long total = (long long)((a.M + 32 * MI - 1) / (32 * MI)) * ((a.N + 32 * NJ - 1) / (32 * NJ));
+    const long long total = (long long)group_tiles(a.M, 32 * MI, a.m_groups) * ((a.N + 32 * NJ - 1) / (32 * NJ));
     static const int knob_deep = std::getenv("VITRES_NTK_DEEP") ? std::atoi(std::getenv("VITRES_NTK_DEEP")) : 1;
     constexpr bool SIDE = (EPI == EPI_STORE && FEAT >= 2) || EPI == EPI_DMUL;
     if constexpr (MI == 2 && SIDE) {
@@ -335,7 +343,8 @@ bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_nt;
     static const int knob = std::getenv("VITRES_NTK") ? std::atoi(std::getenv("VITRES_NTK")) : 1;
     if (!knob) return false;
-    if (a.sched & (8 | 16 | 32 | 64 | 0x100)) return false;          // forms of gemm_nt.hip forced by the caller (tests, measurement aids)
+    if (a.sched & (8 | 16 | 32 | 64 | 0x100)) return false;
+          // forms of gemm_nt.hip forced by the caller (tests, measurement aids)
     if (a.in_dtype != VR_BF16 || a.a_trans || a.atomic || a.split_k > 1 || a.bias_grad || a.pos) return false;
     if (a.K % BK || a.K > 64 * BK || a.K < BK) return false;
     const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);

@@ -49,6 +49,16 @@ struct LiveSlices {
     }
 };
 
+// Row tiles / token splits of a multi-architecture batch (vr_gemm_args.m_groups = G contiguous, equal groups of rows, each with its
+// own keep values): when G divides the rows, the bf16 kernels lay the grid out PER GROUP -- ceil((rows / G) / BM) tiles for each,
+// the last one short -- so that no tile (and no token split of a weight gradient) holds rows of two architectures.  Every consumer
+// of a masked activation then reads, for a row, only the channel slices below ITS architecture's keep (rounded up to the 64-wide
+// slice); that is what lets the producers leave fully masked tiles unwritten (vr_gemm_args.sched bit 0x40000, gemm_ntk.hip).
+__host__ __device__ inline bool group_pure(int rows, int G) { return G > 1 && rows % G == 0; }
+__host__ __device__ inline int group_tiles(int rows, int BM, int G) {
+    return group_pure(rows, G) ? G * ((rows / G + BM - 1) / BM) : (rows + BM - 1) / BM;
+}
+
 // Position p of the workgroup order -> index in [0, n) such that consecutive positions walk the G equal index groups
 // round-robin (group g = [g n / G, (g + 1) n / G)): the XCD-contiguous runs of the tile order then hold every architecture
 // group of a multi-arch batch in equal parts (vr_gemm_args.m_groups).  A bijection for every n, G.
@@ -68,6 +78,19 @@ __device__ __forceinline__ int interleave_groups(int p, int n, int G) {
         }
     }
     return p;
+}
+
+// position q of the row-tile order -> rows [m0, mend) the tile may touch: group-pure layout (consecutive positions walk the groups
+// round-robin, like interleave_groups) or the plain one
+__device__ __forceinline__ void group_tile_rows(int q, int rows, int BM, int G, int& m0, int& mend) {
+    if (group_pure(rows, G)) {
+        const int rpg = rows / G, g = q % G, i = q / G;
+        m0 = g * rpg + i * BM;
+        mend = g * rpg + rpg;
+    } else {
+        m0 = interleave_groups(q, (rows + BM - 1) / BM, G) * BM;
+        mend = rows;
+    }
 }
 
 // Epilogue flavours (compile-time, keeps every instantiation small enough to unroll fully):

@@ -89,10 +89,23 @@ __device__ __forceinline__ void tn_body(const vr_gemm_args& p, const int bid) {
         tile = x * xq + min(x, xr) + (tile >> 3);
     }
     const int tn = tile % tiles_n, rest = tile / tiles_n;
-    const int tm = rest % tiles_m, z = interleave_groups(rest / tiles_m, p.split_k, p.m_groups);   // (token splits of every architecture group on every XCD)
+    const int tm = rest % tiles_m, zq = rest / tiles_m;
     const int m0 = tm * TW, n0 = tn * TW;
-    const int kper = ((p.K + p.split_k - 1) / p.split_k + BT - 1) / BT * BT;
-    const int kbeg = z * kper, kend = min(p.K, kbeg + kper);
+    // token range of this split: the splits of a multi-architecture batch never straddle two groups (the launchers make split_k a
+    // multiple of m_groups; gemm_shared.h group_pure) and consecutive positions walk the groups round-robin -- every group on
+    // every XCD; otherwise equal ranges over all tokens
+    int kbeg, kend;
+    if (group_pure(p.K, p.m_groups) && p.split_k % p.m_groups == 0) {
+        const int G = p.m_groups, kg = p.K / G, spg = p.split_k / G, g = zq % G, zi = zq / G;
+        const int kper = ((kg + spg - 1) / spg + BT - 1) / BT * BT;
+        kbeg = g * kg + zi * kper;
+        kend = min(g * kg + kg, kbeg + kper);
+    } else {
+        const int z = interleave_groups(zq, p.split_k, p.m_groups);
+        const int kper = ((p.K + p.split_k - 1) / p.split_k + BT - 1) / BT * BT;
+        kbeg = z * kper;
+        kend = min(p.K, kbeg + kper);
+    }
     int ntiles = kbeg < kend ? (kend - kbeg + BT - 1) / BT : 0;
     // masked-work skipping: keep_k bounds the kept output rows (dY channels), keep_n the kept columns (X channels) of
     // the samples this token range touches; a tile without kept rows or columns adds exactly zero
@@ -320,6 +333,18 @@ static bool tn_covers(const vr_gemm_args& a0) {
     return true;
 }
 
+// token split of a multi-architecture batch: the multiple of the group count nearest to the wanted split (gemm_shared.h group_pure)
+static bool needs_pure(const vr_gemm_args& a);
+static int group_split(long long split, const vr_gemm_args& a) {
+    if (split < 1) split = 1;
+    if (!vr_gemm_shared::group_pure(a.K, a.m_groups)) return (int)split;
+    if (split < a.m_groups && !needs_pure(a)) return (int)split;        // (few tokens: one split stays one split -- and one sum order)
+    const long long q = (split + a.m_groups / 2) / a.m_groups;
+    return (int)((q < 1 ? 1 : q) * a.m_groups);
+}
+// sched bit 0x80000: the operands may hold unwritten (fully masked) tiles -- readable only split by split within one group
+static bool needs_pure(const vr_gemm_args& a) { return (a.sched & 0x80000) && a.m_groups > 1 && (a.keep_k || a.keep_n); }
+
 // vr_gemm_group: `count` validated weight-gradient problems as one launch.  Returns false when any of them is not a plain
 // (un-mapped, automatic split) tn_kernel form -- the caller then issues them one by one.
 bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t stream, int n_cu) {
@@ -328,6 +353,7 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
     for (int i = 0; i < count; ++i) {
         const vr_gemm_args& a = args[i];
         if (!tn_covers(a) || a.a_map.rpi != 0 || a.b_map.rpi != 0 || a.split_k > 0) return false;
+        if (needs_pure(a) && (a.atomic == 2 || !vr_gemm_shared::group_pure(a.K, a.m_groups))) return false;
     }
     static const int knob_s = std::getenv("VITRES_TN_S") ? std::atoi(std::getenv("VITRES_TN_S")) : 32;
     static const int knob_fill = std::getenv("VITRES_TN_GROUP_FILL") ? std::atoi(std::getenv("VITRES_TN_GROUP_FILL")) : 2;
@@ -358,7 +384,7 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
         const long long slices = (args[i].K + BT - 1) / BT;
         const long long tiles = (long long)((args[i].M + TWv - 1) / TWv) * ((args[i].N + TWv - 1) / TWv);
         long long split = args[i].atomic == 2 ? 1 : (slices + spw - 1) / spw;       // store form: one workgroup per tile
-        g.a[i].split_k = (int)(split < 1 ? 1 : split);
+        g.a[i].split_k = args[i].atomic == 2 ? 1 : group_split(split, args[i]);
         g.first[i] = next;
         next += (int)((tiles * g.a[i].split_k + 7) / 8 * 8);
     }
@@ -383,6 +409,7 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
 bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_tn;
     if (!tn_covers(a0)) return false;
+    if (needs_pure(a0) && (a0.atomic == 2 || !vr_gemm_shared::group_pure(a0.K, a0.m_groups))) return false;
     vr_gemm_args a = a0;
     if (a.atomic == 2) a.split_k = 1;
     static const int knob_s = std::getenv("VITRES_TN_S") ? std::atoi(std::getenv("VITRES_TN_S")) : 32;
@@ -406,6 +433,7 @@ bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
         if (split > by_fill) split = by_fill;
         a.split_k = (int)(split < 1 ? 1 : split);
     }
+    if (a.atomic != 2) a.split_k = group_split(a.split_k, a);
     const long long total = tiles * a.split_k;
     static const int knob_st = std::getenv("VITRES_TN_STAGES") ? std::atoi(std::getenv("VITRES_TN_STAGES")) : 1;
     if (small) {

@@ -439,10 +439,10 @@ def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save, pre=N
     if _ln_fusable(h, C, next_ln):
         post = K.gemm_ln_fwd(h, p["fc2"].w_c, x2, next_ln[0], next_ln[1], next_ln[2], next_ln[3], M=M, N=C, K=F, lda=F,
                              ldb=p["fc2"].ld, ldc=C, bias=p["fc2"].b, scale=scale, keep_n=out_keep, resid=x, rows_in=N,
-                             keep_k=mlp_keep)
+                             keep_k=mlp_keep, sched=K.reads_skipped())
     else:
         K.gemm(h, p["fc2"].w_c, x2, M=M, N=C, K=F, lda=F, ldb=p["fc2"].ld, ldc=C, bias=p["fc2"].b, scale=scale,
-               keep_n=out_keep, resid=x, rows_in=N, keep_k=mlp_keep)
+               keep_n=out_keep, resid=x, rows_in=N, keep_k=mlp_keep, sched=K.reads_skipped())
     saved = (x, mean, rstd, y, u, h) if save else None
     return x2, saved, post
 
@@ -460,10 +460,11 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
 
     grp = _block_wgrads if (WGRAD_GROUP and g.is_cuda) else None
+    rsk = K.reads_skipped()            # (now: the closures below may run after the backward has returned)
 
     def wgrad_fc2():
         linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"], keep_rows=out_keep, keep_cols=mlp_keep,
-                     tokens_per_sample=N, sched=wsch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
+                     tokens_per_sample=N, sched=wsch | rsk, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
     if ov and grp is None:
         on_side(wgrad_fc2, gt)
     else:
@@ -474,7 +475,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
 
     def wgrad_fc1():
         linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"], keep_rows=mlp_keep, keep_cols=embed_keep,
-                     tokens_per_sample=N, sched=wsch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
+                     tokens_per_sample=N, sched=wsch | rsk, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
     if ov and grp is None:
         on_side(wgrad_fc1, du)
     else:
@@ -482,10 +483,11 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     if (FUSE_LN & 2) and C <= FUSE_LN_MAXN and p["fc1"].w_t is not None and K.gemm_ln_supported(du, C, C):
         dw, db, cp = _ln_dst(grads, "n2w", "n2b")
         out = K.gemm_ln_bwd(du, p["fc1"].w_t, x, p["n2w"], mean, rstd, embed_keep, g, dw, db,
-                            next_cast=next_cast, M=M, N=C, K=F, lda=F, ldb=p["fc1"].ld_t, rows_in=N, keep_k=mlp_keep, copies=cp)
+                            next_cast=next_cast, M=M, N=C, K=F, lda=F, ldb=p["fc1"].ld_t, rows_in=N, keep_k=mlp_keep, copies=cp,
+                            sched=K.reads_skipped())
     else:
         dy = torch.empty((B, N, C), dtype=dt, device=x.device)
-        linear_dgrad(du, p["fc1"], dy, M, C, F, F, C, rows_in=N, keep_k=mlp_keep, keep_n=embed_keep, sched=sch)
+        linear_dgrad(du, p["fc1"], dy, M, C, F, F, C, rows_in=N, keep_k=mlp_keep, keep_n=embed_keep, sched=sch | K.reads_skipped())
         dw, db, cp = _ln_dst(grads, "n2w", "n2b")
         out = K.ln_bwd(dy, x, p["n2w"], mean, rstd, embed_keep, N, g, dw, db, next_cast=next_cast, copies=cp)
     if ov and not DEFER_JOIN and not JOIN_PER_BLOCK:

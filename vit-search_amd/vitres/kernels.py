@@ -90,6 +90,24 @@ def ensure_workspaces(dev, roles=(0, 1)):
 # keep rows); every GEMM that carries keep arrays passes it on, so that the kernels deal every group to every XCD.
 # VITRES_GROUP_INTERLEAVE=0 keeps the plain tile order (measurement).
 M_GROUPS = [1]
+# The model vouches (vit_sr_supernet.sample_plan -> plan.skip_writes) that every tile / token split of the bf16 kernels sees ONE
+# architecture of the batch being processed and that every masked Linear of the network is one the group-pure kernels cover: the
+# masked GEMMs then carry sched bit 0x40000 -- producers leave fully masked output tiles unwritten, and a launch that would have
+# to read such an operand through a kernel that tiles across groups fails (VR_EUNSUPPORTED) instead of reading them.
+WRITE_SKIP = [False]
+SKIP_WRITES_BIT = 0x40000
+READS_SKIPPED_BIT = 0x80000
+
+
+def reads_skipped():
+    """sched bit for a GEMM whose operand (the MLP's hidden activation or its gradient) was produced under WRITE_SKIP: the launch
+    must go to a kernel that tiles group by group, or fail."""
+    return READS_SKIPPED_BIT if WRITE_SKIP[0] else 0
+
+
+# test aid (tests/test_gpu_model.py): fill the output of every launch that may leave tiles unwritten with NaN first -- a reader of
+# an unwritten tile then changes the loss / gradients instead of quietly reading whatever the arena held
+DBG_POISON = [__import__("os").environ.get("VITRES_DBG_POISON", "0") != "0"]
 _GROUP_INTERLEAVE = __import__("os").environ.get("VITRES_GROUP_INTERLEAVE", "1") != "0"
 
 
@@ -107,6 +125,8 @@ def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=Fals
     args.resid, args.dact_u, args.bias_grad, args.keep_k = _p(resid), _p(dact_u), _p(bias_grad), _p(keep_k)
     args.n_period, args.k_period, args.sched = n_period, k_period, sched
     args.m_groups = M_GROUPS[0] if (_GROUP_INTERLEAVE and (keep_k is not None or keep_n is not None) and rows_in > 0) else 0
+    if WRITE_SKIP[0] and (keep_k is not None or keep_n is not None) and rows_in > 0 and (M_GROUPS[0] <= 1 or args.m_groups > 1):
+        args.sched |= SKIP_WRITES_BIT
     args.M, args.N, args.K = M, N, K
     args.lda, args.ldb, args.ldc, args.ldu = lda, ldb, ldc, ldu
     args.a_trans, args.b_trans = int(a_trans), int(b_trans)
@@ -127,7 +147,7 @@ def _kept_flops(M, N, K, rows_in, keep_k, keep_n, k_period=0):
         if keep is None:
             return None
         k = keep.detach().to("cpu", torch.float64)
-        return torch.clamp(k, max=period) * (dim // period) if period else torch.clamp(k, max=dim)
+        return torch.clamp(k, min=0, max=period) * (dim // period) if period else torch.clamp(k, min=0, max=dim)
     kk, kn = kept(keep_k, K, k_period), kept(keep_n, N, 0)
     if kk is None and kn is None:
         return 2.0 * M * N * K
@@ -201,6 +221,11 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
                       bias=bias, pos=pos, scale=scale, keep_n=keep_n, resid=resid, dact_u=dact_u, ldu=ldu, act=act,
                       atomic=atomic, split_k=split_k, rows_in=rows_in, a_map=a_map, b_map=b_map, c_map=c_map,
                       bias_grad=bias_grad, keep_k=keep_k, n_period=n_period, k_period=k_period, sched=sched, ws=ws)
+    if DBG_POISON[0] and (args.sched & SKIP_WRITES_BIT) and keep_n is not None and not a_trans and resid is None and \
+            out.dtype == torch.bfloat16:
+        out.fill_(float("nan"))
+        if out2 is not None:
+            out2.fill_(float("nan"))
     if PROFILE is None:
         _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
         return out

@@ -56,6 +56,8 @@ def trunc_normal_(t, std):
 
 
 _SKIP_DROPPED = __import__("os").environ.get("VITRES_SKIP_DROPPED_LAYERS", "1") != "0"
+# VITRES_SKIP_MASKED_WRITES=0: the masked GEMMs store the zeros of their fully masked tiles (measurement / A-B aid)
+_SKIP_WRITES = __import__("os").environ.get("VITRES_SKIP_MASKED_WRITES", "1") != "0"
 
 class BypassBlock(nn.Module):
     """Removed transformer block (exists == 0): identity, resets the layer mask (reference :50-56)."""
@@ -98,7 +100,7 @@ class SpatialReductionPatchEmbedding(nn.Module):
 class _Plan:
     """Host-side description of one forward: which keep vector / drop-path scale each layer uses."""
     __slots__ = ("keep_dev", "rows", "layers", "head", "scales", "batch", "n_dp", "order", "dp_noise", "host", "embed_col", "groups",
-                 "keeps_host", "scales_host", "embed_map", "want_tape", "dead_blocks")
+                 "keeps_host", "scales_host", "embed_map", "want_tape", "dead_blocks", "skip_writes")
 
     def __init__(self):
         self.rows, self.layers, self.keep_dev, self.head, self.scales, self.batch, self.n_dp = [], [], None, None, None, 0, 0
@@ -109,6 +111,7 @@ class _Plan:
         self.keeps_host = self.scales_host = None
         self.want_tape = True    # False under torch.no_grad(): the forward keeps nothing for a backward
         self.embed_map = None    # int64 device map: internal sample -> caller's sample, consumed by the type-0 patch gather
+        self.skip_writes = False # every kernel tile of this batch sees one architecture: fully masked output tiles stay unwritten (kernels.WRITE_SKIP)
         self.dead_blocks = None  # forward-only: indices of the blocks whose layer keep is 0 for every sample (left out on the host)
         self.embed_col = None    # type-0 patch embedding: the patchify operand already gathered (engine.GraphedTrainStep)
 
@@ -531,6 +534,10 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             if 1 < G < B:
                 plan.order = [j * G + g for g in range(G) for j in range(epa)]
                 plan.groups = G
+            # One architecture per kernel tile (the G contiguous groups above, or one architecture for the whole batch) and a network
+            # whose masked Linears all run on the group-pure bf16 kernels: the zeros of fully masked activation tiles -- hidden units /
+            # heads beyond an architecture's width, whole dropped layers -- are then never read and need not be written
+            plan.skip_writes = bool(_SKIP_WRITES and (plan.groups > 1 or G == 1) and self._masked_writes_skippable())
 
         def expand(gs, who):             # [len(gs), B]: entry b of a group vector g is g[b % len(g)]
             if not gs:
@@ -545,6 +552,20 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         log = expand(groups, caller)
         self.last_keeps = list(torch.from_numpy(log)) if groups else []
         return plan
+
+    def _masked_writes_skippable(self):
+        """Static half of _Plan.skip_writes: bf16 kernels, every transformer block's widths multiples of the 64-wide K slice (the
+        forms gemm_ntk.hip / gemm_nt_ln.hip / gemm_tn.hip cover), atomic weight gradients (the store form runs one workgroup over all
+        architecture groups)."""
+        ok = getattr(self, "_skippable_dims", None)
+        if ok is None:
+            ok = True
+            for blk in self.blocks:
+                if isinstance(blk, Block):
+                    dims = (blk.attn.qkv.in_features, blk.attn.num_heads * blk.attn.head_dim, blk.mlp.fc1.out_features)
+                    ok = ok and all(d % 64 == 0 for d in dims)
+            self._skippable_dims = ok
+        return ok and self.compute_dtype == torch.bfloat16 and not Fn.WGRAD_STORE
 
     def _dp_scales_host(self, plan):
         """DropPath scales floor(keep_prob + u) / keep_prob (nets/drop.py:21-26) of one forward, [n_dp, B] float32 on the host in
@@ -618,8 +639,14 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                 kh = flat[:nk].reshape(plan.keeps_host.shape)
                 for L in plan.layers:
                     if L is not None and L.get("dp") is not None and L.get("attn") is not None and L.get("mlp") is not None:
-                        kh[L["attn"]][plan.scales_host[L["dp"]] == 0] = 0
-                        kh[L["mlp"]][plan.scales_host[L["dp"] + 1] == 0] = 0
+                        # (width k -> -(k + 2), not 0: a sample masked on its own shares kernel tiles with the live rows of its
+                        # architecture group; every kernel reads a negative width as 0, and gemm_ntk.hip's write skipping decodes
+                        # the group's width from it -- the sample's zeros below that width are stored.  A layer dropped for the
+                        # whole group keeps its 0: nothing of it is written or read)
+                        ra, rm = kh[L["attn"]], kh[L["mlp"]]
+                        da, dm = (plan.scales_host[L["dp"]] == 0) & (ra > 0), (plan.scales_host[L["dp"] + 1] == 0) & (rm > 0)
+                        ra[da] = -ra[da] - 2
+                        rm[dm] = -rm[dm] - 2
         return flat, nk
 
     def attach_plan_buffer(self, plan, dev_flat, nk):
@@ -777,6 +804,13 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         return stem.embed_params(self, need_bwd)      # (need_bwd: also the flipped weights of the data-gradient convolutions)
 
     def _run_forward(self, x, plan, with_patch, save):
+        K.WRITE_SKIP[0] = plan.skip_writes       # (for the GEMMs of THIS forward only: other callers of kernels.gemm get whole outputs)
+        try:
+            return self._run_forward_impl(x, plan, with_patch, save)
+        finally:
+            K.WRITE_SKIP[0] = False
+
+    def _run_forward_impl(self, x, plan, with_patch, save):
         a = self._arena
         if save and Fn.reset_ln_grads(self) and a.get("ln_parts_flat") is not None:      # (a backward died: see _run_backward)
             a["ln_parts_flat"].zero_()
@@ -996,6 +1030,13 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         return out[0] if parts == 2 else out
 
     def _bwd_loop(self, st, stop):
+        K.WRITE_SKIP[0] = st["plan"].skip_writes
+        try:
+            return self._bwd_loop_impl(st, stop)
+        finally:
+            K.WRITE_SKIP[0] = False
+
+    def _bwd_loop_impl(self, st, stop):
         a = self._arena
         gv = self._gview
         dev = a["flat"].device
