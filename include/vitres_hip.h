@@ -105,15 +105,23 @@ typedef struct vr_gemm_args {
                             capped at two resident workgroups per CU, VITRES_TN_GROUP_CAP); 0x100 = gemm_nt.hip's kernels instead of the
                             lean-loop ones (gemm_ntk.hip); 0x600 / 0x1800 = slices in flight (1 - 3) / tile (1: 128 x 128, 2: 64 x 128,
                             3: 64 x 64) of the lean-loop kernels instead of their grid-size rule (tests); 8, 16, 32: measurement aids of
-                            gemm_nt.hip (force its kernels, record stamps) */
+                            gemm_nt.hip (force its kernels, record stamps);
+                            0x40000 = the caller vouches that every reader of C / C2 is a kernel that tiles group by group (m_groups
+                            below) and skips the masked channels of a row's group: bf16 outputs without a residual then leave
+                            tiles that are masked (keep_n) for every row UNWRITTEN instead of storing zeros; 0x80000 = an operand
+                            of this launch was produced that way -- the launch runs on the group-by-group kernels or fails with
+                            VR_EUNSUPPORTED, it is never handed to a kernel that tiles across groups */
     vr_rowmap a_map;     /* remap of A's token rows (M index if a_trans==0, K index if a_trans==1) */
     vr_rowmap b_map;     /* remap of B's token rows (only meaningful when b_trans==1 && a_trans==1) */
     vr_rowmap c_map;     /* remap of output rows */
     int32_t m_groups;    /* > 1: the token index (M rows; wgrad: K tokens) consists of this many equal, contiguous groups of samples
                             with different keep_k / keep_n each -- the architecture groups of the supernet's multi-arch step
-                            (engine.py:119-165, channel_drop.py:101-105).  Pure scheduling hint: the kernels interleave the groups'
-                            row tiles (wgrad: token splits) in their XCD-contiguous workgroup order, so that no XCD is dealt only
-                            the sparsest (or only the densest) architecture; 0 / 1: one group */
+                            (engine.py:119-165, channel_drop.py:101-105).  The kernels interleave the groups' row tiles (wgrad:
+                            token splits) in their XCD-contiguous workgroup order, so that no XCD is dealt only the sparsest (or
+                            only the densest) architecture; when m_groups divides the rows, the bf16 kernels (gemm_ntk / gemm_nt_ln
+                            / gemm_tn) also cut the grid per group -- no tile or token split holds rows of two groups (the last
+                            tile of a group is short).  Results do not depend on it.  A keep value -(k + 2) marks a sample that is
+                            masked on its own inside a group of width k (DropPath): every kernel reads it as 0.  0 / 1: one group */
     void* ws;            /* optional workspace of the split-K form (sched 64, VITRES_NT_SPLIT): the workgroups that share a tile exchange
                             fp32 partial accumulators through it.  >= vr_gemm_ws_bytes() bytes, 16-byte aligned, ZERO before its first
                             use (the kernels leave its tickets at zero), never shared by launches that may run concurrently (one per
