@@ -749,7 +749,8 @@ def test_single_stage_patch16_sibling_vs_reference_golden(mode, dtype):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,defer", [(torch.float32, "0"), (torch.bfloat16, "0"), (torch.bfloat16, "1"), (torch.float32, "1"),
                                          (torch.bfloat16, "overlap1"), (torch.bfloat16, "overlap2"), (torch.float32, "overlap2"),
-                                         (torch.float32, "overlap2s2"), (torch.bfloat16, "overlap2s2")])
+                                         (torch.float32, "overlap2s2"), (torch.bfloat16, "overlap2s2"),
+                                         (torch.bfloat16, "1+overlap1")])
 def test_optimizer_inside_the_graph_equals_step_after_the_graph(dtype, defer, monkeypatch):
     """GraphedTrainStep(optimizer=FlatAdamW): the AdamW update captured into the step's hipGraph (hyper-parameters read from device
     memory that prepare_step() rewrites per step) walks the same parameter trajectory as graph replay + optimizer.step(),
@@ -768,8 +769,10 @@ def test_optimizer_inside_the_graph_equals_step_after_the_graph(dtype, defer, mo
         defer = defer[:-2]
         monkeypatch.setattr(Fn, "N_SIDE", 2)
         monkeypatch.setattr(Fn, "_side_streams", {})
-    overlap = defer[len("overlap"):] if defer.startswith("overlap") else "0"
-    defer = "0" if defer.startswith("overlap") else defer
+    # 1+overlap1 (round 5): VITRES_OPT_DEFER=1 with the DEFAULT overlap setting -- the early-update cut used to stay armed and left
+    # the capture with unjoined side work
+    overlap = "1" if defer == "1+overlap1" else (defer[len("overlap"):] if defer.startswith("overlap") else "0")
+    defer = "1" if defer == "1+overlap1" else ("0" if defer.startswith("overlap") else defer)
     monkeypatch.setenv("VITRES_OPT_DEFER", defer)
     monkeypatch.setenv("VITRES_OPT_OVERLAP", overlap)
     monkeypatch.setenv("VITRES_OPT_OVERLAP_BLOCKS", "8")

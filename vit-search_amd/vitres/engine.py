@@ -379,7 +379,7 @@ class GraphedTrainStep:
                 # of the backward; what is left (the first stage + embedding) follows the backward at full width.
                 n_early = int(os.environ.get("VITRES_OPT_OVERLAP", "1"))
                 opt_cut = None
-                if n_early > 0:
+                if n_early > 0 and self.defer is None:             # (the deferred form updates beside the NEXT forward: no cut)
                     oc = model.split_plan(parts=max(n_early + 1, 3))
                     oc = oc[:n_early] if isinstance(oc, list) else None
                     if oc:
