@@ -1102,3 +1102,52 @@ def test_gemm_lean_loop_periodic_masks_and_rowmaps(nbuf):
     ref = E.gemm(x, w2, torch.zeros(Mp, 512, dtype=torch.bfloat16), **kw)
     real = K.gemm(x.to(DEV), w2.to(DEV), torch.zeros(Mp, 512, dtype=torch.bfloat16, device=DEV), sched=sched, **{k: to(v) for k, v in kw.items()})
     assert relerr(real, ref) < tol(torch.bfloat16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_gemm_masked_tiles_unwritten_and_readers_refused(tile, monkeypatch):
+    """Round 5, vr_gemm_args.sched 0x40000 / 0x80000 and the per-group grid (m_groups divides the rows): four architecture groups of
+    widths 512 / 256 / 128 / 0 (a dropped layer), one sample of the widest group masked on its own (keep -(512 + 2)).  Written: every
+    tile that holds a kept column of its GROUP -- values of the emulation, zeros beyond a row's width, zeros for the marked sample;
+    left as they were (NaN here): the tiles beyond the group's width and the whole dropped group.  Without the bit everything is
+    written.  A reader of such an operand (bit 0x80000) that the group-by-group kernels do not cover (K % 64 != 0 -> gemm_nt.hip)
+    fails instead of running."""
+    G, spg, rows_in, N, K_ = 4, 2, 65, 512, 256
+    M = G * spg * rows_in                                           # 130 rows per group: two short tiles at 128, three at 64
+    widths = [512, 256, 128, 0]
+    keep = torch.tensor([w for w in widths for _ in range(spg)], dtype=torch.int32)
+    keep[1] = -(512 + 2)
+    a, b = rnd(M, K_, seed=1).to(torch.bfloat16), rnd(N, K_, seed=2, scale=K_ ** -0.5).to(torch.bfloat16)
+    bias = rnd(N, seed=3)
+    kw = dict(M=M, N=N, K=K_, lda=K_, ldb=K_, ldc=N, bias=bias, keep_n=keep, rows_in=rows_in)
+    ref = E.gemm(a, b, torch.zeros(M, N, dtype=torch.bfloat16), **kw)
+    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+    kw_d = {k: to(v) for k, v in kw.items()}
+    BN = 64 if tile == 3 else 128
+    K.M_GROUPS[0] = G
+    try:
+        for skip in (False, True):
+            K.WRITE_SKIP[0] = skip
+            out = K.gemm(a.to(DEV), b.to(DEV), torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV), sched=tile << 11,
+                         **kw_d).cpu()
+            for g_, w in enumerate(widths):
+                rows = slice(g_ * spg * rows_in, (g_ + 1) * spg * rows_in)
+                wr = (w + BN - 1) // BN * BN if skip else N           # columns of the group's written tiles
+                assert torch.isfinite(out[rows, :wr]).all(), (skip, g_)
+                if wr:
+                    assert relerr(out[rows, :wr], ref[rows, :wr]) < 8e-3, (skip, g_)
+                assert torch.isnan(out[rows, wr:]).all(), (skip, g_)  # untouched
+            assert float(out[rows_in:2 * rows_in].abs().max()) == 0.0  # the sample masked on its own: zeros, stored
+        # a reader the group-by-group kernels do not cover
+        K.WRITE_SKIP[0] = False
+        K2 = 96
+        a2, b2 = rnd(M, K2, seed=4).to(torch.bfloat16).to(DEV), rnd(N, K2, seed=5).to(torch.bfloat16).to(DEV)
+        kk = torch.tensor([w * K2 // 512 for w in widths for _ in range(spg)], dtype=torch.int32, device=DEV)
+        o2 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        K.gemm(a2, b2, o2, M=M, N=N, K=K2, lda=K2, ldb=K2, ldc=N, keep_k=kk, rows_in=rows_in)       # fine without the bit
+        with pytest.raises(RuntimeError, match="VR_EUNSUPPORTED"):
+            K.gemm(a2, b2, o2, M=M, N=N, K=K2, lda=K2, ldb=K2, ldc=N, keep_k=kk, rows_in=rows_in, sched=K.READS_SKIPPED_BIT)
+    finally:
+        K.M_GROUPS[0] = 1
+        K.WRITE_SKIP[0] = False
