@@ -214,3 +214,52 @@ def test_sync_ranges_tile_the_gradient_arena_for_every_shipped_network():
             for m in blocks[:cut]:
                 for p in m.parameters():
                     assert a["offsets"][a["index"][id(p)]][0] < start
+
+
+def test_plan_marks_for_write_skipping():
+    """Round 5 host logic (no GPU): _Plan.skip_writes is set only when every kernel tile of the batch sees one architecture (G
+    contiguous groups, or one architecture for the whole batch), the network's masked widths are multiples of the 64-wide slice and the
+    bf16 kernels run; the rows the KERNELS read mark a DropPath-dropped sample of a live layer as -(k + 2) (k = its group's width),
+    keep a dropped layer's 0, and leave the sampled keeps reported to the caller alone."""
+    sp = supernet_config.sr_tiny
+
+    def make(epa, nd=sp.network_def, cfg=sp.num_channels_to_keep, img=224, classes=1000):
+        with torch.device("meta"):
+            m = vitres.create_model("flexible_vit_sr_patch14_224_patch_output_supernet", img_size=img, num_classes=classes, network_def=nd,
+                                    drop_path_rate=0.4, num_channels_to_keep=cfg, example_per_arch=epa, num_warmup_epochs=30)
+        m.train()
+        m.set_epoch(31)
+        return m
+    m = make(8)
+    torch.manual_seed(5)
+    plan = m.sample_plan(32)
+    assert plan.groups == 4 and plan.skip_writes
+    assert make(32).sample_plan(32).skip_writes                       # one architecture for the whole batch
+    assert not make(1).sample_plan(32).skip_writes                    # an architecture per sample: tiles mix them
+    m32 = make(8)
+    m32.compute_dtype = torch.float32
+    assert not m32.sample_plan(32).skip_writes                        # exact-fp32 kernels: no skipping forms
+    micro = make(2, nd=recipe.MICRO_DEFS[0], cfg=recipe.micro_keep_config(), img=recipe.MICRO_IMG, classes=recipe.MICRO_CLASSES)
+    assert not micro.sample_plan(8).skip_writes                       # widths of 32 / 48: not the lean kernels' forms
+    m.drop_path_generator(seed=3)
+    seen_mark = seen_dead = False
+    for seed in range(6):
+        torch.manual_seed(40 + seed)
+        plan = m.sample_plan(32)
+        reported = [k.clone() for k in m.last_keeps]
+        flat, nk = m.plan_host_buffer(plan)
+        kh = flat[:nk].reshape(plan.keeps_host.shape)
+        for L in plan.layers:
+            if L is None or L.get("attn") is None or L.get("dp") is None:
+                continue
+            for row, srow in ((L["attn"], L["dp"]), (L["mlp"], L["dp"] + 1)):
+                sampled, sent = plan.keeps_host[row], kh[row]
+                dropped = plan.scales_host[srow] == 0
+                live = sampled > 0
+                assert (sent[~dropped] == sampled[~dropped]).all()
+                assert (sent[dropped & live] == -sampled[dropped & live] - 2).all()
+                assert (sent[~live] == 0).all()
+                seen_mark |= bool((dropped & live).any())
+                seen_dead |= bool((~live).any())
+        assert all(torch.equal(a, b) for a, b in zip(reported, m.last_keeps))
+    assert seen_mark and seen_dead
