@@ -41,12 +41,13 @@ REF_TINY_DEF = ((4, 192),) + ((1, (192, 3, 64), (192, 768), 1),) * 4 + ((3, 192,
     ((1, (384, 6, 64), (384, 1536), 1),) * 4 + ((3, 384, 768),) + \
     ((1, (768, 12, 64), (768, 3072), 1),) * 4 + ((2, 768, 1000),)
 MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}      # dense TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_ROUND = "r06"                            # profiles/<round>_traffic_<workload>.json, <round>_graph_kernels_<workload>.json
 
 
 def load_traffic(workload, batch, dtype):
-    """PMC traffic of this workload (tools/traffic_run.sh -> profiles/r05_traffic_<workload>.json), used only when the file was
+    """PMC traffic of this workload (tools/traffic_run.sh -> profiles/r06_traffic_<workload>.json), used only when the file was
     measured on the same workload, per-GPU batch and dtype as this run (its "key"); otherwise `traffic` stays null."""
-    name = "r05_traffic_%s.json" % workload
+    name = "%s_traffic_%s.json" % (PROFILE_ROUND, workload)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
     try:
         tj = json.load(open(path))
@@ -553,6 +554,7 @@ def main():
                         traffic = round(tv["read_bytes_per_launch"] + tv["write_bytes_per_launch"], 1)
                         traffic_note = "HBM-side bytes per launch (read + write) of %s from profiles/%s: %s" % (fam, tj_name, tj["source"])
             r.update({"traffic": traffic, "traffic_note": traffic_note,
+                      "traffic_over_algorithmic": (round(traffic / (by / n), 3) if traffic else None),
                       "arithmetic_intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
                       "launches_per_step": n // args.profile_steps, "avg_launch_us": round(sec / n * 1e6, 2),
                       "flops_per_launch": fl / n, "dense_flops_per_launch": dense / n, "algorithmic_bytes_per_launch": by / n,
@@ -573,7 +575,7 @@ def main():
         # the same family inside the replayed graph (rocprofv3 trace of this workload, tools/prof_step.sh): eager launches run ~10 %
         # slower than the graph's, so `frac` above is the pessimistic figure
         try:
-            gj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_graph_kernels_%s.json" % args.workload)))
+            gj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "%s_graph_kernels_%s.json" % (PROFILE_ROUND, args.workload))))
         except (OSError, ValueError):
             gj = None
         if gj and gj.get("key") == {"workload": args.workload, "batch": int(B), "dtype": args.dtype}:
@@ -583,7 +585,7 @@ def main():
                 gb_ = roof["algorithmic_bytes_per_launch"] / us / 1e3
                 roof["graph"] = {"avg_launch_us": round(us, 2), "achieved_GBps": round(gb_, 1), "frac_hbm": round(gb_ / HBM_PEAK, 4),
                                  "achieved_TFLOPs_kept": round(roof["flops_per_launch"] / us / 1e6, 2),
-                                 "source": "profiles/r05_graph_kernels_%s.json: %s" % (args.workload, gj["source"])}
+                                 "source": "profiles/%s_graph_kernels_%s.json: %s" % (PROFILE_ROUND, args.workload, gj["source"])}
         roof.update({
                 "note": "FLOPs and bytes = kept (un-masked) sub-problems only; HIP events (recorded on the stream each kernel is launched "
                         "on) around every vr_gemm launch of %d extra eager steps after the timed region, each queued behind a 40 ms GPU spin so that "

@@ -127,6 +127,13 @@ typedef struct vr_gemm_args {
                             use (the kernels leave its tickets at zero), never shared by launches that may run concurrently (one per
                             stream).  NULL: every tile is computed by one workgroup. */
     int64_t ws_bytes;
+    int32_t ring;        /* lean-loop bf16 kernels (gemm_ntk.hip): slice buffers of the K loop's ring (1 - 6; one slice is multiplied while
+                            ring - 1 are in flight).  0 = the library's rule: as deep as LDS allows without lowering the number of
+                            workgroups the grid gives a CU */
+    int32_t k_shares;    /* lean-loop bf16 kernels: workgroups that share a tile's K slices (needs ws; the partial fp32 tiles meet in ws by
+                            plain stores, the last arriver sums them in share order and runs the epilogue -- results do not depend on
+                            arrival order).  0 = the library's rule (under-filled grids with >= 16 slices), 1 = never, 2 - 4 = that many
+                            wherever the form has a split kernel */
 } vr_gemm_args;
 
 /* bytes of vr_gemm_args.ws that enable tile sharing on the current device */

@@ -24,7 +24,8 @@ def _flat2d(t, ld):
 
 def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
          scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
-         a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0):
+         a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0, ws=None, ring=0,
+         k_shares=0, m_groups=None):
     # keep_k / k_period are pure work-skipping hints (the skipped operands are zero by contract): ignored here
     A2, B2 = _flat2d(a, lda), _flat2d(b, ldb)
     if not a_trans:

@@ -348,3 +348,83 @@ def test_masked_tiles_left_unwritten_are_never_read(case, monkeypatch):
             print(mode, "loss %.2e, gradients %.2e" % (abs(l0 - l1) / abs(l0), rel(g1, g0)))
             assert abs(l0 - l1) <= max(4 * noise_l, 2e-6) * abs(l0), (case, mode, l0, l1, noise_l)
             assert rel(g1, g0) < max(4 * noise_g, 1e-4), (case, mode, rel(g1, g0), noise_g)
+
+
+def test_benched_configuration_vs_cpu_oracle():
+    """the BENCHED configuration itself -- sr_tiny supernet, B = 128, example_per_arch 64 (two
+    architecture groups of 64: the group-pure tiling, group_tile_rows, write skipping and token splits bench.py runs), epoch 31,
+    drop_path 0.2 on injected draws -- against the CPU oracle (pinned to the reference by F1-F19) run on this box's host cores on
+    the SAME weights, inputs, keeps and DropPath draws (reference engine.py:112-157, nets/channel_drop.py:93-111).
+      fp32 HIP kernels: logits <= 1e-3 (north_star gate), loss <= 1e-4, masks bit-exact, every parameter gradient <= 5e-4 (whole
+        tensors, relative to the tensor's largest element);
+      bf16 kernels with write skipping ON against the same oracle outputs: the documented bf16 band (logits <= 3e-2, loss <= 1e-2,
+        per-tensor gradient norm <= 5e-2)."""
+    from test_oracle_golden import oracle_noise
+    from vitres import supernet_config
+    from vitres.nets import vit_sr_supernet as V
+    B, epa, dp = 128, 64, 0.2
+    prod = make(recipe.SR_TINY_DEF, "sr_tiny", dp, epa=epa)
+    orc = O.OracleViTSR(recipe.SR_TINY_DEF, num_classes=1000, drop_path_rate=dp, supernet=True, patch_output=True,
+                        num_channels_to_keep=supernet_config.sr_tiny.num_channels_to_keep, example_per_arch=epa, num_warmup_epochs=30)
+    shapes = [(k, tuple(v.shape)) for k, v in orc.state_dict().items()]
+    assert shapes == [(k, tuple(v.shape)) for k, v in prod.state_dict().items()]
+    sd = recipe.fill_state_dict(shapes, 4343)
+    x, t, pt, _ = recipe.inputs(23, B, 224, 1000, 16)
+    rates = [b.dp for b in orc.blocks if isinstance(b, O.OracleBlock) and b.dp > 0]
+    noise = recipe.drop_path_noise(1234, rates, B)
+    prod = prod.to(DEV)
+    prod.train(); orc.train()
+    prod.set_epoch(31); orc.set_epoch(31)
+    prod.load_state_dict(sd); orc.load_state_dict(sd)
+    xd, td, ptd = x.to(DEV), t.to(DEV), pt.to(DEV)
+
+    def hip(dtype):
+        prod.set_compute_dtype(dtype)
+        prod._arena = None
+        prod.load_state_dict(sd)
+        prod.zero_grad(set_to_none=True)
+        torch.manual_seed(77)
+        plan = prod.sample_plan(B)
+        assert plan.groups == B // epa and plan.n_dp == len(noise)
+        plan.dp_noise = torch.from_numpy(np.stack(noise))
+        cls, pat = prod(xd, patch_output_type="seq", plan=plan)
+        loss = O.soft_target_ce(cls, td) + O.soft_target_ce(pat, ptd)
+        loss.backward()
+        torch.cuda.synchronize()
+        return plan, cls.detach().float().cpu(), pat.detach().float().cpu(), float(loss), \
+            {n: p.grad.detach().float().cpu() for n, p in prod.named_parameters()}
+
+    plan, cls, pat, loss, grads = hip(torch.float32)
+    keeps = [k.clone() for k in prod.last_keeps]
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.manual_seed(77)                       # the oracle draws its own architectures from the same seed: masks bit-exact
+    (ocls, opat), drawn = orc(x, dp_noise=oracle_noise(orc, noise), patch_output_type="seq", return_keeps=True)
+    assert len(drawn) == len(keeps) and all(torch.equal(a, b) for a, b in zip(drawn, keeps))
+    oloss = O.soft_target_ce(ocls, t) + O.soft_target_ce(opat, pt)
+    oloss.backward()
+    ograds = {n: p.grad.detach() for n, p in orc.named_parameters()}
+    ocls, opat, oloss = ocls.detach(), opat.detach(), float(oloss)
+    G_ = B // epa                                 # caller order: sample b runs architecture b % G (channel_drop.py:101-105)
+    assert any(not torch.equal(k[0::G_], k[1::G_]) for k in keeps), "the two architecture groups drew different widths"
+    # fp32 parity mode
+    e_cls, e_pat = rel(cls, ocls), rel(pat, opat)
+    worst = max(rel(grads[n], ograds[n]) for n in ograds)
+    print("B=128/epa=64 fp32 vs CPU oracle: logits %.2e / %.2e, loss %.2e, worst gradient %.2e" % (
+        e_cls, e_pat, abs(loss - oloss) / abs(oloss), worst))
+    assert e_cls < 1e-3 and e_pat < 1e-3, (e_cls, e_pat)
+    assert abs(loss - oloss) < 1e-4 * abs(oloss)
+    for n in ograds:
+        assert rel(grads[n], ograds[n]) < 5e-4, (n, rel(grads[n], ograds[n]))
+    # bf16 fast path, masked tiles left unwritten (the benched kernels), against the same oracle outputs
+    assert V._SKIP_WRITES
+    plan_b, cls_b, pat_b, loss_b, grads_b = hip(torch.bfloat16)
+    assert plan_b.skip_writes, "the benched path leaves masked tiles unwritten"
+    assert all(torch.equal(a, b) for a, b in zip(prod.last_keeps, keeps))
+    drift = {n: abs(float(grads_b[n].double().norm()) - float(ograds[n].double().norm())) / max(float(ograds[n].double().norm()), 1e-12)
+             for n in ograds}
+    wn = max(drift, key=drift.get)
+    print("B=128/epa=64 bf16 (write skipping) vs CPU oracle: logits %.2e / %.2e, loss %.2e, worst gradient-norm drift %.2e (%s)" % (
+        rel(cls_b, ocls), rel(pat_b, opat), abs(loss_b - oloss) / abs(oloss), drift[wn], wn))
+    assert rel(cls_b, ocls) < 3e-2 and rel(pat_b, opat) < 3e-2
+    assert abs(loss_b - oloss) < 1e-2 * abs(oloss)
+    assert drift[wn] < 5e-2, (wn, drift[wn])

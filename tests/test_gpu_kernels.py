@@ -104,15 +104,17 @@ def _wide_case(M, N, K_, variant, rows_in, seed=0):
     return a, b, torch.zeros(M, N, dtype=out_dtype), kw
 
 
-@pytest.mark.parametrize("M,N,K_,rows_in", [(2176, 1024, 3072, 17), (8320, 512, 1536, 65), (2176, 1024, 2304, 17), (1300, 320, 640, 65),
-                                            (4 * 257, 512, 192, 257)])
-@pytest.mark.parametrize("variant", ["res", "dgrad"])
-@pytest.mark.parametrize("sched", [64, 65])
-def test_gemm_split_k(M, N, K_, rows_in, variant, sched):
-    """Split-K form of the 4-wave kernel (gemm_nt.hip SPLIT, sched bit 64: by grid size -- three shares per tile at the first three
-    shapes, two forced at the small ones; bit 1 there: two slices per round): fp32-residual forward and the plain bf16 data
-    gradient, prefix masks on both sides (a share beyond a tile's kept prefix has no slices), launch after launch -- the tickets
-    must come back to zero -- and beside a busy second stream (no share may wait for another)."""
+@pytest.mark.parametrize("M,N,K_,rows_in", [(2176, 1024, 3072, 17), (8320, 512, 1536, 65), (2176, 3072, 1024, 17), (1300, 320, 640, 65),
+                                            (4 * 257, 512, 256, 257)])
+@pytest.mark.parametrize("variant", ["fwd", "gelu", "res", "dgrad", "dmul"])
+@pytest.mark.parametrize("groups", [1, 2])
+def test_gemm_k_shares(M, N, K_, rows_in, variant, groups):
+    """K-split of the lean-loop kernel (gemm_ntk.hip SPLIT, vr_gemm_args.k_shares; round 6): 2 - 4 workgroups share a tile's live
+    slices round-robin, their fp32 partial tiles meet in vr_gemm_args.ws by plain stores and the last arriver sums them in share
+    order.  Every block-Linear form x tile x ring x share count, prefix masks on both sides (shares without a live slice), one and
+    two architecture groups (the group-pure grid), launch after launch beside a busy second stream (nobody may wait for anybody):
+    against the emulation, against the unsplit kernel, bit-identical from run to run (the sum does not depend on arrival order),
+    tickets back at zero."""
     a, b, out, kw = _wide_case(M, N, K_, variant, rows_in)
     ref = E.gemm(a, b, out.clone(), **{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
     to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
@@ -124,14 +126,128 @@ def test_gemm_split_k(M, N, K_, rows_in, variant, sched):
     with torch.cuda.stream(side):
         for _ in range(3):
             busy = torch.tanh(busy @ busy * 1e-2)
-    for rep in range(4):
-        real = K.gemm(ad, bd, torch.full_like(out, float("nan")).to(DEV), sched=sched, **kw_d)
-        torch.cuda.synchronize()
-        assert relerr(real, ref) < t_, (variant, rep, relerr(real, ref))
     ws = K._workspace(torch.device(DEV))
-    assert ws is not None and int(ws[:8192].view(torch.int32).abs().sum()) == 0          # tickets back at zero
-    plain = K.gemm(ad, bd, torch.zeros_like(out).to(DEV), sched=0, **kw_d)
-    assert relerr(plain, ref) < t_
+    assert ws is not None
+    for tile in (1, 2, 3):
+        plain = K.gemm(ad, bd, torch.full_like(out, float("nan")).to(DEV), sched=tile << 11, k_shares=1, m_groups=groups, **kw_d).clone()
+        assert relerr(plain, ref) < t_
+        for ring in (1, 2, 3):
+            for shares in (2, 3, 4):
+                runs = []
+                for rep in range(2):
+                    real = K.gemm(ad, bd, torch.full_like(out, float("nan")).to(DEV), sched=tile << 11, ring=ring, k_shares=shares,
+                                  m_groups=groups, **kw_d)
+                    torch.cuda.synchronize()
+                    assert relerr(real, ref) < t_, (variant, tile, ring, shares, rep, relerr(real, ref))
+                    assert relerr(real, plain) < (2e-5 if out.dtype == torch.float32 else 8e-3)
+                    runs.append(real.clone())
+                assert torch.equal(runs[0], runs[1]), (variant, tile, ring, shares)
+        if variant == "gelu":
+            ref2 = torch.zeros(M, N, dtype=torch.bfloat16)
+            kw2 = dict(kw); kw2["out2"] = ref2
+            E.gemm(a, b, out.clone(), **kw2)
+            assert relerr(kw_d["out2"], ref2) < t_
+    assert int(ws[:16384].view(torch.int32).abs().sum()) == 0          # tickets back at zero
+    # the library's own rule on the same problem (whatever it chooses) agrees too
+    auto = K.gemm(ad, bd, torch.full_like(out, float("nan")).to(DEV), m_groups=groups, **kw_d)
+    assert relerr(auto, ref) < t_
+
+
+@pytest.mark.parametrize("M,N,K_,rows_in", [(12 * 257, 768, 256, 257), (6 * 257, 776, 320, 257), (10 * 65, 256, 192, 65), (4 * 257, 1024, 256, 257)])
+@pytest.mark.parametrize("variant", ["fwd", "gelu", "dmulk", "dgradk"])
+@pytest.mark.parametrize("groups", [1, 2])
+def test_gemm_panel_resident(M, N, K_, rows_in, variant, groups):
+    """gemm_panel.hip (round 6): the A panel resident in LDS, the weight strips in registers, both panel heights (144 rows x 8
+    waves, 80 rows x 4 waves; sched 0x200000 / 0x800000 force them), the four stage-1 forms (qkv-like bias store with per-head
+    periodic column masks, fc1 GELU pair, fc2 data gradient times the saved gelu', plain data gradient -- the last two on a
+    K-contiguous weight), prefix masks on K (k-steps beyond a panel's widest sample are never loaded or multiplied), ragged last
+    panels and column strips, one and two architecture groups; against the emulation and the tiled lean kernel (sched 0x100000)."""
+    Bn = M // rows_in
+    g = torch.Generator().manual_seed(7)
+    a = rnd(M, K_, seed=1).to(torch.bfloat16)
+    keep_k = torch.full((Bn,), K_, dtype=torch.int32)
+    keep_k[Bn // 2:] = (K_ * 5 // 8) // 32 * 32
+    a = a * (torch.arange(K_)[None, :] < keep_k.long().repeat_interleave(rows_in)[:, None])
+    b = rnd(N, K_, seed=2, scale=K_ ** -0.5).to(torch.bfloat16)
+    period = 0
+    keep_n = torch.full((Bn,), N, dtype=torch.int32)
+    if variant == "fwd" and N % 3 == 0 and (N // 3) % 64 == 0:         # qkv layout: per-head prefixes inside three sections
+        period = N // 3
+        keep_n[:] = period
+        keep_n[Bn // 2:] = period // 2
+    else:
+        keep_n[Bn // 2:] = (N * 5 // 8) // 8 * 8
+    keep_n[1] = 0                                                        # a fully masked sample inside a live group
+    kw = dict(M=M, N=N, K=K_, lda=K_, ldb=K_, ldc=N, rows_in=rows_in, keep_n=keep_n, keep_k=keep_k, n_period=period)
+    if variant == "fwd":
+        kw.update(bias=rnd(N, seed=3))
+    elif variant == "gelu":
+        kw.update(bias=rnd(N, seed=3), act=2, out2=torch.zeros(M, N, dtype=torch.bfloat16))
+    elif variant == "dmulk":
+        kw.update(dact_u=rnd(M, N, seed=5).to(torch.bfloat16), ldu=N, act=2)
+    out = torch.zeros(M, N, dtype=torch.bfloat16)
+    ref = E.gemm(a, b, out.clone(), **{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+    kw_d = {k: to(v) for k, v in kw.items()}
+    ad, bd = a.to(DEV), b.to(DEV)
+    tiled = K.gemm(ad, bd, torch.full_like(out, float("nan")).to(DEV), sched=0x100000, m_groups=groups, **kw_d).clone()
+    assert relerr(tiled, ref) < 8e-3
+    for form in ((0x200000,) if K_ > 256 else (0x200000, 0x200000 | 0x800000)):
+        if K_ > 256:
+            form |= 0x800000
+        for rep in range(2):
+            real = K.gemm(ad, bd, torch.full_like(out, float("nan")).to(DEV), sched=form, m_groups=groups, **kw_d)
+            torch.cuda.synchronize()
+            assert relerr(real, ref) < 8e-3, (variant, hex(form), rep, relerr(real, ref))
+            assert relerr(real, tiled) < 8e-3
+        if variant == "gelu":
+            ref2 = torch.zeros(M, N, dtype=torch.bfloat16)
+            kw2 = dict(kw); kw2["out2"] = ref2
+            E.gemm(a, b, out.clone(), **kw2)
+            assert relerr(kw_d["out2"], ref2) < 8e-3
+
+
+@pytest.mark.parametrize("form", [0x200000, 0x200000 | 0x800000])
+def test_gemm_panel_resident_leaves_masked_strips_unwritten(form):
+    """sched 0x40000 on the panel kernel: a 32-column strip is left unwritten only when the whole 64-wide slice it lies in is beyond
+    the width of the panel's architecture group (the readers' granule) -- everything below is written, zeros included; a
+    DropPath-dropped sample (keep -(k + 2)) gets its zeros below its group's width k."""
+    rows_in, Bn, N, K_ = 257, 8, 768, 256
+    M = Bn * rows_in
+    a = rnd(M, K_, seed=1).to(torch.bfloat16)
+    b = rnd(N, K_, seed=2, scale=K_ ** -0.5).to(torch.bfloat16)
+    keep_n = torch.tensor([768, 768, -(768 + 2), 768, 416, 416, -(416 + 2), 416], dtype=torch.int32)
+    kw = dict(M=M, N=N, K=K_, lda=K_, ldb=K_, ldc=N, rows_in=rows_in, keep_n=keep_n.to(DEV), bias=rnd(N, seed=3).to(DEV), act=2,
+              out2=torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV))
+    out = K.gemm(a.to(DEV), b.to(DEV), torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV), sched=form | 0x40000,
+                 m_groups=2, **kw).cpu().float()
+    out2 = kw["out2"].cpu().float()
+    half = M // 2
+    for o in (out, out2):
+        assert torch.isfinite(o[:half]).all()                                  # group 0: full width
+        assert torch.isfinite(o[half:, :448]).all() and torch.isnan(o[half:, 448:]).all()   # group 1: 416 -> slices below 448 written
+        assert (o[2 * rows_in:3 * rows_in] == 0).all()                         # DropPath-dropped sample of group 0: zeros, written
+        assert (o[6 * rows_in:7 * rows_in, :448] == 0).all()
+        assert (o[half:, 416:448] == 0).all()
+    ref_kn = keep_n.clone()
+    ref_kn[ref_kn < 0] = 0
+    ref = E.gemm(a, b, torch.zeros(M, N, dtype=torch.bfloat16), M=M, N=N, K=K_, lda=K_, ldb=K_, ldc=N, rows_in=rows_in, keep_n=ref_kn,
+                 bias=rnd(N, seed=3), act=2, out2=torch.zeros(M, N, dtype=torch.bfloat16))
+    assert relerr(torch.nan_to_num(out), ref) < 8e-3
+
+
+@pytest.mark.parametrize("tile,ring", [(1, 4), (2, 4), (2, 5), (2, 6), (3, 4), (3, 6)])
+@pytest.mark.parametrize("variant", ["fwd", "res", "dgrad", "dmul"])
+def test_gemm_lean_loop_deep_rings(tile, ring, variant):
+    """Rings of 4 - 6 slice buffers (round 6: the rule's choice where a grid gives a CU a single workgroup with >= 16 slices)."""
+    M, N, K_, rows_in = 2176, 1024, 2304, 17
+    a, b, out, kw = _wide_case(M, N, K_, variant, rows_in)
+    ref = E.gemm(a, b, out.clone(), **{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+    kw_d = {k: to(v) for k, v in kw.items()}
+    for rep in range(2):
+        real = K.gemm(a.to(DEV), b.to(DEV), torch.full_like(out, float("nan")).to(DEV), sched=tile << 11, ring=ring, k_shares=1, **kw_d)
+        assert relerr(real, ref) < (1e-4 if out.dtype == torch.float32 else 8e-3), (tile, ring, variant, relerr(real, ref))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -61,7 +61,8 @@ template <int ROWB> __device__ __forceinline__ bfv8 tr_frag(const char* p) {
 // 8 us against 2.5 us for a plain bf16 tile -- 16 KB in flight per workgroup, i.e. latency-bound by registers.  DEPTH = 2: the
 // next round's residual is requested as soon as this round's accumulators are parked (their registers are free then: no
 // higher peak), a round's worth of work ahead of its use; DEPTH = MI (the 8-wave kernel, two waves per SIMD): everything up front.
-template <typename TO, int EPI, bool FAST, int MI, int NJ, int FEAT, int DEPTH = 1>
+// WAITV (gemm_panel.hip): one s_waitcnt vmcnt(0) in front of the tile's first store -- see there.
+template <typename TO, int EPI, bool FAST, int MI, int NJ, int FEAT, int DEPTH = 1, bool WAITV = false>
 __device__ __forceinline__ void epilogue(const vr_gemm_args& p, f32x4 (&acc)[MI][NJ], float* park, const RowMeta* meta0, const int nw0,
                                          const int lane) {
     constexpr int WCOLS = 16 * NJ;
@@ -185,6 +186,9 @@ __device__ __forceinline__ void epilogue(const vr_gemm_args& p, f32x4 (&acc)[MI]
                     if (has_pos) loadw<float, CW>(p.pos, (long long)rm[q].mloc * p.N + nc, pv[q], vecb, nv);
                 }
             }
+        }
+        if constexpr (WAITV) {
+            if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {

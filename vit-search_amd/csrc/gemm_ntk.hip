@@ -17,6 +17,15 @@
 //   * NBUF = 1: one slice buffer, several workgroups per CU overlap each other (the first stage's grids);
 //     NBUF = 2 / 3: slice i + 1 (and i + 2) are in flight while slice i is multiplied -- one s_barrier per slice, counted vmcnt.
 //
+//   * NBUF up to 6 for grids that give a CU one workgroup (the long-K GEMMs of stages 2 / 3): what paces a lone workgroup is the
+//     memory latency divided by the slices it keeps in flight;
+//   * SPLIT (round 6): the live slices of a tile are dealt round-robin to `ksplit` workgroups (consecutive workgroups of ONE XCD:
+//     they run together and share the tile's rows in that XCD's L2).  Each writes its fp32 accumulators to its slab of
+//     vr_gemm_args.ws with plain write-through stores, drains and takes the tile's ticket; the holder of the last ticket acquires,
+//     sums the slabs IN SHARE ORDER (its own included: the result does not depend on who arrives last) and runs the epilogue.
+//     Nobody waits for anybody, no fp32 atomics touch the output, tickets return to zero.  For grids that leave the chip
+//     under-filled with a long serial K loop (stage 2 / 3: 136 - 544 tiles walking 16 - 48 slices).
+//
 // Covered: FAST epilogue forms (N, ldc, ldu, n_period multiples of 8), K a multiple of 64 and at most 4096, FEAT 0 - 3 (no
 // positional embedding), operands below 4 GB.  Everything else stays with gemm_nt.hip / gemm.hip (vr_gemm_ntk_launch returns false).
 #include <algorithm>
@@ -50,8 +59,14 @@ __device__ __forceinline__ int max_keep_wave(const int* keep, int s_lo, int s_hi
     return mk;
 }
 
-template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM, bool DEEP_EPI = false>
-__global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gemm_args p) {
+__device__ __forceinline__ void store_wt(float* p, const f32x4 v) {        // write-through (sc1) 16-byte store
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+constexpr int SPLIT_TICKET_BYTES = 4096 * 4;      // ticket ints in front of the slabs
+constexpr int SPLIT_MAX_TILES = 4096;
+
+template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM, bool DEEP_EPI = false, bool SPLIT = false>
+__global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gemm_args p, const int ksplit) {
     constexpr int BM = 32 * MI, WROWS = 16 * MI;
     constexpr int BN = 32 * NJ, WCOLS = 16 * NJ;
     constexpr int A_BYTES = BM * BK * 2, AP = MI;
@@ -60,7 +75,7 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
     constexpr int META_OFF = NBUF * STAGE_BYTES;
     static_assert(META_OFF >= 4 * 4096, "epilogue park area");
     // ONE shared array (slice ring | row metadata): a second __shared__ object makes hipcc drain the DMA queue before LDS reads
-    __shared__ __attribute__((aligned(1024))) char smem[META_OFF + BM * (int)sizeof(RowMeta)];
+    __shared__ __attribute__((aligned(1024))) char smem[META_OFF + BM * (int)sizeof(RowMeta) + (SPLIT ? 16 : 0)];
     RowMeta* rowmeta = reinterpret_cast<RowMeta*>(smem + META_OFF);
     // forms whose fully masked tiles hold nothing but zeros (bf16 result, no residual): see the write skipping below
     constexpr bool SKIP_FORM = sizeof(TO) == 2 && ((EPI == EPI_STORE && FEAT <= 1) || EPI == EPI_GELU || EPI == EPI_DMUL);
@@ -70,10 +85,20 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = group_tiles(p.M, BM, p.m_groups);
     const int total = tiles_n * tiles_m;
     int tile = blockIdx.x;
-    if (total >= 16) {       // workgroup ids go round-robin to the 8 XCDs: an XCD owns one contiguous run of the n-fastest order
+    int zs = 0;                // SPLIT: this workgroup's share of the tile's slices
+    if constexpr (SPLIT) {     // grid = 8 x ceil(total / 8) x ksplit: XCD x (= id % 8) owns a contiguous run of tiles, its workgroups
+                               // walk (tile, share) share-fastest -- the shares of a tile are neighbours on one XCD
+        const int x = tile & 7, i = tile >> 3;
+        const int xq = total >> 3, xr = total & 7;
+        const int tl = i / ksplit;
+        zs = i - tl * ksplit;
+        if (tl >= xq + (x < xr ? 1 : 0)) return;
+        tile = x * xq + min(x, xr) + tl;
+    } else if (total >= 16) {       // workgroup ids go round-robin to the 8 XCDs: an XCD owns one contiguous run of the n-fastest order
         const int xq = total >> 3, xr = total & 7, x = tile & 7;
         tile = x * xq + min(x, xr) + (tile >> 3);
     }
+    const int tile_lin = tile;
     // row tiles of a multi-architecture batch never straddle two groups (gemm_shared.h group_tile_rows): rows [m0, mend)
     const int tn = tile % tiles_n, n0 = tn * BN;
     int m0, mend;
@@ -134,7 +159,8 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
 
     // ---- the first slice leaves before the masks are known (slice 0 is live whenever anything is) ----
     const int ntiles = p.K / BK;
-    issue(0, 0);
+    const int first = SPLIT ? zs : 0;          // (host: ksplit <= ntiles / 4)
+    issue(first, 0);
 
     // ---- masked-work skipping: live slices as a bit mask ----
     unsigned long long live = ntiles >= 64 ? ~0ull : ((1ull << ntiles) - 1ull);
@@ -177,6 +203,17 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
             }
         }
         if (!any) live = 0;
+    }
+    if constexpr (SPLIT) {               // this share's slices: every ksplit-th live one
+        unsigned long long m = live, mine = 0;
+        int c = 0;
+        while (m) {
+            const int kt = __builtin_ctzll(m);
+            m &= m - 1;
+            if (c == zs) mine |= 1ull << kt;
+            c = c + 1 == ksplit ? 0 : c + 1;
+        }
+        live = mine;
     }
     if (t < BM) {                        // per-row epilogue metadata (its loads overlap the first slice)
         const int m = m0 + t;
@@ -236,8 +273,8 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
     };
 
     // slice 0 went out unconditionally: with nothing live it is drained and dropped
-    const bool first_live = (live & 1ull) != 0;
-    live &= ~1ull;
+    const bool first_live = ((live >> first) & 1ull) != 0;
+    live &= ~(1ull << first);
     if constexpr (NBUF == 1) {
         bool have = first_live;
         if (!first_live && live) {                    // (periodic masks can skip slice 0)
@@ -280,7 +317,10 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
                 ++pending;
             }
             // the head slice has landed when at most the younger slices' pieces are outstanding
-            if (pending >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AP + BP)) : "memory");
+            if (NBUF >= 6 && pending >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AP + BP)) : "memory");
+            else if (NBUF >= 5 && pending == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (AP + BP)) : "memory");
+            else if (NBUF >= 4 && pending == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AP + BP)) : "memory");
+            else if (pending >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AP + BP)) : "memory");
             else if (pending == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + BP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();             // every wave's pieces of the head slice are in LDS; the buffer multiplied last
@@ -300,6 +340,44 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
         __syncthreads();
     }
 
+    if constexpr (SPLIT) {
+        constexpr int SLAB = BM * BN;
+        float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(p.ws) + SPLIT_TICKET_BYTES) + (size_t)tile_lin * ksplit * SLAB;
+        int* tickets = reinterpret_cast<int*>(p.ws);
+        float* mine = slabs + (size_t)zs * SLAB + t * 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) store_wt(mine + (i * NJ + j) * (KTHR * 4), acc[i][j]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem + META_OFF + BM * (int)sizeof(RowMeta));
+        if (t == 0) *flag = __hip_atomic_fetch_add(tickets + tile_lin, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != ksplit - 1) return;                              // not the last share of this tile to arrive
+        if (t == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(tickets + tile_lin, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        // the slabs in share order, this workgroup's own included (read back): a fixed summation order whoever arrives last
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < ksplit; ++z) {
+            const float* src = slabs + (size_t)z * SLAB + t * 4;
+#pragma unroll
+            for (int r0 = 0; r0 < MI * NJ; r0 += 4) {                 // (four 16-byte loads in flight)
+                f32x4 part[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[r] = *reinterpret_cast<const f32x4*>(src + (r0 + r) * (KTHR * 4));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[(r0 + r) / NJ][(r0 + r) % NJ] += part[r];
+            }
+        }
+    }
+
     // side operands of the epilogue (fp32 residual rows, saved gelu'): with two 16-row rounds per wave all of them are requested up
     // front (DEPTH = MI: 32 / 16 registers) -- one exposed HBM latency per tile instead of one per round
     constexpr int EDEPTH = (MI == 2 && DEEP_EPI) ? 2 : 1;
@@ -307,44 +385,54 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
                                                  lane);
 }
 
-template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM> void klaunch(const vr_gemm_args& a, hipStream_t stream) {
+template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM> void klaunch(const vr_gemm_args& a, hipStream_t stream, int shares) {
     const long long total = (long long)group_tiles(a.M, 32 * MI, a.m_groups) * ((a.N + 32 * NJ - 1) / (32 * NJ));
-    static const int knob_deep = std::getenv("VITRES_NTK_DEEP") ? std::atoi(std::getenv("VITRES_NTK_DEEP")) : 1;
     constexpr bool SIDE = (EPI == EPI_STORE && FEAT >= 2) || EPI == EPI_DMUL;
-    if constexpr (MI == 2 && SIDE) {
-        if (knob_deep) {
-            hipLaunchKernelGGL((ntk_kernel<TO, EPI, MI, NJ, NBUF, FEAT, BKM, true>), dim3((unsigned)total), dim3(KTHR), 0, stream, a);
+    // the forms of the block Linears have a split kernel (FEAT 2: a block without DropPath -- the first one -- is never a long-K one)
+    constexpr bool CAN_SPLIT = NBUF <= 3 && ((EPI == EPI_STORE && (FEAT == 0 || FEAT == 1 || FEAT == 3)) || EPI == EPI_GELU || EPI == EPI_DMUL);
+    if constexpr (CAN_SPLIT) {
+        if (shares > 1) {
+            const unsigned grid = (unsigned)(8 * ((total + 7) / 8) * shares);
+            hipLaunchKernelGGL((ntk_kernel<TO, EPI, MI, NJ, NBUF, FEAT, BKM, MI == 2 && SIDE, true>), dim3(grid), dim3(KTHR), 0, stream, a, shares);
             return;
         }
     }
-    hipLaunchKernelGGL((ntk_kernel<TO, EPI, MI, NJ, NBUF, FEAT, BKM>), dim3((unsigned)total), dim3(KTHR), 0, stream, a);
+    hipLaunchKernelGGL((ntk_kernel<TO, EPI, MI, NJ, NBUF, FEAT, BKM, MI == 2 && SIDE>), dim3((unsigned)total), dim3(KTHR), 0, stream, a, 1);
 }
 
-template <typename TO, int EPI, int FEAT, bool BKM> void ktile(const vr_gemm_args& a, hipStream_t stream, int tile, int nbuf) {
+template <typename TO, int EPI, int FEAT, bool BKM> void ktile(const vr_gemm_args& a, hipStream_t stream, int tile, int nbuf, int shares) {
     if (tile == 1) {
-        if (nbuf == 1) klaunch<TO, EPI, 4, 4, 1, FEAT, BKM>(a, stream);
-        else if (nbuf == 2) klaunch<TO, EPI, 4, 4, 2, FEAT, BKM>(a, stream);
-        else klaunch<TO, EPI, 4, 4, 3, FEAT, BKM>(a, stream);
+        if (nbuf == 1) klaunch<TO, EPI, 4, 4, 1, FEAT, BKM>(a, stream, shares);
+        else if (nbuf == 2) klaunch<TO, EPI, 4, 4, 2, FEAT, BKM>(a, stream, shares);
+        else if (nbuf == 3) klaunch<TO, EPI, 4, 4, 3, FEAT, BKM>(a, stream, shares);
+        else klaunch<TO, EPI, 4, 4, 4, FEAT, BKM>(a, stream, 1);
     } else if (tile == 2) {
-        if (nbuf == 1) klaunch<TO, EPI, 2, 4, 1, FEAT, BKM>(a, stream);
-        else if (nbuf == 2) klaunch<TO, EPI, 2, 4, 2, FEAT, BKM>(a, stream);
-        else klaunch<TO, EPI, 2, 4, 3, FEAT, BKM>(a, stream);
+        if (nbuf == 1) klaunch<TO, EPI, 2, 4, 1, FEAT, BKM>(a, stream, shares);
+        else if (nbuf == 2) klaunch<TO, EPI, 2, 4, 2, FEAT, BKM>(a, stream, shares);
+        else if (nbuf == 3) klaunch<TO, EPI, 2, 4, 3, FEAT, BKM>(a, stream, shares);
+        else if (nbuf == 4) klaunch<TO, EPI, 2, 4, 4, FEAT, BKM>(a, stream, 1);
+        else if (nbuf == 5) klaunch<TO, EPI, 2, 4, 5, FEAT, BKM>(a, stream, 1);
+        else klaunch<TO, EPI, 2, 4, 6, FEAT, BKM>(a, stream, 1);
     } else {
-        if (nbuf == 1) klaunch<TO, EPI, 2, 2, 1, FEAT, BKM>(a, stream);
-        else if (nbuf == 2) klaunch<TO, EPI, 2, 2, 2, FEAT, BKM>(a, stream);
-        else klaunch<TO, EPI, 2, 2, 3, FEAT, BKM>(a, stream);
+        if (nbuf == 1) klaunch<TO, EPI, 2, 2, 1, FEAT, BKM>(a, stream, shares);
+        else if (nbuf == 2) klaunch<TO, EPI, 2, 2, 2, FEAT, BKM>(a, stream, shares);
+        else if (nbuf == 3) klaunch<TO, EPI, 2, 2, 3, FEAT, BKM>(a, stream, shares);
+        else if (nbuf == 4) klaunch<TO, EPI, 2, 2, 4, FEAT, BKM>(a, stream, 1);
+        else klaunch<TO, EPI, 2, 2, 6, FEAT, BKM>(a, stream, 1);
     }
 }
 
 }  // namespace vr_gemm_nt
 
+bool vr_gemm_panel_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);      // gemm_panel.hip: panel-resident stage-1 kernels
+
 // Called by vr_gemm_nt_launch in front of gemm_nt.hip's own kernels.  Returns false when the form is not covered here.
 bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_nt;
-    static const int knob = std::getenv("VITRES_NTK") ? std::atoi(std::getenv("VITRES_NTK")) : 1;
-    if (!knob) return false;
-    if (a.sched & (8 | 16 | 32 | 64 | 0x100)) return false;
-          // forms of gemm_nt.hip forced by the caller (tests, measurement aids)
+    if (!(a.sched & (8 | 16 | 32 | 0x100)) && vr_gemm_panel_launch(a, stream, n_cu)) return true;
+    if (a.sched & (8 | 16 | 32 | 0x100)) return false;      // forms of gemm_nt.hip forced by the caller (tests, measurement aids)
+    // an operand with unwritten masked tiles (0x80000) is readable only by the group-pure row tiling: refused where it cannot be had
+    if ((a.sched & 0x80000) && a.keep_k && a.m_groups > 1 && !group_pure(a.M, a.m_groups)) return false;
     if (a.in_dtype != VR_BF16 || a.a_trans || a.atomic || a.split_k > 1 || a.bias_grad || a.pos) return false;
     if (a.K % BK || a.K > 64 * BK || a.K < BK) return false;
     const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);
@@ -368,62 +456,85 @@ bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     // tile by grid size (gemm_nt.hip's measured crossovers); slices in flight by how many workgroups a CU gets
     const long long tn = (a.N + 127) / 128;
     const long long t128 = (long long)((a.M + 127) / 128) * tn, t64 = (long long)((a.M + 63) / 64) * tn;
-    static const int knob_tile = std::getenv("VITRES_NTK_TILE") ? std::atoi(std::getenv("VITRES_NTK_TILE")) : 0;
-    static const int knob_buf = std::getenv("VITRES_NTK_BUF") ? std::atoi(std::getenv("VITRES_NTK_BUF")) : 0;
-    // sched bits 0x1800: tile override (1: 128 x 128, 2: 64 x 128, 3: 64 x 64), bits 0x600: slices-in-flight override (tests)
+    // sched bits 0x1800: tile override (1: 128 x 128, 2: 64 x 128, 3: 64 x 64), 0x600: slice buffers 1 - 3 (tests); vr_gemm_args.ring /
+    // k_shares: slice buffers 1 - 6 / shares
     const int s_tile = (a.sched >> 11) & 3, s_buf = (a.sched >> 9) & 3;
     // (in-graph sweep of all nine tile x depth combinations, profiles/r05_ntk_policy_sweep.txt: 64 x 128 tiles for the forms with a
     // bf16 side operand or two outputs once the 128 x 128 grid is below four / six per CU -- they run beside the weight-gradient
     // group's resident workgroups, which leave room for three 25 KB workgroups but only two 34 KB ones --, and 64 x 64 only when
     // even the 64 x 128 grid leaves CUs empty)
-    static const int knob_pol = std::getenv("VITRES_NTK_POLICY") ? std::atoi(std::getenv("VITRES_NTK_POLICY")) : 1;
     int auto_tile = t128 >= 2LL * n_cu ? 1 : (t64 >= 2LL * n_cu ? 2 : 3);
-    if (knob_pol) {
-        if (auto_tile == 3 && t64 >= n_cu) auto_tile = 2;
-        if (auto_tile == 1 && a.dact_u && a.b_trans) auto_tile = 2;                       // fc2 data gradient (times the saved gelu')
-        if (auto_tile == 1 && gelu && a.C2 && t128 < 4LL * n_cu) auto_tile = 2;           // fc1 forward (training: two outputs) of the second stage
+    if (auto_tile == 3 && t64 >= n_cu) auto_tile = 2;
+    if (auto_tile == 1 && a.dact_u && a.b_trans) auto_tile = 2;                       // fc2 data gradient (times the saved gelu')
+    if (auto_tile == 1 && gelu && a.C2 && t128 < 4LL * n_cu) auto_tile = 2;           // fc1 forward (training: two outputs) of the second stage
+    // K-split (SPLIT kernels).  k_shares: 0 = the rule below, 1 = never, 2 - 4 = that many shares wherever the form has a split
+    // kernel and the workspace holds the slabs.  The rule (tools/ksplit_sweep.py on the stage 2 / 3 shapes, profiles/r06_ksplit_sweep.txt):
+    // what paces a lone workgroup per CU is not the memory latency (rings of 4 - 6 slices: +-0) but its own serial chain of LDS-DMA
+    // issue, LDS reads and MFMAs per slice -- a second / third workgroup on the CU overlaps it.  Four shares pay where they turn a
+    // grid of 1 - 2 workgroups per CU with <= 24 slices into 4 - 8 short-lived ones; with 36 - 48 slices per tile (K = 2304 / 3072)
+    // every split form measured loses to the unsplit 64 x 128 ring (slab round trip + a tail round), as do grids that already give a
+    // CU three workgroups.
+    const bool split_form = feat != 2 && a.ws;
+    const int ntiles = a.K / BK;
+    int shares = 1, rule_tile = 0, rule_ring = 0;
+    if (split_form && a.k_shares == 0 && !s_tile && a.ring == 0) {
+        if (of32 && feat == 3 && ntiles >= 8 && ntiles <= 24 && t64 >= 3LL * n_cu / 2 && t64 <= 3LL * n_cu) {
+            shares = 4; rule_tile = 2; rule_ring = 2;            // proj / fc2 forward of the second stage (fp32 residual stream)
+        } else if (!of32 && ntiles >= 8 && ntiles <= 16 && t128 >= n_cu && t128 < 2LL * n_cu) {
+            shares = 4; rule_tile = a.C2 || a.dact_u ? 1 : 2; rule_ring = 2;   // qkv / fc1 forward, fc2 data gradient of the last stage
+        }
+    } else if (split_form && a.k_shares > 1) {
+        shares = std::min(std::min(a.k_shares, 4), std::max(1, ntiles / 2));
     }
-    const int tile = s_tile ? s_tile : knob_tile ? knob_tile : auto_tile;
-    const long long wgs = tile == 1 ? t128 : (tile == 2 ? t64 : (long long)((a.M + 63) / 64) * ((a.N + 63) / 64));
+    const int tile = s_tile ? s_tile : (rule_tile ? rule_tile : auto_tile);
+    const long long wgs = (long long)group_tiles(a.M, tile == 1 ? 128 : 64, a.m_groups) * ((a.N + (tile == 3 ? 63 : 127)) / (tile == 3 ? 64 : 128));
+    const int stage_kb = tile == 1 ? 32 : (tile == 2 ? 24 : 16);
+    if (shares > 1) {
+        const long long slab = (tile == 1 ? 128LL * 128 : (tile == 2 ? 64LL * 128 : 64LL * 64)) * 4;
+        if (wgs > SPLIT_MAX_TILES || (long long)SPLIT_TICKET_BYTES + wgs * shares * slab > a.ws_bytes) { shares = 1; rule_ring = 0; }
+    }
     // slices in flight: as many as LDS allows WITHOUT lowering the number of workgroups the grid gives a CU (a 96 KB ring that leaves
     // a CU one workgroup where three single-buffer ones would run loses: candidate scoring, M4352 N2304 K1280 36 -> 44 us)
     int auto_buf = 1;
     if (a.K >= 4 * BK) {
-        const int stage_kb = tile == 1 ? 32 : (tile == 2 ? 24 : 16);
-        const int per_cu = (int)std::max<long long>(1, (2 * wgs + n_cu) / (2LL * n_cu));          // workgroups per CU, rounded
+        const long long wg_all = wgs * shares;
+        const int per_cu = (int)std::max<long long>(1, (2 * wg_all + n_cu) / (2LL * n_cu));          // workgroups per CU, rounded
         const int want = std::min(per_cu, tile == 1 ? 4 : 5);
         // data gradients run beside the weight-gradient group, whose two resident workgroups hold 64 KB of a CU's LDS
-        static const int knob_bwd_kb = std::getenv("VITRES_NTK_BWD_LDS_KB") ? std::atoi(std::getenv("VITRES_NTK_BWD_LDS_KB")) : 96;
-        const int lds_kb = a.b_trans ? knob_bwd_kb : 160;
-        for (int nb = (a.K >= 8 * BK ? 3 : 2); nb >= 1; --nb)
+        const int lds_kb = a.b_trans ? 96 : 160;
+        const int deepest = ntiles >= 8 ? 3 : 2;
+        for (int nb = deepest; nb >= 1; --nb)
             if (lds_kb / (nb * stage_kb + 2) >= want) { auto_buf = nb; break; }
     }
-    int nbuf = s_buf ? s_buf : knob_buf ? knob_buf : auto_buf;
+    int nbuf = a.ring > 0 ? a.ring : (s_buf ? s_buf : (rule_ring ? rule_ring : auto_buf));
+    if (nbuf > 3) shares = 1;                                   // (the deep rings have no split kernels)
+    nbuf = std::min(nbuf, tile == 1 ? 4 : 6);
+    if (tile == 3 && nbuf == 5) nbuf = 4;
     if (a.b_trans) {
         if (of32 || feat != 0 || gelu || a.b_map.rpi != 0 || a.ldb < (a.N + 7) / 8 * 8) return false;
         if (a.dact_u) {
             if (a.act != 2) return false;
-            ktile<bf16_t, EPI_DMUL, 0, true>(a, stream, tile, nbuf);
+            ktile<bf16_t, EPI_DMUL, 0, true>(a, stream, tile, nbuf, shares);
         } else {
-            ktile<bf16_t, EPI_STORE, 0, true>(a, stream, tile, nbuf);
+            ktile<bf16_t, EPI_STORE, 0, true>(a, stream, tile, nbuf, shares);
         }
         return true;
     }
     if (a.dact_u) return false;
     if (gelu) {
         if (of32 || feat != 1 || a.act == 3) return false;
-        ktile<bf16_t, EPI_GELU, 1, false>(a, stream, tile, nbuf);
+        ktile<bf16_t, EPI_GELU, 1, false>(a, stream, tile, nbuf, shares);
         return true;
     }
     if (of32) {
-        if (feat == 3) ktile<float, EPI_STORE, 3, false>(a, stream, tile, nbuf);
-        else if (feat == 2) ktile<float, EPI_STORE, 2, false>(a, stream, tile, nbuf);
-        else if (feat == 1) ktile<float, EPI_STORE, 1, false>(a, stream, tile, nbuf);
+        if (feat == 3) ktile<float, EPI_STORE, 3, false>(a, stream, tile, nbuf, shares);
+        else if (feat == 2) ktile<float, EPI_STORE, 2, false>(a, stream, tile, nbuf, shares);
+        else if (feat == 1) ktile<float, EPI_STORE, 1, false>(a, stream, tile, nbuf, shares);
         else return false;
         return true;
     }
-    if (feat == 1) ktile<bf16_t, EPI_STORE, 1, false>(a, stream, tile, nbuf);
-    else if (feat == 0) ktile<bf16_t, EPI_STORE, 0, false>(a, stream, tile, nbuf);
+    if (feat == 1) ktile<bf16_t, EPI_STORE, 1, false>(a, stream, tile, nbuf, shares);
+    else if (feat == 0) ktile<bf16_t, EPI_STORE, 0, false>(a, stream, tile, nbuf, shares);
     else return false;
     return true;
 }

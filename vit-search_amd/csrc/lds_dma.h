@@ -21,7 +21,7 @@ __device__ __forceinline__ v4i make_rsrc(const void* ptr, unsigned num_records) 
     return r;
 }
 __device__ __forceinline__ void dma16(unsigned lds, unsigned voff, v4i rsrc, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 template <typename T> __device__ __forceinline__ unsigned lds_addr(T* p) { return (unsigned)(uintptr_t)(lds_char*)p; }
 }  // namespace vr_dma

@@ -30,7 +30,7 @@ class GemmArgs(ctypes.Structure):
         ("in_dtype", c_int32), ("out_dtype", c_int32),
         ("act", c_int32), ("atomic", c_int32), ("split_k", c_int32), ("rows_in", c_int32), ("n_period", c_int32), ("k_period", c_int32), ("sched", c_int32),
         ("a_map", RowMap), ("b_map", RowMap), ("c_map", RowMap), ("m_groups", c_int32),
-        ("ws", c_void_p), ("ws_bytes", c_int64),
+        ("ws", c_void_p), ("ws_bytes", c_int64), ("ring", c_int32), ("k_shares", c_int32),
     ]
 
 

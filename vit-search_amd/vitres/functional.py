@@ -271,7 +271,7 @@ def wgrad_store_ok(tokens, dtype, is_cuda):
 
 
 def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None, db=None, keep_rows=None,
-                 keep_cols=None, row_period=0, tokens_per_sample=0, sched=0, collect=None, store=False, split=0):
+                 keep_cols=None, row_period=0, tokens_per_sample=0, sched=0, collect=None, store=False, split=0, m_groups=None):
     """dw[N_out, K_in] += dy[M, N_out]^T @ x[M, K_in]  (fp32 atomics, split over tokens; db[N_out] += colsum(dy)).
     keep_rows / keep_cols: per-sample kept prefix of dy's / x's channels -> fully masked tiles are skipped.
     collect: a list -> the call is appended to it instead of being launched (K.gemm_group launches the list as one kernel).
@@ -279,7 +279,8 @@ def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_m
     split: explicit token split (workgroups per output tile); 0 = the kernel's rule (32 slices of 64 tokens per workgroup)."""
     kw = dict(M=N_out, N=K_in, K=M, lda=lddy, ldb=ldx, ldc=ldw or K_in, a_trans=True, b_trans=True,
               atomic=(2 if store else True), split_k=(1 if store else split), a_map=a_map, b_map=b_map, bias_grad=db,
-              keep_k=keep_rows, keep_n=keep_cols, k_period=row_period, rows_in=tokens_per_sample, sched=sched)
+              keep_k=keep_rows, keep_n=keep_cols, k_period=row_period, rows_in=tokens_per_sample, sched=sched,
+              m_groups=(K.M_GROUPS[0] if m_groups is None else m_groups))       # (now: the call may be launched after the backward has returned)
     if collect is not None:
         collect.append((dy, x, dw, kw))
     else:
@@ -371,10 +372,11 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                   # d(branch output), compute dtype
 
     grp = _block_wgrads if (WGRAD_GROUP and g.is_cuda) else None
+    mg = K.M_GROUPS[0]                 # (now: the closures below may run after the backward has returned)
 
     def wgrad_proj():
         linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"], keep_rows=out_keep, keep_cols=attn_keep,
-                     tokens_per_sample=N, sched=wsch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
+                     tokens_per_sample=N, sched=wsch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda), m_groups=mg)
     if grp is not None:
         wgrad_proj()
         if WGRAD_EARLY:
@@ -392,7 +394,7 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     def wgrad_qkv():
         linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C, db=grads["qkv.b"], keep_rows=attn_keep,
                      keep_cols=embed_keep, row_period=HD, tokens_per_sample=N, sched=wsch, collect=grp,
-                     store=wgrad_store_ok(M, dt, g.is_cuda))
+                     store=wgrad_store_ok(M, dt, g.is_cuda), m_groups=mg)
     if grp is not None:
         wgrad_qkv()
         if not WGRAD_EARLY:
@@ -460,11 +462,11 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
 
     grp = _block_wgrads if (WGRAD_GROUP and g.is_cuda) else None
-    rsk = K.reads_skipped()            # (now: the closures below may run after the backward has returned)
+    rsk, mg = K.reads_skipped(), K.M_GROUPS[0]            # (now: the closures below may run after the backward has returned)
 
     def wgrad_fc2():
         linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"], keep_rows=out_keep, keep_cols=mlp_keep,
-                     tokens_per_sample=N, sched=wsch | rsk, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
+                     tokens_per_sample=N, sched=wsch | rsk, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda), m_groups=mg)
     if ov and grp is None:
         on_side(wgrad_fc2, gt)
     else:
@@ -475,7 +477,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
 
     def wgrad_fc1():
         linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"], keep_rows=mlp_keep, keep_cols=embed_keep,
-                     tokens_per_sample=N, sched=wsch | rsk, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda))
+                     tokens_per_sample=N, sched=wsch | rsk, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda), m_groups=mg)
     if ov and grp is None:
         on_side(wgrad_fc1, du)
     else:

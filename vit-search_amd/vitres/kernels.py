@@ -54,7 +54,9 @@ def _rm(m):
 # that finds none while capturing simply runs without tile sharing.
 _WS = {}
 _WS_ROLE = [0]
-_WIDE_ON = __import__("os").environ.get("VITRES_NT_SPLIT", "0") != "0"      # the split-K form of gemm_nt.hip (opt-in) needs the workspace
+# dev aid (A/B inside the step): bits OR-ed into vr_gemm_args.sched / value of k_shares of every forward / data-gradient launch
+_DBG_SCHED_OR = int(__import__("os").environ.get("VITRES_DBG_SCHED_OR", "0"), 0)
+_DBG_K_SHARES = int(__import__("os").environ.get("VITRES_DBG_K_SHARES", "0"))
 
 
 class ws_role:
@@ -79,8 +81,6 @@ def _workspace(dev, role=None):
 
 
 def ensure_workspaces(dev, roles=(0, 1)):
-    if not _WIDE_ON:
-        return
     for r in roles:
         _workspace(torch.device(dev), r)
 
@@ -113,19 +113,23 @@ _GROUP_INTERLEAVE = __import__("os").environ.get("VITRES_GROUP_INTERLEAVE", "1")
 
 def _gemm_args(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
                scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
-               a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0, ws="auto"):
+               a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0, ws="auto",
+               ring=0, k_shares=0, m_groups=None):
     args = GemmArgs()
-    if isinstance(ws, str):         # "auto": the role's workspace, when the split-K form can be chosen at all (opt-in)
-        ws = _workspace(a.device) if ((_WIDE_ON or (sched & (32 | 64))) and not a_trans and a.dtype == torch.bfloat16 and a.is_cuda and
-                                      M >= 256 and K >= 128) else None
+    if isinstance(ws, str):         # "auto": the role's workspace wherever the K-split kernels (gemm_ntk.hip) could be chosen
+        ws = _workspace(a.device) if (not a_trans and a.dtype == torch.bfloat16 and a.is_cuda and K >= 512 and k_shares != 1) else None
     if ws is not None:
         args.ws, args.ws_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
+    args.ring, args.k_shares = ring, (k_shares or (_DBG_K_SHARES if not a_trans else 0))
+    if not a_trans:
+        sched |= _DBG_SCHED_OR
     args.A, args.B, args.C, args.C2 = _p(a), _p(b), _p(out), _p(out2)
     args.bias, args.pos, args.scale, args.keep_n = _p(bias), _p(pos), _p(scale), _p(keep_n)
     args.resid, args.dact_u, args.bias_grad, args.keep_k = _p(resid), _p(dact_u), _p(bias_grad), _p(keep_k)
     args.n_period, args.k_period, args.sched = n_period, k_period, sched
-    args.m_groups = M_GROUPS[0] if (_GROUP_INTERLEAVE and (keep_k is not None or keep_n is not None) and rows_in > 0) else 0
-    if WRITE_SKIP[0] and (keep_k is not None or keep_n is not None) and rows_in > 0 and (M_GROUPS[0] <= 1 or args.m_groups > 1):
+    mg = M_GROUPS[0] if m_groups is None else m_groups      # (closures launched later pass the value of their own forward / backward)
+    args.m_groups = mg if (_GROUP_INTERLEAVE and (keep_k is not None or keep_n is not None) and rows_in > 0) else 0
+    if WRITE_SKIP[0] and (keep_k is not None or keep_n is not None) and rows_in > 0 and (mg <= 1 or args.m_groups > 1):
         args.sched |= SKIP_WRITES_BIT
     args.M, args.N, args.K = M, N, K
     args.lda, args.ldb, args.ldc, args.ldu = lda, ldb, ldc, ldu
@@ -169,8 +173,8 @@ def _launch_gemm_ln(args, ln, a, M, N, K, rows_in, keep_k, keep_n, k_period, ext
     # algorithmic bytes from the KEPT widths, like _gemm_work: sample b reads rows x kept K of A; the weights once for the widest
     # sample; the row-wide side tensors (residual stream, LayerNorm output ...) in full
     if keep_k is not None and rows_in > 0:
-        kk = torch.clamp(keep_k.detach().to("cpu", torch.float64), max=k_period) * (K // k_period) if k_period else \
-            torch.clamp(keep_k.detach().to("cpu", torch.float64), max=K)
+        kk = torch.clamp(keep_k.detach().to("cpu", torch.float64), min=0, max=k_period) * (K // k_period) if k_period else \
+            torch.clamp(keep_k.detach().to("cpu", torch.float64), min=0, max=K)
         a_bytes, k_w = float((rows_in * kk).sum()) * 2, float(kk.max())
     else:
         a_bytes, k_w = float(M) * K * 2, float(K)
@@ -214,13 +218,15 @@ def gemm_ln_bwd(du, wt, x, ln_w, mean, rstd, ln_keep, dx_in, dw, db, next_cast=N
 
 def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out2=None, bias=None, pos=None,
          scale=None, keep_n=None, resid=None, dact_u=None, ldu=0, act=0, atomic=False, split_k=1, rows_in=0,
-         a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0, ws="auto"):
-    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T) -- see vr_gemm in include/vitres_hip.h.  ws: stream-K workspace (a uint8 tensor),
+         a_map=None, b_map=None, c_map=None, bias_grad=None, keep_k=None, n_period=0, k_period=0, sched=0, ws="auto",
+         ring=0, k_shares=0, m_groups=None):
+    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T) -- see vr_gemm in include/vitres_hip.h.  ws: K-split workspace (a uint8 tensor),
     None, or "auto" = the current role's (see _workspace)."""
     args = _gemm_args(a, b, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, a_trans=a_trans, b_trans=b_trans, out2=out2,
                       bias=bias, pos=pos, scale=scale, keep_n=keep_n, resid=resid, dact_u=dact_u, ldu=ldu, act=act,
                       atomic=atomic, split_k=split_k, rows_in=rows_in, a_map=a_map, b_map=b_map, c_map=c_map,
-                      bias_grad=bias_grad, keep_k=keep_k, n_period=n_period, k_period=k_period, sched=sched, ws=ws)
+                      bias_grad=bias_grad, keep_k=keep_k, n_period=n_period, k_period=k_period, sched=sched, ws=ws,
+                      ring=ring, k_shares=k_shares, m_groups=m_groups)
     if DBG_POISON[0] and (args.sched & SKIP_WRITES_BIT) and keep_n is not None and not a_trans and resid is None and \
             out.dtype == torch.bfloat16:
         out.fill_(float("nan"))
@@ -230,7 +236,8 @@ def gemm(a, b, out, *, M, N, K, lda, ldb, ldc, a_trans=False, b_trans=False, out
         _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
         return out
     flops, alg_bytes = _gemm_work(a, out, M, N, K, a_trans, rows_in, keep_k, keep_n, k_period, n_period, out2=out2, resid=resid,
-                                  dact_u=dact_u, pos=pos, bias=bias, atomic=atomic)
+                                  dact_u=dact_u, pos=pos, bias=bias, atomic=atomic,
+                                  skip_writes=bool(args.sched & SKIP_WRITES_BIT))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _lib.check(_lib.lib().vr_gemm(ctypes.byref(args), _stream()), "vr_gemm")
@@ -273,13 +280,38 @@ def gemm_group(calls):
         PROFILE_DESC.append("group " + " + ".join("M%d N%d K%d" % (kw["M"], kw["N"], kw["K"]) for _, _, _, kw in calls))
 
 
+def _written_cols(keep_n, N, n_period, BN=128):
+    """Per sample: the output columns a launch under SKIP_WRITES_BIT actually stores -- the BN-wide column tiles that hold a kept
+    column for the sample's architecture GROUP (gemm_ntk.hip: a tile beyond the group's width is not written; a DropPath-dropped
+    sample, marked -(k + 2), still gets its group's width k: its zeros below k are stored)."""
+    gw = keep_n.detach().to("cpu", torch.int64)
+    gw = torch.where(gw < 0, -gw - 2, gw)
+    out = torch.zeros(gw.shape, dtype=torch.float64)
+    for w in set(gw.tolist()):
+        cols = 0
+        for n0 in range(0, N, BN):
+            ln = min(BN, N - n0)
+            if w <= 0:
+                live = False
+            elif n_period <= 0:
+                live = n0 < w
+            else:
+                r = n0 % n_period
+                live = r < w or r + ln > n_period
+            cols += ln if live else 0
+        out[gw == w] = cols
+    return out
+
+
 def _gemm_work(a, out, M, N, K, a_trans, rows_in, keep_k, keep_n, k_period, n_period, out2=None, resid=None, dact_u=None,
-               pos=None, bias=None, atomic=False):
+               pos=None, bias=None, atomic=False, skip_writes=False):
     """(kept FLOPs, algorithmic HBM bytes) of one vr_gemm launch, both from the KEPT (un-masked) widths of the samples it
     touches -- skipped work is never counted, and neither are operand bytes the masks let the kernel skip.
-      forward / dgrad (C[M,N] = A[M,K] B[N,K]^T): sample b reads rows_in x kk[b] of A and writes rows_in x N of C (masked columns
-        are written as zeros: downstream kernels read whole rows); the weights are read once for the widest sample:
-        max(kk) x max(kn); epilogue side tensors (fp32 residual, GELU pre-activation, second output) are counted in full;
+      forward / dgrad (C[M,N] = A[M,K] B[N,K]^T): sample b reads rows_in x kk[b] of A; the weights are read once for the widest
+        sample: max(kk) x max(kn).  Outputs and epilogue side tensors (fp32 residual, saved gelu', second output): a launch that
+        stores zeros in masked columns (downstream kernels read whole rows) counts rows_in x N per sample; a launch under
+        SKIP_WRITES_BIT (skip_writes: bf16 result, no residual) counts only the 128-column tiles its architecture group keeps
+        (_written_cols) -- a fully masked tile is neither written nor is its saved gelu' read, a dropped layer counts nothing;
       wgrad (C[M,N] += A[T,M]^T B[T,N], a_trans): sample b reads rows_in x (kr[b] + kc[b]) channels; C (fp32) is read-modified-
         written once over its widest kept block."""
     esz, osz = a.element_size(), out.element_size()
@@ -288,7 +320,7 @@ def _gemm_work(a, out, M, N, K, a_trans, rows_in, keep_k, keep_n, k_period, n_pe
         if keep is None:
             return None
         k = keep.detach().to("cpu", torch.float64)
-        return torch.clamp(k, max=period) * (dim // period) if period else torch.clamp(k, max=dim)
+        return torch.clamp(k, min=0, max=period) * (dim // period) if period else torch.clamp(k, min=0, max=dim)
     if a_trans:                                   # wgrad: keep_k bounds output rows (M), keep_n output columns (N); K = tokens
         kr, kc = kept(keep_k, M, k_period), kept(keep_n, N, n_period)
         if kr is None and kc is None:
@@ -299,14 +331,18 @@ def _gemm_work(a, out, M, N, K, a_trans, rows_in, keep_k, keep_n, k_period, n_pe
         flops = float((2.0 * rows_in * kr * kc).sum())
         return flops, float((rows_in * (kr + kc)).sum() * esz + 2 * float(kr.max()) * float(kc.max()) * 4)
     kk, kn = kept(keep_k, K, k_period), kept(keep_n, N, n_period)
-    side = M * N * ((osz if out2 is not None else 0) + (4 if resid is not None else 0) + (esz if dact_u is not None else 0))
+    per_elem = osz + (osz if out2 is not None else 0) + (4 if resid is not None else 0) + (esz if dact_u is not None else 0)
     if kk is None and kn is None:
-        return 2.0 * M * N * K, float((M * K + N * K) * esz + M * N * osz + side)
+        return 2.0 * M * N * K, float((M * K + N * K) * esz + M * N * per_elem)
     nb = len(kk if kk is not None else kn)
     kk = kk if kk is not None else torch.full((nb,), float(K), dtype=torch.float64)
     kn = kn if kn is not None else torch.full((nb,), float(N), dtype=torch.float64)
     flops = float((2.0 * rows_in * kk * kn).sum())
-    return flops, float((rows_in * kk).sum() * esz + float(kk.max()) * float(kn.max()) * esz + M * N * osz + side)
+    if skip_writes and keep_n is not None and rows_in > 0 and resid is None and osz == 2:
+        out_bytes = float((rows_in * _written_cols(keep_n, N, n_period)).sum()) * per_elem
+    else:
+        out_bytes = float(M) * N * per_elem
+    return flops, float((rows_in * kk).sum() * esz + float(kk.max()) * float(kn.max()) * esz + out_bytes)
 
 
 def zero_ranges(buf, ranges):
@@ -416,7 +452,7 @@ def ln_grad_reduce(slots, copies):
 
 def _attn_profiled(call, keep_hd, B, N, H, D, passes):
     """bench.py's `roofline.blocks_mfma_util`: kept FLOPs (4 N^2 per kept head channel and pass pair) and HIP events of one launch."""
-    kept = float(keep_hd.sum().item()) if keep_hd is not None else float(B * H * D)
+    kept = float(keep_hd.clamp(min=0).sum().item()) if keep_hd is not None else float(B * H * D)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     call()

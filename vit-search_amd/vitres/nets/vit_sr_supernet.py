@@ -353,6 +353,10 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             for name, mod in self.named_modules():
                 fused = (name.endswith("attn.qkv") or name.endswith("mlp.fc1")) and isinstance(mod, nn.Linear) and \
                     mod.in_features <= Fn.FUSE_LN_MAXN
+                # round 6: proj / fc2 of the narrow first stage too -- their data gradients (K = the block's width <= 320) run on
+                # the panel-resident kernel (gemm_panel.hip), which reads the weight K-contiguous straight into MFMA operands
+                fused = fused or ((name.endswith("attn.proj") or name.endswith("mlp.fc2")) and isinstance(mod, nn.Linear) and
+                                  mod.out_features <= 320 and which != "fused_only")
                 if which != "all" and not fused:
                     continue
                 if isinstance(mod, nn.Linear) and id(mod.weight) in a["index"]:
@@ -537,7 +541,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             # One architecture per kernel tile (the G contiguous groups above, or one architecture for the whole batch) and a network
             # whose masked Linears all run on the group-pure bf16 kernels: the zeros of fully masked activation tiles -- hidden units /
             # heads beyond an architecture's width, whole dropped layers -- are then never read and need not be written
-            plan.skip_writes = bool(_SKIP_WRITES and (plan.groups > 1 or G == 1) and self._masked_writes_skippable())
+            plan.skip_writes = bool(_SKIP_WRITES and (plan.groups > 1 or G == 1) and self._masked_writes_skippable(B))
 
         def expand(gs, who):             # [len(gs), B]: entry b of a group vector g is g[b % len(g)]
             if not gs:
@@ -553,19 +557,24 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         self.last_keeps = list(torch.from_numpy(log)) if groups else []
         return plan
 
-    def _masked_writes_skippable(self):
-        """Static half of _Plan.skip_writes: bf16 kernels, every transformer block's widths multiples of the 64-wide K slice (the
-        forms gemm_ntk.hip / gemm_nt_ln.hip / gemm_tn.hip cover), atomic weight gradients (the store form runs one workgroup over all
-        architecture groups)."""
-        ok = getattr(self, "_skippable_dims", None)
-        if ok is None:
-            ok = True
+    def _masked_writes_skippable(self, B):
+        """The part of _Plan.skip_writes that does not depend on the draw: bf16 kernels; every transformer block's widths multiples of
+        the 64-wide K slice and at most 4096 (64 slices), every activation a reader walks below 4 GB (32-bit byte offsets) -- the forms
+        gemm_ntk.hip covers: a reader of skipped tiles (sched 0x80000) that gemm_ntk.hip declines is refused by every other kernel
+        (VR_EUNSUPPORTED), so such a network keeps writing its zeros; atomic weight gradients (the store form runs one workgroup over
+        all architecture groups)."""
+        dims_ok = getattr(self, "_skippable_dims", None)
+        if dims_ok is None:
+            ok, widest = True, 0
             for blk in self.blocks:
                 if isinstance(blk, Block):
                     dims = (blk.attn.qkv.in_features, blk.attn.num_heads * blk.attn.head_dim, blk.mlp.fc1.out_features)
-                    ok = ok and all(d % 64 == 0 for d in dims)
-            self._skippable_dims = ok
-        return ok and self.compute_dtype == torch.bfloat16 and not Fn.WGRAD_STORE
+                    ok = ok and all(d % 64 == 0 and d <= 4096 for d in dims)
+                    widest = max(widest, 3 * dims[1], dims[2])
+            dims_ok = self._skippable_dims = (ok, widest)
+        ok, widest = dims_ok
+        tokens = self.pos_embed.shape[1]                                   # (the first stage's: later stages have fewer)
+        return ok and B * tokens * widest * 2 < 0xfff00000 and self.compute_dtype == torch.bfloat16 and not Fn.WGRAD_STORE
 
     def _dp_scales_host(self, plan):
         """DropPath scales floor(keep_prob + u) / keep_prob (nets/drop.py:21-26) of one forward, [n_dp, B] float32 on the host in
