@@ -1075,10 +1075,15 @@ def test_softce_train(dtype, R, rps, K_, mapped):
     assert relerr(real[:, :K_], x.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
 
 
-@pytest.mark.parametrize("T,C,F,HD", [(257 * 8, 64, 192, 64), (65 * 16, 128, 384, 96), (17 * 6, 256, 768, 192)])
-def test_gemm_group_equals_the_launches_one_by_one(T, C, F, HD):
+@pytest.mark.parametrize("T,C,F,HD", [(257 * 8, 64, 192, 64), (65 * 16, 128, 384, 96), (17 * 6, 256, 768, 192), (257 * 16, 256, 768, 256),
+                                      (65 * 32, 512, 1536, 512)])
+@pytest.mark.parametrize("sched", [0, 64, 0x10000])
+def test_gemm_group_equals_the_launches_one_by_one(T, C, F, HD, sched):
     """vr_gemm_group: the four weight gradients of a transformer block as one launch (masked tiles, bias gradients, per-head
-    periods included) against the same calls issued through vr_gemm -- and against the torch statement."""
+    periods included) against the same calls issued through vr_gemm -- and against the torch statement.  sched 0: the 4-wave
+    kernel with the lean instruction stream of round 6 (tn8_group_kernel<4>: LDS-DMA through a buffer descriptor, tokens past a
+    split's end and masked channel chunks through its range check); 64: tn_body's stream; 0x10000: the 8-wave, double-buffered
+    form (one workgroup per CU, one token split for the whole group)."""
     import functools
     dt = torch.bfloat16
     rps = T // 8 if T % 8 == 0 else T // 2
@@ -1100,7 +1105,7 @@ def test_gemm_group_equals_the_launches_one_by_one(T, C, F, HD):
                 dy[s_ * rps:(s_ + 1) * rps, lim:] = 0
             x[s_ * rps:(s_ + 1) * rps, int(kc[s_]):] = 0
         kw = dict(M=out_f, N=in_f, K=T, lda=out_f, ldb=in_f, ldc=in_f, a_trans=True, b_trans=True, atomic=True, split_k=0,
-                  k_period=period, rows_in=rps)
+                  k_period=period, rows_in=rps, sched=sched)
         dw_ref, db_ref = torch.zeros(out_f, in_f), torch.zeros(out_f)
         calls_cpu.append((dy, x, dw_ref, dict(kw, keep_k=kr, keep_n=kc, bias_grad=db_ref)))
         dw_g, db_g = torch.zeros(out_f, in_f, device=DEV), torch.zeros(out_f, device=DEV)
@@ -1114,7 +1119,7 @@ def test_gemm_group_equals_the_launches_one_by_one(T, C, F, HD):
         K.gemm(a, b, dw_1, **kw1)
     torch.cuda.synchronize()
     for (dw_g, db_g), (dw_1, db_1, _), (_, _, dw_ref, kwr) in zip(outs_gpu, outs_one, calls_cpu):
-        assert relerr(dw_g, dw_1) < 1e-5 and relerr(db_g, db_1) < 1e-5          # same kernel body, same split rule apart
+        assert relerr(dw_g, dw_1) < 2e-5 and relerr(db_g, db_1) < 2e-5          # same products, another split / summation order
         assert relerr(dw_g, dw_ref) < 1e-4 and relerr(db_g, kwr["bias_grad"]) < 2e-4      # fp32 results of bf16 operands
 
 

@@ -467,31 +467,23 @@ bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     if (auto_tile == 3 && t64 >= n_cu) auto_tile = 2;
     if (auto_tile == 1 && a.dact_u && a.b_trans) auto_tile = 2;                       // fc2 data gradient (times the saved gelu')
     if (auto_tile == 1 && gelu && a.C2 && t128 < 4LL * n_cu) auto_tile = 2;           // fc1 forward (training: two outputs) of the second stage
-    // K-split (SPLIT kernels).  k_shares: 0 = the rule below, 1 = never, 2 - 4 = that many shares wherever the form has a split
-    // kernel and the workspace holds the slabs.  The rule (tools/ksplit_sweep.py on the stage 2 / 3 shapes, profiles/r06_ksplit_sweep.txt):
-    // what paces a lone workgroup per CU is not the memory latency (rings of 4 - 6 slices: +-0) but its own serial chain of LDS-DMA
-    // issue, LDS reads and MFMAs per slice -- a second / third workgroup on the CU overlaps it.  Four shares pay where they turn a
-    // grid of 1 - 2 workgroups per CU with <= 24 slices into 4 - 8 short-lived ones; with 36 - 48 slices per tile (K = 2304 / 3072)
-    // every split form measured loses to the unsplit 64 x 128 ring (slab round trip + a tail round), as do grids that already give a
-    // CU three workgroups.
+    // K-split (SPLIT kernels): vr_gemm_args.k_shares = 2 - 4 shares wherever the form has a split kernel and the workspace holds the
+    // slabs; 0 / 1: never.  No rule turns it on: measured on every stage 2 / 3 shape of the step (tools/ksplit_sweep.py,
+    // profiles/r06_ksplit_sweep.txt) every real split loses to the unsplit kernel -- what paces a lone workgroup per CU is not memory
+    // latency (rings of 4 - 6 slices: +-0) but its own serial chain of LDS-DMA issue, LDS reads and MFMAs per slice, which a second
+    // workgroup on the CU overlaps as well as a share does, without the slab round trip (tiles x shares x 32 - 64 KB written through and
+    // read back: 1 - 3x the GEMM's own bytes at these sizes) and without the extra tail round.
     const bool split_form = feat != 2 && a.ws;
     const int ntiles = a.K / BK;
-    int shares = 1, rule_tile = 0, rule_ring = 0;
-    if (split_form && a.k_shares == 0 && !s_tile && a.ring == 0) {
-        if (of32 && feat == 3 && ntiles >= 8 && ntiles <= 24 && t64 >= 3LL * n_cu / 2 && t64 <= 3LL * n_cu) {
-            shares = 4; rule_tile = 2; rule_ring = 2;            // proj / fc2 forward of the second stage (fp32 residual stream)
-        } else if (!of32 && ntiles >= 8 && ntiles <= 16 && t128 >= n_cu && t128 < 2LL * n_cu) {
-            shares = 4; rule_tile = a.C2 || a.dact_u ? 1 : 2; rule_ring = 2;   // qkv / fc1 forward, fc2 data gradient of the last stage
-        }
-    } else if (split_form && a.k_shares > 1) {
-        shares = std::min(std::min(a.k_shares, 4), std::max(1, ntiles / 2));
-    }
+    int shares = 1;
+    constexpr int rule_tile = 0, rule_ring = 0;
+    if (split_form && a.k_shares > 1) shares = std::min(std::min(a.k_shares, 4), std::max(1, ntiles / 2));
     const int tile = s_tile ? s_tile : (rule_tile ? rule_tile : auto_tile);
     const long long wgs = (long long)group_tiles(a.M, tile == 1 ? 128 : 64, a.m_groups) * ((a.N + (tile == 3 ? 63 : 127)) / (tile == 3 ? 64 : 128));
     const int stage_kb = tile == 1 ? 32 : (tile == 2 ? 24 : 16);
     if (shares > 1) {
         const long long slab = (tile == 1 ? 128LL * 128 : (tile == 2 ? 64LL * 128 : 64LL * 64)) * 4;
-        if (wgs > SPLIT_MAX_TILES || (long long)SPLIT_TICKET_BYTES + wgs * shares * slab > a.ws_bytes) { shares = 1; rule_ring = 0; }
+        if (wgs > SPLIT_MAX_TILES || (long long)SPLIT_TICKET_BYTES + wgs * shares * slab > a.ws_bytes) shares = 1;
     }
     // slices in flight: as many as LDS allows WITHOUT lowering the number of workgroups the grid gives a CU (a 96 KB ring that leaves
     // a CU one workgroup where three single-buffer ones would run loses: candidate scoring, M4352 N2304 K1280 36 -> 44 us)

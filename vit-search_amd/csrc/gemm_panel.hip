@@ -25,7 +25,8 @@
 // Covered (vr_gemm_panel_launch returns false otherwise): bf16 operands and result, K-contiguous weight (data gradients read the
 // transposed bf16 shadow), K % 32 == 0 <= 320, k_period == 0, no residual / scale / pos / row maps, FAST epilogue alignment.
 // PROBE (sched 0x400000, measurement only): the same kernel without weight loads, LDS reads and MFMAs -- what the access pattern
-// (A once, kept C strips once) costs by itself (tools/panel_bench.py).
+// (A once, kept C strips once) costs by itself; 0x1000000 / 0x2000000: without the weight loads / without LDS reads and MFMAs
+// (tools/panel_bench.py).
 #include <algorithm>
 
 #include "gemm_nt_parts.h"
@@ -36,7 +37,8 @@ namespace vr_gemm_nt {
 using vr_dma::dma16;
 using vr_dma::make_rsrc;
 
-template <typename TO, int EPI, int MI, int NW, int KSTEPS, int FEAT, bool PROBE>
+// PROBE: 0 = the kernel; 1 = bytes only (no weight loads, LDS reads, MFMAs); 2 = without the weight loads; 3 = without LDS reads / MFMAs
+template <typename TO, int EPI, int MI, int NW, int KSTEPS, int FEAT, int PROBE>
 __global__ __launch_bounds__(NW * 64, MI >= 8 ? 1 : 2) void panel_kernel(const vr_gemm_args p) {
     constexpr int NJ = 2, BM = 16 * MI, NTHR = NW * 64;
     constexpr int KSL = (KSTEPS + 1) / 2;                         // 64-wide K slices of the panel image
@@ -105,9 +107,6 @@ __global__ __launch_bounds__(NW * 64, MI >= 8 ? 1 : 2) void panel_kernel(const v
         }
         rowmeta[r] = rm;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     // ---- this wave's strips: w, w + NW, ... (at most 16 of them: N <= 32 x 16 x NW) ----
     const int nstrips = (p.N + 31) / 32;
     const bool skip_ok = SKIP_FORM && (p.sched & 0x40000) && p.keep_n && (p.m_groups <= 1 || group_pure(p.M, p.m_groups)) &&
@@ -138,7 +137,8 @@ __global__ __launch_bounds__(NW * 64, MI >= 8 ? 1 : 2) void panel_kernel(const v
     // conservative s_waitcnt vmcnt(0 / 1) in front of a strip's first MFMA -- i.e. wait for the previous strip's STORES.  Instead
     // ONE s_waitcnt vmcnt(0) sits in front of a strip's first store (epilogue WAITV): the next strip's operands have been requested
     // one strip of MFMAs earlier, the previous strip's stores two; the stores issued behind it are waited for by nobody until the
-    // next strip's epilogue.
+    // next strip's epilogue.  k-steps are requested in PAIRS (2 s, 2 s + 1: the two 64-byte halves of the same 128-byte lines of
+    // W[n][.]) -- a half requested 18 MFMAs after the other found its line evicted from the 32 KB L1 by the seven other waves.
     bfv8 bw[KSTEPS][NJ];
     const bf16_t* bptr[NJ];
     auto point = [&](int i) {                                     // operand rows of the wave's i-th strip
@@ -155,15 +155,17 @@ __global__ __launch_bounds__(NW * 64, MI >= 8 ? 1 : 2) void panel_kernel(const v
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bw[ks][j]) : "v"(bptr[j] + ks * 32) : "memory");
     };
     int ci = wr ? __builtin_ctz(wr) : 32;                         // index of the strip being worked on
-    if constexpr (!PROBE) {
-        if (ci < 32 && ((ml >> ci) & 1u)) {
+    if constexpr (PROBE == 0 || PROBE == 3) {
+        if (ci < 32 && ((ml >> ci) & 1u)) {                       // the first strip's operands travel with the panel
             point(ci);
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks)
                 if (ks < nks) load_step(ks);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
     while (ci < 32) {
         const unsigned rest = wr & ~((2u << ci) - 1u);
         const int ni = rest ? __builtin_ctz(rest) : 32;
@@ -175,20 +177,32 @@ __global__ __launch_bounds__(NW * 64, MI >= 8 ? 1 : 2) void panel_kernel(const v
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (!PROBE) {
+        if constexpr (PROBE != 1) {
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 if (ks < nks) {
-                    if (mul) {
-                        const char* Ab = As + (ks >> 1) * A_SLICE + ((ks & 1) ? slot_o : slot_e);
+                    if constexpr (PROBE != 3) {
+                        if (mul) {
+                            const char* Ab = As + (ks >> 1) * A_SLICE + ((ks & 1) ? slot_o : slot_e);
 #pragma unroll
-                        for (int i = 0; i < MI; ++i) {
-                            const bfv8 a = *reinterpret_cast<const bfv8*>(Ab + i * 2048);
+                            for (int i = 0; i < MI; ++i) {
+                                const bfv8 a = *reinterpret_cast<const bfv8*>(Ab + i * 2048);
 #pragma unroll
-                            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ks][j], a, acc[i][j], 0, 0, 0);
+                                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[ks][j], a, acc[i][j], 0, 0, 0);
+                            }
                         }
                     }
-                    if (pre) load_step(ks);                      // the registers just read take the next strip's k-step
+                    if constexpr (PROBE == 3) {                  // (keeps the operand registers allocated until here, like the MFMAs do)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bw[ks][j]));
+                    }
+                    if constexpr (PROBE != 2) {
+                        // the registers just read take the next strip's k-steps: both halves of a line in one go
+                        if (pre && ((ks & 1) || ks + 1 >= nks)) {
+                            if (ks & 1) load_step(ks - 1);
+                            load_step(ks);
+                        }
+                    }
                 }
             }
         }
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(NW * 64, MI >= 8 ? 1 : 2) void panel_kernel(const v
 }
 
 template <typename TO, int EPI, int FEAT> bool plaunch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
-    const bool probe = (a.sched & 0x400000) != 0;
+    const int probe = (a.sched & 0x400000) ? 1 : ((a.sched & 0x1000000) ? 2 : ((a.sched & 0x2000000) ? 3 : 0));   // measurement forms
     // panel height: 144 rows x 8 waves (one workgroup per CU) when that fills >= 3/4 of the chip in one round, else 80 rows x 4
     // waves (two per CU) when those fit in one round; otherwise the tiled kernels are at least as good
     const int p144 = group_tiles(a.M, 144, a.m_groups), p80 = group_tiles(a.M, 80, a.m_groups);
@@ -209,21 +223,31 @@ template <typename TO, int EPI, int FEAT> bool plaunch(const vr_gemm_args& a, hi
     if (a.sched & 0x200000) form = (k8 && !(a.sched & 0x800000)) ? 9 : 5;              // forced (tests): 0x800000 picks the 80-row form
     if (!form) return false;
     if (form == 9) {
-        if (probe) hipLaunchKernelGGL((panel_kernel<TO, EPI, 9, 8, 8, FEAT, true>), dim3(p144), dim3(512), 0, stream, a);
-        else hipLaunchKernelGGL((panel_kernel<TO, EPI, 9, 8, 8, FEAT, false>), dim3(p144), dim3(512), 0, stream, a);
+        switch (probe) {
+            case 1: hipLaunchKernelGGL((panel_kernel<TO, EPI, 9, 8, 8, FEAT, 1>), dim3(p144), dim3(512), 0, stream, a); break;
+            case 2: hipLaunchKernelGGL((panel_kernel<TO, EPI, 9, 8, 8, FEAT, 2>), dim3(p144), dim3(512), 0, stream, a); break;
+            case 3: hipLaunchKernelGGL((panel_kernel<TO, EPI, 9, 8, 8, FEAT, 3>), dim3(p144), dim3(512), 0, stream, a); break;
+            default: hipLaunchKernelGGL((panel_kernel<TO, EPI, 9, 8, 8, FEAT, 0>), dim3(p144), dim3(512), 0, stream, a);
+        }
     } else {
-        if (probe) hipLaunchKernelGGL((panel_kernel<TO, EPI, 5, 4, 10, FEAT, true>), dim3(p80), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((panel_kernel<TO, EPI, 5, 4, 10, FEAT, false>), dim3(p80), dim3(256), 0, stream, a);
+        switch (probe) {
+            case 1: hipLaunchKernelGGL((panel_kernel<TO, EPI, 5, 4, 10, FEAT, 1>), dim3(p80), dim3(256), 0, stream, a); break;
+            default: hipLaunchKernelGGL((panel_kernel<TO, EPI, 5, 4, 10, FEAT, 0>), dim3(p80), dim3(256), 0, stream, a);
+        }
     }
     return true;
 }
 
 }  // namespace vr_gemm_nt
 
-// Called by vr_gemm_ntk_launch in front of the tiled kernels.  sched 0x100000: never; 0x200000: wherever the form is covered.
+// Called by vr_gemm_ntk_launch in front of the tiled kernels.  OPT-IN (sched 0x200000: wherever the form is covered): measured round 6
+// (profiles/r06_panel_resident.txt) the access pattern alone -- A once, C once -- streams at 4.5 - 5.6 TB/s, but the kernel reaches
+// 2.4 - 3.6 TB/s against the tiled kernels' 3.0 - 4.5 alone and costs the sr_tiny step +0.25 ms: the weight strips (384 KB per panel
+// from L2 as 16-row x 64-byte pieces) arrive at ~40 GB/s per CU and add to, instead of hiding behind, the MFMA phase of the one
+// workgroup a CU holds.
 bool vr_gemm_panel_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_nt;
-    if (a.sched & 0x100000) return false;
+    if (!(a.sched & 0x200000)) return false;
     if (a.in_dtype != VR_BF16 || a.out_dtype != VR_BF16 || a.a_trans || a.b_trans || a.atomic || a.split_k > 1 || a.bias_grad || a.pos ||
         a.resid || a.scale)
         return false;
@@ -232,7 +256,6 @@ bool vr_gemm_panel_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);
     if (!fast || a.lda % 8 || a.ldb % 8 || ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return false;
     if ((long long)a.M * a.lda * 2 >= 0xfff00000LL) return false;
-    if (!(a.sched & 0x200000) && (a.N < 256 || a.M < 8192)) return false;
     // an operand with unwritten masked tiles is readable only when no panel mixes two architecture groups
     if ((a.sched & 0x80000) && a.keep_k && a.m_groups > 1 && !group_pure(a.M, a.m_groups)) return false;
     const bool gelu = a.act == 1 || (a.act == 2 && !a.dact_u);

@@ -313,6 +313,197 @@ __global__ __launch_bounds__(NTHR, 4) void tn_group_kernel(const TnGroup g) {
     }
 }
 
+// ---- round 6: the group launch's kernel for the atomic form ---------------------------------------------------------------
+// tn_body above is one 4-wave workgroup per item, single slice buffer (issue, wait, multiply: nothing overlaps inside it), two of
+// them resident per CU -- and every item pays |tile| x 4 B of fp32 atomics whatever its share of the tokens: 16 token splits x
+// 2.6 MB x 2 (read-modify-write) per stage-1 group at ~1.1 TB/s of payload, 40 of 107 us (profiles/r05_wgrad_atomics.txt), 2.16x the
+// algorithmic bytes in measured traffic.  tn8_body is ONE 8-wave workgroup per CU on the same 64 KB of LDS: 128 x 128 tile, waves
+// 2 (rows) x 4 (columns) of 64 x 32, the slices double-buffered INSIDE the workgroup (LDS-DMA through a buffer descriptor: one
+// 32-bit offset per piece, tokens past the split's end and masked channel chunks read as zeros through its range check; counted
+// vmcnt, one barrier per slice) -- the second wave per SIMD overlaps what the second workgroup used to.  An item then covers twice
+// the tokens at the same residency: half the token splits, half the atomic payload.
+constexpr int NTHR8 = 512;
+typedef int v4i_tn __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i_tn tn_rsrc(const void* ptr, unsigned num_records) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)ptr;
+    v4i_tn r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)num_records);
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void tn_dma16(unsigned lds, unsigned voff, v4i_tn rsrc) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+
+// NW = 8: as above.  NW = 4: the 4-wave workgroup (waves 2 x 2 of 64 x 64, one slice buffer, two resident per CU) with the same lean
+// instruction stream -- what tn_body does in ~8 x (64-bit address + two selects) per piece and slice is one v_add here.
+template <int NW>
+__device__ __forceinline__ void tn8_body(const vr_gemm_args& p, const int bid, char* smem) {
+    typedef Geo<128> G;
+    constexpr int TW = 128, ROWB = G::ROWB, SLOTS = G::SLOTS, TPP = G::TPP, TILE_BYTES = G::TILE_BYTES;
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES, FM = 4, FN = NW == 8 ? 2 : 4, PPW8 = G::PIECES / NW;       // 16 pieces per operand slice
+    constexpr int WCOLS = FN * 16, WNB = NW == 8 ? 2 : 1;                                     // columns per wave, log2(waves along N)
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> WNB, wn = wave & ((1 << WNB) - 1);
+    const int tiles_n = (p.N + TW - 1) / TW, tiles_m = (p.M + TW - 1) / TW;
+    const int total = tiles_n * tiles_m * p.split_k;
+    int tile = bid;
+    if (tile >= total) return;
+    if (total >= 16) {
+        const int xq = total >> 3, xr = total & 7, x = tile & 7;
+        tile = x * xq + min(x, xr) + (tile >> 3);
+    }
+    const int tn = tile % tiles_n, rest = tile / tiles_n;
+    const int tm = rest % tiles_m, zq = rest / tiles_m;
+    const int m0 = tm * TW, n0 = tn * TW;
+    int kbeg, kend;
+    if (group_pure(p.K, p.m_groups) && p.split_k % p.m_groups == 0) {
+        const int Gr = p.m_groups, kg = p.K / Gr, spg = p.split_k / Gr, g = zq % Gr, zi = zq / Gr;
+        const int kper = ((kg + spg - 1) / spg + BT - 1) / BT * BT;
+        kbeg = g * kg + zi * kper;
+        kend = min(g * kg + kg, kbeg + kper);
+    } else {
+        const int z = interleave_groups(zq, p.split_k, p.m_groups);
+        const int kper = ((p.K + p.split_k - 1) / p.split_k + BT - 1) / BT * BT;
+        kbeg = z * kper;
+        kend = min(p.K, kbeg + kper);
+    }
+    int ntiles = kbeg < kend ? (kend - kbeg + BT - 1) / BT : 0;
+    int kmax = 1 << 30, nmax = 1 << 30;
+    if ((p.keep_k || p.keep_n) && ntiles > 0) {
+        int s_lo = 0, s_hi = 0;
+        if (p.rows_in > 0) { s_lo = kbeg / p.rows_in; s_hi = (kend - 1) / p.rows_in; }
+        kmax = max_keep(p.keep_k, s_lo, s_hi, 1 << 30);
+        nmax = max_keep(p.keep_n, s_lo, s_hi, 1 << 30);
+        if (!range_has_kept(n0, TW, p.n_period, nmax) || !range_has_kept(m0, TW, p.k_period, kmax)) ntiles = 0;
+    }
+    if (ntiles == 0) return;
+    const bool skipm = !p.keep_k || (p.k_period > 0 && (p.k_period & 7)), skipn = !p.keep_n || (p.n_period > 0 && (p.n_period & 7));
+
+    // ---- LDS-DMA: piece h of this wave = slice tokens (2 wave + h) * 4 .. + 4; lane -> (token, 16-byte slot).  Offsets are relative
+    //      to the split's first token row; the descriptors end with its last one (rows beyond read as zeros), a chunk beyond the
+    //      row's width or the kept prefix of this token range gets an offset no slice brings back into range ----
+    const v4i_tn rsA = tn_rsrc(reinterpret_cast<const bf16_t*>(p.A) + (long long)kbeg * p.lda, (unsigned)((long long)(kend - kbeg) * p.lda * 2));
+    const v4i_tn rsB = tn_rsrc(reinterpret_cast<const bf16_t*>(p.B) + (long long)kbeg * p.ldb, (unsigned)((long long)(kend - kbeg) * p.ldb * 2));
+    unsigned voA[PPW8], voB[PPW8];
+#pragma unroll
+    for (int h = 0; h < PPW8; ++h) {
+        const int tk = (wave * PPW8 + h) * TPP + lane / SLOTS;
+        const int c = (lane % SLOTS) ^ G::swz(tk);
+        const bool ak = skipm || kept_col(m0 + c * 8, p.k_period, kmax), bk = skipn || kept_col(n0 + c * 8, p.n_period, nmax);
+        const bool aok = m0 + c * 8 + 8 <= p.lda && ak, bok = n0 + c * 8 + 8 <= p.ldb && bk;
+        voA[h] = aok ? (unsigned)((tk * p.lda + m0 + c * 8) * 2) : 0x80000000u;
+        voB[h] = bok ? (unsigned)((tk * p.ldb + n0 + c * 8) * 2) : 0x80000000u;
+    }
+    const unsigned stepA = (unsigned)(BT * p.lda * 2), stepB = (unsigned)(BT * p.ldb * 2);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int li = lane & 15, g = lane >> 4;
+    const int xr2 = G::swz(8 * g + (li >> 2));
+    const int rowoff = (8 * g + (li >> 2)) * ROWB + (li & 1) * 8;
+    int offA[FM], offB[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) offA[i] = rowoff + ((8 * wm + 2 * i + ((li & 3) >> 1)) ^ xr2) * 16;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) offB[j] = TILE_BYTES + rowoff + (((WCOLS / 8) * wn + 2 * j + ((li & 3) >> 1)) ^ xr2) * 16;
+
+    f32x4 acc[FM][FN];
+    f32x4 accb[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool want_bg = p.bias_grad != nullptr && tn == 0 && wn == 0;
+    const s8 ones_bits = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
+    const bfv8 ones = __builtin_bit_cast(bfv8, ones_bits);
+
+    auto issue = [&](int kt, int buf) {
+        const unsigned dst = lds0 + buf * STAGE_BYTES + wave * (PPW8 * 1024);
+#pragma unroll
+        for (int h = 0; h < PPW8; ++h) {
+            tn_dma16(dst + h * 1024, voA[h] + kt * stepA, rsA);
+            tn_dma16(dst + TILE_BYTES + h * 1024, voB[h] + kt * stepB, rsB);
+        }
+    };
+    auto compute = [&](int buf) {
+        const char* sb_ = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bfv8 a[FM];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = tr_frag<ROWB>(sb_ + offA[i] + s * 32 * ROWB);
+            if (want_bg) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const bfv8 b = tr_frag<ROWB>(sb_ + offB[j] + s * 32 * ROWB);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    __syncthreads();                     // (the previous item's last slice has been read by every wave)
+    if constexpr (NW == 8) {
+        issue(0, 0);
+        for (int kt = 0; kt < ntiles; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // slice kt (the only one in flight) has landed
+            __builtin_amdgcn_s_barrier();                             // ... for every wave; the other buffer has been read
+            if (kt + 1 < ntiles) issue(kt + 1, (kt + 1) & 1);
+            compute(kt & 1);
+        }
+    } else {
+        for (int kt = 0; kt < ntiles; ++kt) {
+            issue(kt, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
+    }
+
+    float* C = reinterpret_cast<float*>(p.C);
+    bool ncol[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * WCOLS + 16 * j + li;
+        ncol[j] = n < p.N && kept_col(n, p.n_period, nmax);
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 64 + 16 * i + 4 * g + r;
+            if (m >= p.M) continue;
+            if (!kept_col(m, p.k_period, kmax)) continue;
+            float* crow = C + (long long)m * p.ldc;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WCOLS + 16 * j + li;
+                if (ncol[j]) atomicAdd(crow + n, acc[i][j][r]);
+            }
+            if (want_bg && li == 0) atomicAdd(p.bias_grad + m, accb[i][r]);
+        }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 4) void tn8_group_kernel(const TnGroup g) {
+    __shared__ __attribute__((aligned(1024))) char smem[(NW == 8 ? 2 : 1) * 2 * Geo<128>::TILE_BYTES];
+    for (int bid = (int)blockIdx.x; bid < g.first[MAXG]; bid += (int)gridDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int i = 1; i < MAXG; ++i)
+            if (i < g.count && bid >= g.first[i]) k = i;
+        tn8_body<NW>(g.a[k], bid - g.first[k], smem);
+    }
+}
+
 template <int TW, int STAGES> void launch_tw(const vr_gemm_args& a, hipStream_t stream, long long total) {
     const bool mapped = a.a_map.rpi != 0 || a.b_map.rpi != 0;
     if (mapped) {
@@ -355,52 +546,76 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
         if (!tn_covers(a) || a.a_map.rpi != 0 || a.b_map.rpi != 0 || a.split_k > 0) return false;
         if (needs_pure(a) && (a.atomic == 2 || !vr_gemm_shared::group_pure(a.K, a.m_groups))) return false;
     }
-    static const int knob_s = std::getenv("VITRES_TN_S") ? std::atoi(std::getenv("VITRES_TN_S")) : 32;
-    static const int knob_fill = std::getenv("VITRES_TN_GROUP_FILL") ? std::atoi(std::getenv("VITRES_TN_GROUP_FILL")) : 2;
-    // one slice count per workgroup for the whole group: ~knob_fill workgroups per CU in total (2 measured best inside the
-    // step: 8.52 ms against 8.61 at 4 and 8.76 at 6 -- fewer workgroups, fewer fp32 atomics), never finer than 8 slices
-    // (each workgroup pays |tile| x 4 B of atomics) nor coarser than the single-launch rule (VITRES_TN_S)
-    // store-form members (atomic == 2) run one workgroup per tile over all tokens: no token split to fill the chip with, so a group
-    // of them uses 64 x 64 tiles (VITRES_TN_STORE_TW) -- four times the workgroups at the same output traffic
-    bool all_store = true;
-    for (int i = 0; i < count; ++i) all_store = all_store && args[i].atomic == 2;
-    static const int knob_stw = std::getenv("VITRES_TN_STORE_TW") ? std::atoi(std::getenv("VITRES_TN_STORE_TW")) : 64;
-    static const int knob_gtw = std::getenv("VITRES_TN_GROUP_TW") ? std::atoi(std::getenv("VITRES_TN_GROUP_TW")) : 128;
-    static const int knob_gst = std::getenv("VITRES_TN_GROUP_STAGES") ? std::atoi(std::getenv("VITRES_TN_GROUP_STAGES")) : 1;
-    const int TWv = ((all_store && knob_stw == 64) || knob_gtw == 64) ? 64 : 128;
-    long long work = 0;
-    for (int i = 0; i < count; ++i)
-        work += (long long)((args[i].M + TWv - 1) / TWv) * ((args[i].N + TWv - 1) / TWv) * ((args[i].K + BT - 1) / BT);
-    long long spw = work / ((long long)knob_fill * n_cu);
-    spw = spw < 8 ? 8 : (spw > knob_s ? knob_s : spw);
+    bool all_store = true, any_store = false;
+    for (int i = 0; i < count; ++i) {
+        all_store = all_store && args[i].atomic == 2;
+        any_store = any_store || args[i].atomic == 2;
+    }
     TnGroup g;
     g.count = count;
     int next = 0;
+    const long long slices = (args[0].K + BT - 1) / BT;
+    bool same_k = true;
+    for (int i = 1; i < count; ++i) same_k = same_k && args[i].K == args[0].K && args[i].m_groups == args[0].m_groups;
+    if (!any_store && same_k && (args[0].sched & 0x10000)) {
+        // ---- atomic form, OPT-IN (sched 0x10000 on the first problem): tn8_group_kernel<8>, one 8-wave workgroup per CU ----
+        // One token split for the whole group.  Cost of s splits in slice-times of one workgroup: rounds of the chip x (slices of an
+        // item + its epilogue: 64 KB of fp32 atomics per item, ~40 slice-times while every CU adds at once -- ~1.1 TB/s of payload
+        // chip-wide, profiles/r05_wgrad_atomics.txt); a multi-architecture batch splits by whole groups.
+        long long tiles = 0;
+        for (int i = 0; i < count; ++i) tiles += (long long)((args[i].M + 127) / 128) * ((args[i].N + 127) / 128);
+        const int G = vr_gemm_shared::group_pure(args[0].K, args[0].m_groups) ? args[0].m_groups : 1;
+        bool pure = false;
+        for (int i = 0; i < count; ++i) pure = pure || needs_pure(args[i]);
+        long long best = -1, best_s = 1;
+        for (long long sq = (pure ? G : 1); sq <= 64; sq += (G > 1 ? (sq < G ? G - sq : G) : 1)) {
+            const long long per = (slices + sq - 1) / sq;
+            if (per < 4 && sq > (pure ? G : 1)) break;
+            const long long rounds = (tiles * sq + n_cu - 1) / n_cu;
+            const long long cost = rounds * (per + 40);
+            if (best < 0 || cost < best) { best = cost; best_s = sq; }
+        }
+        for (int i = 0; i < count; ++i) {
+            g.a[i] = args[i];
+            const long long t_i = (long long)((args[i].M + 127) / 128) * ((args[i].N + 127) / 128);
+            g.a[i].split_k = (int)best_s;
+            g.first[i] = next;
+            next += (int)((t_i * best_s + 7) / 8 * 8);
+        }
+        for (int i = count; i <= MAXG; ++i) g.first[i] = next;
+        const int lim = (n_cu + 7) / 8 * 8;
+        hipLaunchKernelGGL(tn8_group_kernel<8>, dim3((unsigned)(next < lim ? next : lim)), dim3(NTHR8), 0, stream, g);
+        return true;
+    }
+    // ---- store-form members (atomic == 2) run one workgroup per tile over all tokens: no token split to fill the chip with, so a group
+    // of them uses 64 x 64 tiles -- four times the workgroups at the same output traffic; the 4-wave kernel, capped at two resident
+    // workgroups per CU (round 4), ~2 workgroups per CU in total (measured best inside the step), 8 - 32 slices each
+    const int TWv = all_store ? 64 : 128;
+    long long work = 0;
+    for (int i = 0; i < count; ++i)
+        work += (long long)((args[i].M + TWv - 1) / TWv) * ((args[i].N + TWv - 1) / TWv) * ((args[i].K + BT - 1) / BT);
+    long long spw = work / (2LL * n_cu);
+    spw = spw < 8 ? 8 : (spw > 32 ? 32 : spw);
     static const int knob_dbg = std::getenv("VITRES_DBG_TN") ? std::atoi(std::getenv("VITRES_DBG_TN")) : 0;
     for (int i = 0; i < count; ++i) {
         g.a[i] = args[i];
         g.a[i].sched |= (knob_dbg & 3) << 13;
-        if (knob_dbg & 4) g.a[i].sched |= 0x8000;               // VITRES_DBG_TN=4: add the masked zeros too
-        const long long slices = (args[i].K + BT - 1) / BT;
+        const long long sl_i = (args[i].K + BT - 1) / BT;
         const long long tiles = (long long)((args[i].M + TWv - 1) / TWv) * ((args[i].N + TWv - 1) / TWv);
-        long long split = args[i].atomic == 2 ? 1 : (slices + spw - 1) / spw;       // store form: one workgroup per tile
+        long long split = args[i].atomic == 2 ? 1 : (sl_i + spw - 1) / spw;       // store form: one workgroup per tile
         g.a[i].split_k = args[i].atomic == 2 ? 1 : group_split(split, args[i]);
         g.first[i] = next;
         next += (int)((tiles * g.a[i].split_k + 7) / 8 * 8);
     }
     for (int i = count; i <= MAXG; ++i) g.first[i] = next;
-    // VITRES_TN_GROUP_CAP = workgroups per CU the group may hold at once, in tenths (15 = 1.5 per CU; 0 = one workgroup per item)
-    static const int knob_cap = std::getenv("VITRES_TN_GROUP_CAP") ? std::atoi(std::getenv("VITRES_TN_GROUP_CAP")) : 20;
     int grid = next;
-    if (knob_cap > 0 && !(args[0].sched & 128)) {            // (sched bit 128: nothing runs beside this group -- the step's last)
-        const int lim = (knob_cap * n_cu / 10 + 7) / 8 * 8;
+    if (!(args[0].sched & 128)) {            // (sched bit 128: nothing runs beside this group -- the step's last)
+        const int lim = (2 * n_cu + 7) / 8 * 8;
         grid = next < lim ? next : lim;
     }
-    if (knob_gst == 3) {
-        if (TWv == 64) hipLaunchKernelGGL((tn_group_kernel<false, 64, 3>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
-        else hipLaunchKernelGGL((tn_group_kernel<false, 128, 3>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
-    } else if (TWv == 64) hipLaunchKernelGGL((tn_group_kernel<false, 64>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
-    else hipLaunchKernelGGL((tn_group_kernel<false, 128>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
+    if (TWv == 64) hipLaunchKernelGGL((tn_group_kernel<false, 64>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
+    else if (any_store || knob_dbg || (args[0].sched & 64)) hipLaunchKernelGGL((tn_group_kernel<false, 128>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
+    else hipLaunchKernelGGL(tn8_group_kernel<4>, dim3((unsigned)grid), dim3(NTHR), 0, stream, g);     // (sched 64: tn_body's instruction stream, tests)
     return true;
 }
 
@@ -412,36 +627,27 @@ bool vr_gemm_tn_launch(const vr_gemm_args& a0, hipStream_t stream, int n_cu) {
     if (needs_pure(a0) && (a0.atomic == 2 || !vr_gemm_shared::group_pure(a0.K, a0.m_groups))) return false;
     vr_gemm_args a = a0;
     if (a.atomic == 2) a.split_k = 1;
-    static const int knob_s = std::getenv("VITRES_TN_S") ? std::atoi(std::getenv("VITRES_TN_S")) : 32;
-    static const int knob_tw = std::getenv("VITRES_TN_TW") ? std::atoi(std::getenv("VITRES_TN_TW")) : 0;
     const long long slices = (a.K + BT - 1) / BT;
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
     // Every workgroup pays |tile| x 4 B of fp32 atomics whatever its share of the tokens, so the token split is coarse: 32
     // slices (2048 tokens) per workgroup (measured inside the two-stream training step: +3 % over 16/32 adaptive; 24 / 40 /
-    // 48 / 64 slower; VITRES_TN_S overrides), never more than 4 workgroups per CU.  64 x 64 tiles give 4x the workgroups at the
+    // 48 / 64 slower), never more than 4 workgroups per CU.  64 x 64 tiles give 4x the workgroups at the
     // same atomic volume.  (Round 2: splitting the few-tile problems -- patch-embedding and head weights, 64 - 160 workgroups --
     // finer until the chip holds two workgroups per CU: step 7.77 -> 7.86 ms, their atomics and the contention cost more.)
-    long long split = (slices + knob_s - 1) / knob_s;
-    // (64 x 64 is opt-in, VITRES_TN_TW=64: alone on the chip it is up to 2x faster for stage-1 weights, but inside the training
-    // step the extra workgroups take CUs from the data-gradient chain they run beside: measured -3 %)
-    const bool small = knob_tw == 64;
+    long long split = (slices + 31) / 32;
+    // (64 x 64 tiles for the atomic form: alone on the chip up to 2x faster for stage-1 weights, but inside the training step the extra
+    // workgroups take CUs from the data-gradient chain they run beside: measured -3 %; the store form of a single launch keeps 128 too)
+    const bool small = false;
     const long long tiles = small ? t64 : t128;
     if (a.split_k <= 0) {
-        static const int knob_fill = std::getenv("VITRES_TN_FILL") ? std::atoi(std::getenv("VITRES_TN_FILL")) : 4;
-        const long long by_fill = ((long long)knob_fill * n_cu + tiles - 1) / tiles;
+        const long long by_fill = (4LL * n_cu + tiles - 1) / tiles;
         if (split > by_fill) split = by_fill;
         a.split_k = (int)(split < 1 ? 1 : split);
     }
     if (a.atomic != 2) a.split_k = group_split(a.split_k, a);
     const long long total = tiles * a.split_k;
-    static const int knob_st = std::getenv("VITRES_TN_STAGES") ? std::atoi(std::getenv("VITRES_TN_STAGES")) : 1;
-    if (small) {
-        if (knob_st == 3) launch_tw<64, 3>(a, stream, total);
-        else launch_tw<64, 1>(a, stream, total);
-    } else {
-        if (knob_st == 3) launch_tw<128, 3>(a, stream, total);
-        else launch_tw<128, 1>(a, stream, total);
-    }
+    (void)t64;
+    launch_tw<128, 1>(a, stream, total);
     return true;
 }

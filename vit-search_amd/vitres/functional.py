@@ -44,6 +44,7 @@ FUSE_LN_FWD_MAXK = int(_os.environ.get('VITRES_FUSE_LN_FWD_MAXK', '4096'))
 # (128 x 257, 256): 33 -> 23 us.  0 / 1 = accumulate straight into the parameter gradients.
 LN_COPIES = int(_os.environ.get('VITRES_LN_COPIES', '64'))
 _DBG_SKIP_WGRAD = _os.environ.get('VITRES_DBG_SKIP_WGRAD', '0') != '0'
+_DBG_WGRAD_SCHED = int(_os.environ.get('VITRES_DBG_WGRAD_SCHED', '0'), 0)      # dev aid: OR-ed into the weight gradients' sched (64: 4-wave group kernel)
 _ln_pending = []
 
 
@@ -367,7 +368,7 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     dt = cfg["dtype"]
     ov = _overlap(g)
     sch = 1 if ov else 0
-    wsch = sch | (128 if (LAST_UNCAP and LAST_BLOCK[0]) else 0)     # weight gradients of the step's last block: uncapped group
+    wsch = sch | (128 if (LAST_UNCAP and LAST_BLOCK[0]) else 0) | _DBG_WGRAD_SCHED    # weight gradients of the step's last block: uncapped group
     if gt is None:
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                   # d(branch output), compute dtype
 
@@ -457,7 +458,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     dt = cfg["dtype"]
     ov = _overlap(g)
     sch = 1 if ov else 0
-    wsch = sch | (128 if (LAST_UNCAP and LAST_BLOCK[0]) else 0)     # weight gradients of the step's last block: uncapped group
+    wsch = sch | (128 if (LAST_UNCAP and LAST_BLOCK[0]) else 0) | _DBG_WGRAD_SCHED    # weight gradients of the step's last block: uncapped group
     if gt is None:
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
 

@@ -353,10 +353,6 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             for name, mod in self.named_modules():
                 fused = (name.endswith("attn.qkv") or name.endswith("mlp.fc1")) and isinstance(mod, nn.Linear) and \
                     mod.in_features <= Fn.FUSE_LN_MAXN
-                # round 6: proj / fc2 of the narrow first stage too -- their data gradients (K = the block's width <= 320) run on
-                # the panel-resident kernel (gemm_panel.hip), which reads the weight K-contiguous straight into MFMA operands
-                fused = fused or ((name.endswith("attn.proj") or name.endswith("mlp.fc2")) and isinstance(mod, nn.Linear) and
-                                  mod.out_features <= 320 and which != "fused_only")
                 if which != "all" and not fused:
                     continue
                 if isinstance(mod, nn.Linear) and id(mod.weight) in a["index"]:
