@@ -900,8 +900,8 @@ def test_bf16_step_trains_like_the_fp32_step():
     assert rel_.max() < 0.06 and rel_.mean() < 0.02, msg
 
 
-OPT_IN_FORMS = ["VITRES_NT_SPLIT=2", "VITRES_WGRAD_STORE=1", "VITRES_TN_GROUP_CAP=0", "VITRES_LN_XCD=0 VITRES_ATTN_XCD=0",
-                "VITRES_TAIL_AUX=0 VITRES_EMBED_WGRAD_SLICES=0", "VITRES_OVERLAP=0", "VITRES_LAST_UNCAP=1", "VITRES_TAIL_SPLIT=1"]
+OPT_IN_FORMS = ["VITRES_EMBED_WGRAD_SLICES=0", "VITRES_OVERLAP=0", "VITRES_DBG_K_SHARES=2", "VITRES_DBG_WGRAD_SCHED=0x10000",
+                "VITRES_DBG_WGRAD_SCHED=64", "VITRES_FUSE_LN=0"]
 # (the conv stem's patch-direct path is the default that test_gpu_fullsize's bf16 gradient tests hold against the reference;
 # its kernels are pinned bit for bit to the unfold / fold forms in test_stem_glue_kernels)
 

@@ -19,12 +19,7 @@ int bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float
 
 namespace {
 
-// VITRES_ATTN_VALU=1 forces the exact-fp32-arithmetic VALU kernels also for bf16 tensors (debugging aid)
-inline bool use_mfma(int dtype, int N, int H, int D) {
-    if (dtype != VR_BF16 || !vr_attn_mfma::supported(N, H, D)) return false;
-    const char* e = std::getenv("VITRES_ATTN_VALU");
-    return !(e && e[0] == '1');
-}
+inline bool use_mfma(int dtype, int N, int H, int D) { return dtype == VR_BF16 && vr_attn_mfma::supported(N, H, D); }
 
 constexpr int MAXT = 5;  // key groups of 64 per lane -> N <= 320
 

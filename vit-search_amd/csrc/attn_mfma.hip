@@ -1073,11 +1073,8 @@ template <int NKP> struct Plan {
     static constexpr int PB = NKP >= 9 ? 3 : NKP;
 };
 
-// VITRES_ATTN_XCD (default 1): sample-major block order per XCD (common.h xcd_block)
-static int attn_xcd() {
-    static const int k = std::getenv("VITRES_ATTN_XCD") ? std::atoi(std::getenv("VITRES_ATTN_XCD")) : 1;
-    return k;
-}
+// sample-major block order per XCD (common.h xcd_block)
+static constexpr int attn_xcd() { return 1; }
 template <int D, int NKP>
 static int launch_fwd(const bf16_t* qkv, bf16_t* o, float* lse, const int* keep, int B, int N, int H, float scale,
                       hipStream_t st) {
@@ -1104,11 +1101,9 @@ static int launch_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* d_o, con
     const size_t l1 = (size_t)2 * Img<D, 32 * NKP>::BYTES, l2 = l1 + 2 * 32 * NKP * sizeof(float);
     {       // one launch for dQ, dK, dV where the four staged images leave a CU two workgroups or more: the short sequences
             // and N = 257 at D = 32 (76 KB: 50.5 -> 41.9 us at 64 x 257 x 8 x 32; D = 64 would be alone on its CU: 63 -> 69 us).
-            // VITRES_ATTN_BWD_SHORT=0: always the two kernels, 2: always the merged one
-        static const int knob = std::getenv("VITRES_ATTN_BWD_SHORT") ? std::atoi(std::getenv("VITRES_ATTN_BWD_SHORT")) : 1;
         constexpr size_t L3 = (size_t)4 * Img<D, 32 * NKP>::BYTES + 2 * 32 * NKP * sizeof(float);
         constexpr int SOCC = NKP <= 3 ? 3 : (L3 <= 80 * 1024 ? 2 : 1);
-        const bool merged = knob == 2 || (knob == 1 && SOCC >= 2);
+        const bool merged = SOCC >= 2;
         if (merged) {
             const size_t l3 = (size_t)4 * Img<D, 32 * NKP>::BYTES + 2 * 32 * NKP * sizeof(float);
             if (N > 32 * (NKP - 1)) {

@@ -712,18 +712,16 @@ void launch1(vr_gemm_args a, hipStream_t stream) {
     // dgrad shapes (K <= 1024) its 1 workgroup / CU residency and tail cost more than the halved load traffic buys
     const long long big_tiles = (long long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const int want_split = a.atomic ? max(1, min(a.K / 512, 1 << 16)) : 1;
-    static const bool knob_big = !(std::getenv("VITRES_GEMM_BIG") && std::getenv("VITRES_GEMM_BIG")[0] == '0');
-    static const bool knob_persist = !(std::getenv("VITRES_GEMM_PERSIST") && std::getenv("VITRES_GEMM_PERSIST")[0] == '0');
     const bool shared = (a.sched & 1) != 0;
-    const bool big = knob_big && !shared && a.atomic && (a.M >= 192 && a.N >= 192) && big_tiles * want_split >= 192;
+    const bool big = !shared && a.atomic && (a.M >= 192 && a.N >= 192) && big_tiles * want_split >= 192;
     const long long tiles = big ? big_tiles : (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (a.atomic && a.split_k <= 0) a.split_k = (int)max(1LL, min((long long)want_split, max(1LL, 1024 / tiles)));
     const long long total = tiles * a.split_k;
     if (big) {
-        const int grid = (int)(knob_persist ? min(total, (long long)cu_count()) : total);   // 144 KB LDS: one workgroup per CU
+        const int grid = (int)min(total, (long long)cu_count());   // persistent workgroups; 144 KB LDS: one per CU
         hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TO, EPI, CfgBig>), dim3(grid), dim3(CfgBig::NTHR), 0, stream, a);
     } else {
-        const int grid = (int)((knob_persist && !shared) ? min(total, 2LL * cu_count()) : total);        // 72 KB LDS, <= 256 VGPR: two per CU
+        const int grid = (int)(!shared ? min(total, 2LL * cu_count()) : total);        // 72 KB LDS, <= 256 VGPR: two per CU
         hipLaunchKernelGGL((gemm_kernel<T, TA, TB, TO, EPI, CfgStd>), dim3(grid), dim3(CfgStd::NTHR), 0, stream, a);
     }
 }
@@ -796,7 +794,7 @@ static int gemm_validate(vr_gemm_args& a) {
     return VR_OK;
 }
 
-// tickets (16 KB) + four 128 x 128 fp32 slabs per CU: the workspace of gemm_nt.hip's split-K form (pick_split)
+// tickets (16 KB) + four 128 x 128 fp32 slabs per CU: the workspace of the K-split kernels (gemm_ntk.hip SPLIT, vr_gemm_args.k_shares)
 extern "C" int vr_gemm_ws_bytes(void) { return (int)(4096 * 4 + (size_t)cu_count() * 2 * (256 * 128) * sizeof(float)); }
 
 extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
@@ -804,13 +802,11 @@ extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
     vr_gemm_args a = *args;
     const int vrc = gemm_validate(a);
     if (vrc != VR_OK) return vrc;
-    static const bool knob_nt = !(std::getenv("VITRES_GEMM_NT") && std::getenv("VITRES_GEMM_NT")[0] == '0');
-    if (knob_nt && !(a.sched & 4) && vr_gemm_nt_launch(a, (hipStream_t)stream, cu_count())) {
+    if (!(a.sched & 4) && vr_gemm_nt_launch(a, (hipStream_t)stream, cu_count())) {
         VR_CHECK_LAUNCH();
         return VR_OK;
     }
-    static const bool knob_tn = !(std::getenv("VITRES_GEMM_TN") && std::getenv("VITRES_GEMM_TN")[0] == '0');
-    if (knob_tn && !(a.sched & 4) && vr_gemm_tn_launch(a, (hipStream_t)stream, cu_count())) {
+    if (!(a.sched & 4) && vr_gemm_tn_launch(a, (hipStream_t)stream, cu_count())) {
         VR_CHECK_LAUNCH();
         return VR_OK;
     }
@@ -823,8 +819,7 @@ extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
 
 extern "C" int vr_gemm_group(const vr_gemm_args* args, int count, vr_stream_t stream) {
     if (!args || count <= 0) return VR_EINVAL;
-    static const bool knob = !(std::getenv("VITRES_GEMM_GROUP") && std::getenv("VITRES_GEMM_GROUP")[0] == '0');
-    if (knob && count >= 2 && count <= 4) {
+    if (count >= 2 && count <= 4) {
         vr_gemm_args v[4];
         bool ok = true;
         for (int i = 0; i < count && ok; ++i) {

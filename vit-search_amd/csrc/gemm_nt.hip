@@ -48,18 +48,8 @@ __device__ const uint4 zero_chunk[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}
                 (long long)wall_clock64() * 16 + (slot);                                                 \
     } while (0)
 
-// SPLIT (128 x 128 tiles only): the K slices of a tile are cut into `ksplit` contiguous shares, one workgroup each (grid = tiles x
-// ksplit, share-major so that the workgroups of one share run together and meet in L2).  A workgroup writes its fp32 accumulators
-// to its slab of vr_gemm_args.ws (write-through stores), drains and takes the tile's ticket; the holder of the last ticket
-// acquires, adds the other slabs and runs the epilogue.  Nobody waits for anybody; tickets return to zero.  For grids that leave
-// a CU fewer workgroups than it can overlap (stage 2 / 3: 136 - 260 tiles walking 24 - 48 slices one after the other).
-__device__ __forceinline__ void store_wt(float* p, const f32x4 v) {        // write-through (sc1) 16-byte store
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-constexpr int SPLIT_TICKET_BYTES = 4096 * 4;      // ticket ints in front of the slabs (the upper half: NT_STAMP)
-
-template <typename TO, int EPI, bool FAST, int MI, int NJ, int STAGES, int FEAT, bool BKM = false, bool SPLIT = false>
-__global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm_args p, const int ksplit) {
+template <typename TO, int EPI, bool FAST, int MI, int NJ, int STAGES, int FEAT, bool BKM = false>
+__global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm_args p) {
     constexpr int BM = 32 * MI, WROWS = 16 * MI;      // tile rows, rows per wave
     constexpr int BN = 32 * NJ, WCOLS = 16 * NJ;      // tile columns, columns per wave
     constexpr int A_BYTES = BM * BK * 2, AP = MI;     // A slice bytes, LDS-DMA pieces of A per wave
@@ -77,16 +67,10 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
     const int total = tiles_n * tiles_m;
     // workgroup ids are dealt round-robin to the 8 XCDs: give each XCD one contiguous run of the n-fastest tile order
     int tile = blockIdx.x;
-    int zsplit = 0;
-    if constexpr (SPLIT) {
-        zsplit = tile / total;
-        tile -= zsplit * total;
-    }
     if (total >= 16) {
         const int xq = total >> 3, xr = total & 7, x = tile & 7;
         tile = x * xq + min(x, xr) + (tile >> 3);
     }
-    const int tile_lin = tile;
     const int tn = tile % tiles_n, tm = interleave_groups(tile / tiles_n, tiles_m, p.m_groups);
     const int m0 = tm * BM, n0 = tn * BN;
     const RowMap amap = {p.a_map.rpi, p.a_map.rps, p.a_map.off};
@@ -104,17 +88,7 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         n_any = range_has_kept(n0, BN, p.n_period, nmax);
     }
     LiveSlices live;                 // cursor over the slices with kept k (gemm_shared.h)
-    if constexpr (SPLIT) {
-        // this share's slices: an equal cut of the slices below the tile's largest kept prefix (plain prefixes; periodic masks: of all)
-        int klive = ntiles;
-        if (p.keep_k && p.k_period <= 0) klive = min(ntiles, (kmax + BK - 1) / BK);
-        if (!n_any) klive = 0;
-        const int kb = (int)((long long)zsplit * klive / ksplit);
-        ntiles = (int)((long long)(zsplit + 1) * klive / ksplit);       // (the loops below end at `ntiles`)
-        live.init(p.keep_k, p.k_period, kb, ntiles, kmax, n_any);
-    } else {
-        live.init(p.keep_k, p.k_period, 0, ntiles, kmax, n_any);
-    }
+    live.init(p.keep_k, p.k_period, 0, ntiles, kmax, n_any);
 
     // ---- LDS-DMA source addressing: piece h of this wave = tile rows wave*32 + 8h .. +8, lane -> (row, slot) ----
     // Interior tiles of un-mapped operands (every block Linear) take the affine path: one row address per operand, pieces 8 rows
@@ -333,41 +307,6 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
         __syncthreads();
     }
 
-    if constexpr (SPLIT) {
-        if (ksplit > 1) {
-            constexpr int SLAB = BM * BN;
-            float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(p.ws) + SPLIT_TICKET_BYTES) + (size_t)tile_lin * ksplit * SLAB;
-            int* tickets = reinterpret_cast<int*>(p.ws);
-            float* mine = slabs + (size_t)zsplit * SLAB + t * 4;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) store_wt(mine + (i * NJ + j) * (NTHR * 4), acc[i][j]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            int* flag = reinterpret_cast<int*>(smem + 4 * 4096);          // (behind the epilogue's four 4 KB park areas)
-            if (t == 0) *flag = __hip_atomic_fetch_add(tickets + tile_lin, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            if (*flag != ksplit - 1) return;                              // not the last share of this tile to arrive
-            if (t == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __hip_atomic_store(tickets + tile_lin, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            for (int z = 0; z < ksplit; ++z) {
-                if (z == zsplit) continue;
-                const float* src = slabs + (size_t)z * SLAB + t * 4;
-#pragma unroll
-                for (int r0 = 0; r0 < MI * NJ; r0 += 4) {                 // (four 16-byte loads in flight: 128 registers)
-                    f32x4 part[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) part[r] = *reinterpret_cast<const f32x4*>(src + (r0 + r) * (NTHR * 4));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[(r0 + r) / NJ][(r0 + r) % NJ] += part[r];
-                }
-            }
-        }
-    }
     NT_STAMP(3);
     // (DEPTH = 2 for the fp32-residual forms -- the next round's residual requested once this round's accumulators are parked --
     // measured round 3: +10..17 registers, 4 - 12 spilled at the 128 / 96 caps, residual GEMMs 29.0 -> 30.1 / 19.3 -> 21.0 us: no)
@@ -378,15 +317,15 @@ __global__ __launch_bounds__(NTHR, MI == 4 ? 4 : 5) void nt_kernel(const vr_gemm
 
 template <typename TO, int EPI, int MI, int NJ, int STAGES, int FEAT> void launch3(const vr_gemm_args& a, hipStream_t stream, bool fast) {
     const long long total = (long long)((a.M + 32 * MI - 1) / (32 * MI)) * ((a.N + 32 * NJ - 1) / (32 * NJ));
-    if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true, MI, NJ, STAGES, FEAT>), dim3((unsigned)total), dim3(NTHR), 0, stream, a, 1);
-    else hipLaunchKernelGGL((nt_kernel<TO, EPI, false, MI, NJ, STAGES, 4>), dim3((unsigned)total), dim3(NTHR), 0, stream, a, 1);
+    if (fast) hipLaunchKernelGGL((nt_kernel<TO, EPI, true, MI, NJ, STAGES, FEAT>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
+    else hipLaunchKernelGGL((nt_kernel<TO, EPI, false, MI, NJ, STAGES, 4>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
 }
 
 template <typename TO, int EPI, int MI, int NJ, int STAGES = 1> void launch2(const vr_gemm_args& a, hipStream_t stream, bool fast) {
     if (a.b_trans) {     // weights as the forward stores them (vr_gemm_nt_launch admitted the form): bf16 data gradients only
         if constexpr (sizeof(TO) == 2 && (EPI == EPI_STORE || EPI == EPI_DMUL || EPI == EPI_DGELU)) {
             const long long total = (long long)((a.M + 32 * MI - 1) / (32 * MI)) * ((a.N + 32 * NJ - 1) / (32 * NJ));
-            hipLaunchKernelGGL((nt_kernel<TO, EPI, true, MI, NJ, STAGES, 0, true>), dim3((unsigned)total), dim3(NTHR), 0, stream, a, 1);
+            hipLaunchKernelGGL((nt_kernel<TO, EPI, true, MI, NJ, STAGES, 0, true>), dim3((unsigned)total), dim3(NTHR), 0, stream, a);
         }
         return;
     }
@@ -416,76 +355,25 @@ template <typename TO, int EPI, int MI, int NJ, int STAGES = 1> void launch2(con
     }
 }
 
-// Split-K forms (nt_kernel SPLIT): the fp32-residual forward forms and the plain bf16 data gradient on the forward's weights --
-// the long-K GEMMs of stages 2 and 3.  Returns false when the form has no split kernel.
-template <typename TO, int EPI, int STAGES> bool launch_split(const vr_gemm_args& a, hipStream_t stream, int S) {
-    const long long total = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    const dim3 grid((unsigned)(total * S)), block(NTHR);
-    if constexpr (EPI == EPI_STORE && sizeof(TO) == 2) {
-        if (!a.b_trans || a.bias || a.resid || a.scale || a.pos) return false;
-        hipLaunchKernelGGL((nt_kernel<TO, EPI, true, 4, 4, STAGES, 0, true, true>), grid, block, 0, stream, a, S);
-        return true;
-    } else if constexpr (EPI == EPI_STORE && sizeof(TO) == 4) {
-        if (a.b_trans || a.pos || a.K % BK || !a.bias || !a.resid) return false;
-        if (a.scale) hipLaunchKernelGGL((nt_kernel<TO, EPI, true, 4, 4, STAGES, 3, false, true>), grid, block, 0, stream, a, S);
-        else hipLaunchKernelGGL((nt_kernel<TO, EPI, true, 4, 4, STAGES, 2, false, true>), grid, block, 0, stream, a, S);
-        return true;
-    }
-    return false;
-}
-
-// how to cut an under-filled grid: S shares per tile, `stages` slices per round (2: 64 KB of LDS, two workgroups per CU;
-// 1: 32 KB, four).  0: do not split.
-inline int pick_split(long long t128, int slices, int n_cu, long long ws_bytes, int& stages) {
-    stages = 1;
-    if (t128 >= 2LL * n_cu || t128 > 2048 || slices < 16) return 0;
-    const int s2 = (int)std::min<long long>(std::min<long long>(2LL * n_cu / t128, 4), slices / 8);
-    const int s1 = (int)std::min<long long>(std::min<long long>(4LL * n_cu / t128, 4), slices / 4);
-    int S = 0;
-    if (s2 >= 2) { S = s2; stages = 2; }
-    else if (s1 >= 2) { S = s1; stages = 1; }
-    if (S && (long long)SPLIT_TICKET_BYTES + t128 * S * (128LL * 128 * 4) > ws_bytes) return 0;
-    return S;
-}
-
 template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     const long long tn = (a.N + 127) / 128;
     const long long t128 = (long long)((a.M + 127) / 128) * tn, t64 = (long long)((a.M + 63) / 64) * tn;
     const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);
-    static const int knob = std::getenv("VITRES_NT_TILE") ? std::atoi(std::getenv("VITRES_NT_TILE")) : 0;   // 1/2/3: force
     // tile by grid size (measured crossovers, tools/gemm_bench.py): 128x128 while it gives a CU two workgroups, 64x128
     // below that, 64x64 when even that leaves CUs with a single workgroup (long-K GEMMs of the last stage)
-    const int tile = knob ? knob : (t128 >= 2LL * n_cu ? 1 : (t64 >= 2LL * n_cu ? 2 : 3));
-    static const int knob_pair = std::getenv("VITRES_NT_PAIR") ? std::atoi(std::getenv("VITRES_NT_PAIR")) : 1;
-    // split-K (needs vr_gemm_args.ws).  Measured (tools/split_bench.py, profiles/r03_split_k.txt): it pays where a tile walks >= 36
-    // slices and the grid is at most one 128 x 128 tile per CU -- the bf16 data gradients of the last stage (38.4 -> 29.1 us at
-    // K = 3072, 29.3 -> 24.6 at K = 2304; three shares, two slices per round) -- and nowhere else: the fp32-residual forward forms
-    // already run 64 x 64 ring tiles as fast, stage 2 (260 tiles, K = 1536) loses 1 - 3 us to the slab round trip.  Inside the sr_tiny
-    // step the winning cases change nothing (7.84 - 7.88 against 7.88 ms; everywhere: 8.07 ms), so the default is off:
-    // VITRES_NT_SPLIT=1: those cases; 2: wherever pick_split() finds a cut; sched bit 64: wherever a cut exists (tests).
-    static const int knob_split = std::getenv("VITRES_NT_SPLIT") ? std::atoi(std::getenv("VITRES_NT_SPLIT")) : 0;
-    if ((knob_split || (a.sched & 64)) && a.ws && fast && !knob) {
-        int stages = 1;
-        int S = pick_split(t128, (a.K + BK - 1) / BK, n_cu, a.ws_bytes, stages);
-        const bool wide_open = knob_split >= 2 || (a.sched & 64);
-        if (!wide_open && !(sizeof(TO) == 2 && a.b_trans && stages == 2 && t128 <= n_cu && a.K >= 36 * BK)) S = 0;
-        if ((a.sched & 64) && S == 0 && t128 <= 2048 && a.K >= 2 * BK &&
-            (long long)SPLIT_TICKET_BYTES + t128 * 2 * (128LL * 128 * 4) <= a.ws_bytes) { S = 2; stages = (a.sched & 1) ? 2 : 1; }   // forced (tests)
-        if (S >= 2 && (stages == 2 ? launch_split<TO, EPI, 2>(a, stream, S) : launch_split<TO, EPI, 1>(a, stream, S))) return;
-    }
+    const int tile = t128 >= 2LL * n_cu ? 1 : (t64 >= 2LL * n_cu ? 2 : 3);
     if (tile == 1) launch2<TO, EPI, 4, 4>(a, stream, fast);
     else if (tile == 2) {
         // every tile resident at three workgroups per CU and >= 8 slices: two slices per round (STAGES = 2)
-        if (knob_pair && t64 <= 3LL * n_cu && a.K >= 8 * BK) launch2<TO, EPI, 2, 4, 2>(a, stream, fast);
+        if (t64 <= 3LL * n_cu && a.K >= 8 * BK) launch2<TO, EPI, 2, 4, 2>(a, stream, fast);
         else launch2<TO, EPI, 2, 4>(a, stream, fast);
     } else {
         // 64 x 64 tiles: with fewer than ~3 workgroups per CU and a long K the slices are pipelined inside the workgroup
-        static const int knob_st = std::getenv("VITRES_NT_STAGES") ? std::atoi(std::getenv("VITRES_NT_STAGES")) : 0;
         const long long t3 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-        const bool ring = knob_st ? knob_st == 3 : (t3 < 3LL * n_cu && a.K >= 24 * BK);      // measured: +23 % at K = 3072, -3 % at K = 1024
+        const bool ring = t3 < 3LL * n_cu && a.K >= 24 * BK;      // measured: +23 % at K = 3072, -3 % at K = 1024
         if (ring) launch2<TO, EPI, 2, 2, 3>(a, stream, fast);
-        else if (knob_pair && t3 <= n_cu && a.K >= 4 * BK) launch2<TO, EPI, 2, 2, 4>(a, stream, fast);   // at most one workgroup per CU
-        else if (knob_pair && a.K >= 8 * BK) launch2<TO, EPI, 2, 2, 2>(a, stream, fast);
+        else if (t3 <= n_cu && a.K >= 4 * BK) launch2<TO, EPI, 2, 2, 4>(a, stream, fast);   // at most one workgroup per CU
+        else if (a.K >= 8 * BK) launch2<TO, EPI, 2, 2, 2>(a, stream, fast);
         else launch2<TO, EPI, 2, 2>(a, stream, fast);
     }
 }
@@ -506,9 +394,8 @@ bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     if (a.b_trans) {
         // B = W [K][N] row-major (the forward's weight): plain data gradients with a bf16 result (optionally times gelu'), 16-byte
         // rows, the epilogue's vector form; anything else stays with the general kernel
-        static const bool knob_km = !(std::getenv("VITRES_NT_BKM") && std::getenv("VITRES_NT_BKM")[0] == '0');
         const bool fast = a.N % 8 == 0 && a.ldc % 8 == 0 && (!a.dact_u || a.ldu % 8 == 0) && (a.n_period <= 0 || a.n_period % 8 == 0);
-        if (!knob_km || of32 || a.act == 1 || (a.act == 2 && !a.dact_u) || a.bias || a.resid || a.scale || a.pos || a.C2 ||
+        if (of32 || a.act == 1 || (a.act == 2 && !a.dact_u) || a.bias || a.resid || a.scale || a.pos || a.C2 ||
             a.b_map.rpi != 0 || !fast || a.ldb % 8 || ((uintptr_t)a.B & 15) || a.ldb < (a.N + 7) / 8 * 8)
             return false;
     }

@@ -273,8 +273,7 @@ extern "C" int vr_ln_fwd(const float* x, const float* w, const float* b, void* y
     if (C % 4 || C > 64 * 4 * MAXV_LIMIT) return VR_EUNSUPPORTED;
     if (out_dtype != VR_F32 && out_dtype != VR_BF16) return VR_EUNSUPPORTED;
     if (rows_per_sample <= 0) rows_per_sample = M;
-    // VITRES_LN_XCD (default 1): XCD-contiguous row ranges (common.h xcd_block), forward and backward
-    static const int knob_xcd = std::getenv("VITRES_LN_XCD") ? std::atoi(std::getenv("VITRES_LN_XCD")) : 1;
+    constexpr int knob_xcd = 1;                     // XCD-contiguous row ranges (common.h xcd_block), forward and backward
     const int nv = (C + 255) / 256;
     int ru = nv <= 2 ? 4 : (nv <= 4 ? 2 : 1);
     while (ru > 1 && M < 4 * ru * 1024) ru >>= 1;                       // (fewer than ~4 workgroups per CU: one row per wave)
@@ -313,12 +312,9 @@ extern "C" int vr_ln_bwd(const void* dy, const float* x, const float* w, const f
     if (C % 4 || C > 64 * 4 * MAXV_LIMIT) return VR_EUNSUPPORTED;
     if (dy_dtype != VR_F32 && dy_dtype != VR_BF16) return VR_EUNSUPPORTED;
     if (rows_per_sample <= 0) rows_per_sample = M;
-    static const int knob_xcd = std::getenv("VITRES_LN_XCD") ? std::atoi(std::getenv("VITRES_LN_XCD")) : 1;
+    constexpr int knob_xcd = 1;
     // rows per workgroup: with partial rows the atomics no longer collide, so many small workgroups (better tail) win
-    static const int knob_rows = std::getenv("VITRES_LN_BWD_ROWS") ? std::atoi(std::getenv("VITRES_LN_BWD_ROWS")) : 0;
-    const int BWD_ROWS = knob_rows > 0 ? knob_rows
-                         : copies > 1  ? (M >= 8192 ? 16 : (M >= 2048 ? 8 : 4))
-                                       : (M >= 32768 ? 64 : (M >= 8192 ? 32 : (M >= 2048 ? 8 : 4)));
+    const int BWD_ROWS = copies > 1 ? (M >= 8192 ? 16 : (M >= 2048 ? 8 : 4)) : (M >= 32768 ? 64 : (M >= 8192 ? 32 : (M >= 2048 ? 8 : 4)));
     dim3 grid((M + BWD_ROWS - 1) / BWD_ROWS);
     const int nv = (C + 255) / 256;
 #define VR_LN_BWD(NV)                                                                                                  \

@@ -531,8 +531,7 @@ extern "C" int vr_softce_train(const float* logits, const float* target, const i
                                float gscale, float loss_scale, vr_stream_t stream) {
     if (!logits || !target || !loss_acc || !dlogits || R <= 0 || K <= 0 || rows_per_sample <= 0 || ld_grad < K) return VR_EINVAL;
     const dim3 grid((R + 3) / 4);
-    static const bool knob_reg = !(std::getenv("VITRES_SOFTCE_REG") && std::getenv("VITRES_SOFTCE_REG")[0] == '0');
-    const bool reg = knob_reg && K % 4 == 0 && K <= 1024 && ld_grad % 4 == 0 && ld_grad <= 1024 && !((uintptr_t)logits & 15) &&
+    const bool reg = K % 4 == 0 && K <= 1024 && ld_grad % 4 == 0 && ld_grad <= 1024 && !((uintptr_t)logits & 15) &&
                      !((uintptr_t)target & 15) && !((uintptr_t)dlogits & 15);
     if (reg && grad_dtype == VR_F32) {
         hipLaunchKernelGGL((softce_train_reg_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, logits, target,

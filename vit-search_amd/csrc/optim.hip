@@ -86,8 +86,7 @@ static int adamw_launch(float* p, const float* g, float* m, float* v, void* shad
         for (int i = 0; i < n_groups; ++i) gs.g[i] = groups[i];
     const long long n8 = n / 8;
     long long blocks = (n8 + 255) / 256;
-    static const int knob_blocks = std::getenv("VITRES_ADAMW_BLOCKS") ? std::atoi(std::getenv("VITRES_ADAMW_BLOCKS")) : 0;
-    const long long cap = max_blocks > 0 ? max_blocks : (knob_blocks > 0 ? knob_blocks : 8192);
+    const long long cap = max_blocks > 0 ? max_blocks : 8192;
     if (blocks > cap) blocks = cap;
     if (on_device)
         hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow,

@@ -27,7 +27,6 @@ OVERLAP = _os.environ.get('VITRES_OVERLAP', '3') != '0'
 DEFER_JOIN = _os.environ.get('VITRES_OVERLAP', '3') == '2'
 JOIN_PER_BLOCK = _os.environ.get('VITRES_OVERLAP', '3') == '3'
 FUSE_CAST = _os.environ.get('VITRES_FUSE_CAST', '1') != '0'      # LayerNorm backward also emits the next branch's gradient
-PROJ_LATE = _os.environ.get('VITRES_PROJ_LATE', '0') != '0'      # issue proj's weight gradient after the attention core
 # vr_gemm_ln (gemm_nt_ln.hip): bit 0 = LayerNorm forward behind the Linear that produces its input, bit 1 = LayerNorm backward
 # behind the data-gradient GEMM that produces its gradient; whole-row tiles, so only widths <= VITRES_FUSE_LN_MAXN.  Round 2
 # (kernel rewritten as GEMM K loop + the LayerNorm kernels' row loop glued through LDS) measured inside the sr_tiny step:
@@ -255,28 +254,13 @@ def linear_dgrad(dy, W, dx, M, N_in, K_out, lddy, lddx, **kw):
         K.gemm(dy, W.w_c, dx, M=M, N=N_in, K=K_out, lda=lddy, ldb=W.ld, ldc=lddx, b_trans=True, **kw)
 
 
-# VITRES_WGRAD_STORE=1 (opt-in): the weight gradients of the transformer-block Linears whose token count fits one workgroup's
-# walk (<= WGRAD_STORE_MAXT tokens: the 17-token stage at B = 128, 2176 tokens = 34 slices) are written in STORE form (vr_gemm
-# atomic == 2): one workgroup per tile over all tokens, plain stores -- no fp32 read-modify-write (stage 3 pays 82 MB of atomics
-# per block for 41 MB of gradients) and no zero fill of those spans of the gradient arena (vit_sr_supernet._zero_grad_arena skips
-# them).  Measured round 3 inside the sr_tiny step: 7.85 -> 8.1 ms with 128 x 128 AND with 64 x 64 tiles -- without the token
-# split a group is 576 workgroups walking 34 slices each behind a single slice buffer, and what the atomics cost is less than
-# what the second workgroup per tile hid; 12.4 ms with the 65-token stage included.  Parity-tested; default off.
-WGRAD_STORE = _os.environ.get('VITRES_WGRAD_STORE', '0') != '0'
-WGRAD_STORE_MAXT = int(_os.environ.get('VITRES_WGRAD_STORE_MAXT', '3072'))
-
-
-def wgrad_store_ok(tokens, dtype, is_cuda):
-    """The ONE rule both the block backward and the arena zero-fill apply (they must agree: a store-form span is not cleared)."""
-    return WGRAD_STORE and is_cuda and dtype == torch.bfloat16 and tokens <= WGRAD_STORE_MAXT
-
-
 def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_map=None, db=None, keep_rows=None,
                  keep_cols=None, row_period=0, tokens_per_sample=0, sched=0, collect=None, store=False, split=0, m_groups=None):
     """dw[N_out, K_in] += dy[M, N_out]^T @ x[M, K_in]  (fp32 atomics, split over tokens; db[N_out] += colsum(dy)).
     keep_rows / keep_cols: per-sample kept prefix of dy's / x's channels -> fully masked tiles are skipped.
     collect: a list -> the call is appended to it instead of being launched (K.gemm_group launches the list as one kernel).
-    store: dw and db are OVERWRITTEN (one workgroup per tile over all tokens, plain stores) -- see WGRAD_STORE.
+    store: dw and db are OVERWRITTEN (vr_gemm atomic == 2: one workgroup per tile over all tokens, plain stores; measured round 3 inside
+    the sr_tiny step: 7.85 -> 8.1 ms, so no caller asks for it).
     split: explicit token split (workgroups per output tile); 0 = the kernel's rule (32 slices of 64 tokens per workgroup)."""
     kw = dict(M=N_out, N=K_in, K=M, lda=lddy, ldb=ldx, ldc=ldw or K_in, a_trans=True, b_trans=True,
               atomic=(2 if store else True), split_k=(1 if store else split), a_map=a_map, b_map=b_map, bias_grad=db,
@@ -292,20 +276,6 @@ def linear_wgrad(dy, x, dw, M, N_out, K_in, lddy, ldx, ldw=None, a_map=None, b_m
 # launch on the side stream once the last of their operands (dqkv) exists, instead of four launches of ~200 workgroups each.
 WGRAD_GROUP = _os.environ.get('VITRES_WGRAD_GROUP', '1') != '0'
 _block_wgrads = []       # collected (dy, x, dw, kwargs) of the block being walked backwards
-# VITRES_WGRAD_EARLY=1 (measured slower, 8.73-8.91 against 8.47 ms: the attention kernels lose more to the contention than the
-# LayerNorm backward gains): the group is launched in front of the attention core (fc2, fc1, proj of this block + qkv of the
-# block before), so that it runs beside the attention kernels and the qkv data gradient instead of beside the HBM-bound
-# LayerNorm backward that closes the block
-WGRAD_EARLY = _os.environ.get('VITRES_WGRAD_EARLY', '0') != '0'
-
-
-# The LAST block of a backward (the network's first block): nothing follows it on the main chain and the optimizer waits for its
-# weight-gradient group.  VITRES_LAST_UNCAP=1 launches that group without the per-CU cap (sched bit 128): 7.42 - 7.47 against
-# 7.38 - 7.41 ms capped (it runs beside the patch-embedding weight gradient) -- off.  Also measured and dropped: its fc2 / fc1
-# (/ proj) gradients as an early group of their own (every block: +0.08 ms; last block only: +-0).
-LAST_UNCAP = _os.environ.get('VITRES_LAST_UNCAP', '0') != '0'
-LAST_BLOCK = [False]         # set by the model's backward walk around the last block
-
 
 def flush_wgrads():
     """Launch the collected weight gradients as one group on the side stream (no-op when nothing is pending)."""
@@ -368,7 +338,7 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     dt = cfg["dtype"]
     ov = _overlap(g)
     sch = 1 if ov else 0
-    wsch = sch | (128 if (LAST_UNCAP and LAST_BLOCK[0]) else 0) | _DBG_WGRAD_SCHED    # weight gradients of the step's last block: uncapped group
+    wsch = sch | _DBG_WGRAD_SCHED
     if gt is None:
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                   # d(branch output), compute dtype
 
@@ -377,29 +347,21 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
 
     def wgrad_proj():
         linear_wgrad(gt, o, grads["proj.w"], M, C, HD, C, HD, db=grads["proj.b"], keep_rows=out_keep, keep_cols=attn_keep,
-                     tokens_per_sample=N, sched=wsch, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda), m_groups=mg)
-    if grp is not None:
+                     tokens_per_sample=N, sched=wsch, collect=grp, m_groups=mg)
+    if grp is not None or not ov:
         wgrad_proj()
-        if WGRAD_EARLY:
-            flush_wgrads()                                  # [qkv of the previous block,] fc2, fc1, proj: beside the attention core
-    elif ov and not PROJ_LATE:
+    else:
         on_side(wgrad_proj, gt)
-    elif not ov:
-        wgrad_proj()
     d_o = torch.empty((B, N, HD), dtype=dt, device=x.device)
     linear_dgrad(gt, p["proj"], d_o, M, HD, C, C, HD, keep_n=attn_keep, rows_in=N, keep_k=out_keep, sched=sch)
     dqkv = K.attn_bwd(qkv, o, d_o, lse, attn_keep, B, N, H, D, cfg["scale"])
-    if ov and PROJ_LATE and grp is None:
-        on_side(wgrad_proj, gt)
 
     def wgrad_qkv():
         linear_wgrad(dqkv, y, grads["qkv.w"], M, 3 * HD, C, 3 * HD, C, db=grads["qkv.b"], keep_rows=attn_keep,
-                     keep_cols=embed_keep, row_period=HD, tokens_per_sample=N, sched=wsch, collect=grp,
-                     store=wgrad_store_ok(M, dt, g.is_cuda), m_groups=mg)
+                     keep_cols=embed_keep, row_period=HD, tokens_per_sample=N, sched=wsch, collect=grp, m_groups=mg)
     if grp is not None:
         wgrad_qkv()
-        if not WGRAD_EARLY:
-            flush_wgrads()                                  # fc2, fc1 (MLP branch), proj, qkv: every operand exists now
+        flush_wgrads()                                      # fc2, fc1 (MLP branch), proj, qkv: every operand exists now
     elif ov:
         on_side(wgrad_qkv, dqkv)
     else:
@@ -458,7 +420,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     dt = cfg["dtype"]
     ov = _overlap(g)
     sch = 1 if ov else 0
-    wsch = sch | (128 if (LAST_UNCAP and LAST_BLOCK[0]) else 0) | _DBG_WGRAD_SCHED    # weight gradients of the step's last block: uncapped group
+    wsch = sch | _DBG_WGRAD_SCHED
     if gt is None:
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
 
@@ -467,7 +429,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
 
     def wgrad_fc2():
         linear_wgrad(gt, h, grads["fc2.w"], M, C, F, C, F, db=grads["fc2.b"], keep_rows=out_keep, keep_cols=mlp_keep,
-                     tokens_per_sample=N, sched=wsch | rsk, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda), m_groups=mg)
+                     tokens_per_sample=N, sched=wsch | rsk, collect=grp, m_groups=mg)
     if ov and grp is None:
         on_side(wgrad_fc2, gt)
     else:
@@ -478,7 +440,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
 
     def wgrad_fc1():
         linear_wgrad(du, y, grads["fc1.w"], M, F, C, F, C, db=grads["fc1.b"], keep_rows=mlp_keep, keep_cols=embed_keep,
-                     tokens_per_sample=N, sched=wsch | rsk, collect=grp, store=wgrad_store_ok(M, dt, g.is_cuda), m_groups=mg)
+                     tokens_per_sample=N, sched=wsch | rsk, collect=grp, m_groups=mg)
     if ov and grp is None:
         on_side(wgrad_fc1, du)
     else:
@@ -524,7 +486,7 @@ def sr_fwd(x, p, cfg, embed_keep, new_keep, save, pre=None):
 
 
 def sr_bwd(gout, saved, p, grads, cfg, embed_keep, new_keep, gt=None, next_cast=None):
-    flush_wgrads()                                          # the last block's qkv weight gradient (VITRES_WGRAD_EARLY)
+    flush_wgrads()
     x, mean, rstd, y, col = saved
     B, Ni, C = x.shape
     g = cfg["grid"]
@@ -586,14 +548,11 @@ def embed0_fwd(img, p, cfg, keep, save, sample_map=None, col=None):
 # 160 workgroups walking 32 slices each (103 us, and it was the first kernel of a serial step tail); EMBED_WGRAD_SLICES slices
 # per workgroup -> 4x the workgroups, each paying |tile| x 4 B of atomics (42 MB in all at 8).
 EMBED_WGRAD_SLICES = int(_os.environ.get('VITRES_EMBED_WGRAD_SLICES', '8'))
-# VITRES_TAIL_AUX=1: the end of a backward -- patch-embedding weight gradient, positional-embedding sums, LayerNorm partial-row
-# folds -- runs on the auxiliary stream "tail" beside the first block's weight-gradient group (they feed nothing but the
-# optimizer); 0: in line on the main stream (round 3: 0.15 ms of kernels one after another with nothing beside them).
-TAIL_AUX = _os.environ.get('VITRES_TAIL_AUX', '1') != '0'
-# VITRES_TAIL_SPLIT=1: positional-embedding sums and LayerNorm folds on the MAIN stream while the auxiliary one runs the projection's
-# weight gradient.  Measured slower (round 4): hipGraph's executor runs the step's end on two hardware queues, and a third branch
-# lands on the weight gradients' queue in front of the last two groups (they start ~330 us late, profiles/r04_step_tail_ab.txt).
-TAIL_SPLIT = _os.environ.get('VITRES_TAIL_SPLIT', '0') != '0'
+# The end of a backward -- patch-embedding weight gradient, positional-embedding sums, LayerNorm partial-row folds -- runs on the
+# auxiliary stream "tail" beside the first block's weight-gradient group (they feed nothing but the optimizer); in line on the main
+# stream it was 0.15 ms of kernels one after another with nothing beside them (round 3).  On THREE branches (the sums on the main
+# stream) the third lands on the weight gradients' hardware queue in front of the last two groups: +0.1 ms (round 4).
+TAIL_AUX = True
 
 
 def embed0_bwd(g, saved, p, grads, cfg, keep, gt=None, wgrad=True, pos=True):

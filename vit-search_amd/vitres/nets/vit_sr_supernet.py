@@ -387,32 +387,12 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         return Fn.Weights(m.weight, m.bias.detach() if m.bias is not None else None, w, w.shape[1], w_t, ld_t)
 
     def _zero_grad_arena(self, buf, B):
-        """optimizer.zero_grad() of the flat gradient arena (reference engine.py:175) minus the spans the backward OVERWRITES:
-        the weight and bias gradients of the transformer-block Linears whose weight gradient runs in store form
-        (functional.wgrad_store_ok -- the same rule, from the same token count B x N of the block)."""
+        """optimizer.zero_grad() of the flat gradient arena (reference engine.py:175): every weight gradient ACCUMULATES (fp32 atomics
+        of the token splits), so the whole arena is cleared, in one launch."""
         a = self._arena
-        key = (B, self.compute_dtype, buf.is_cuda, Fn.WGRAD_STORE, Fn.WGRAD_STORE_MAXT)
         cached = a.get("zero_ranges")
-        if cached is None or cached[0] != key:
-            spans = []
-            grid = self.img_size // self.patch_size
-            for blk in self.blocks:
-                if isinstance(blk, Block):
-                    if Fn.wgrad_store_ok(B * (self.num_tokens + grid * grid), self.compute_dtype, buf.is_cuda):
-                        for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
-                            for p_ in (lin.weight, lin.bias):
-                                if p_ is not None:
-                                    spans.append(a["offsets"][a["index"][id(p_)]])
-                elif isinstance(blk, SpatialReductionPatchEmbedding):
-                    grid //= 2
-            ranges, cur = [], 0
-            for off, n in sorted(spans):
-                if off > cur:
-                    ranges.append((cur, off))
-                cur = max(cur, off + n)
-            if cur < buf.numel():
-                ranges.append((cur, buf.numel()))
-            cached = a["zero_ranges"] = (key, ranges, sum(n for _, n in spans))
+        if cached is None or cached[0] != buf.numel():
+            cached = a["zero_ranges"] = (buf.numel(), [(0, buf.numel())], 0)
         if buf.is_cuda:
             K.zero_ranges(buf, cached[1])
         else:
@@ -557,8 +537,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
         """The part of _Plan.skip_writes that does not depend on the draw: bf16 kernels; every transformer block's widths multiples of
         the 64-wide K slice and at most 4096 (64 slices), every activation a reader walks below 4 GB (32-bit byte offsets) -- the forms
         gemm_ntk.hip covers: a reader of skipped tiles (sched 0x80000) that gemm_ntk.hip declines is refused by every other kernel
-        (VR_EUNSUPPORTED), so such a network keeps writing its zeros; atomic weight gradients (the store form runs one workgroup over
-        all architecture groups)."""
+        (VR_EUNSUPPORTED), so such a network keeps writing its zeros."""
         dims_ok = getattr(self, "_skippable_dims", None)
         if dims_ok is None:
             ok, widest = True, 0
@@ -570,7 +549,7 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
             dims_ok = self._skippable_dims = (ok, widest)
         ok, widest = dims_ok
         tokens = self.pos_embed.shape[1]                                   # (the first stage's: later stages have fewer)
-        return ok and B * tokens * widest * 2 < 0xfff00000 and self.compute_dtype == torch.bfloat16 and not Fn.WGRAD_STORE
+        return ok and B * tokens * widest * 2 < 0xfff00000 and self.compute_dtype == torch.bfloat16
 
     def _dp_scales_host(self, plan):
         """DropPath scales floor(keep_prob + u) / keep_prob (nets/drop.py:21-26) of one forward, [n_dp, B] float32 on the host in
@@ -1094,13 +1073,9 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                          "fc1.w": gv(blk.mlp.fc1.weight), "fc1.b": gv(blk.mlp.fc1.bias),
                          "fc2.w": gv(blk.mlp.fc2.weight), "fc2.b": gv(blk.mlp.fc2.bias)}
                 with_parts(grads, ("n1w", blk.norm1.weight), ("n2w", blk.norm2.weight))
-                Fn.LAST_BLOCK[0] = not any(e[0] == "block" for e in rtape[ti + 1:])     # (no block follows: functional.LAST_UNCAP)
-                try:
-                    g, gt = Fn.mlp_branch_bwd(g, sm, p, grads, cfg, ek, km, ko, s2, gt=gt, next_cast=(s1, ko))      # gt: attention branch's
-                    nc = consumer_cast(ti)
-                    g = Fn.attn_branch_bwd(g, sa, p, grads, cfg, ek, ka, ko, s1, gt=gt, next_cast=nc)
-                finally:
-                    Fn.LAST_BLOCK[0] = False
+                g, gt = Fn.mlp_branch_bwd(g, sm, p, grads, cfg, ek, km, ko, s2, gt=gt, next_cast=(s1, ko))      # gt: attention branch's
+                nc = consumer_cast(ti)
+                g = Fn.attn_branch_bwd(g, sa, p, grads, cfg, ek, ka, ko, s1, gt=gt, next_cast=nc)
                 g, gt = g if nc is not None else (g, None)
             elif kind == "sr":
                 _, blk, p, cfg, (ek, nk), sv = entry
@@ -1140,14 +1115,8 @@ class FlexibleDistillVisionTransformerSR(nn.Module):
                         # nothing downstream but the optimizer: the projection's weight gradient on the auxiliary stream beside the
                         # first block's last weight gradient, the small reductions meanwhile on the main stream
                         Fn.flush_wgrads()
-                        if Fn.TAIL_SPLIT:
-                            if gt is None:
-                                gt = K.scale_mask_cast(g, None, ekeep, g.shape[1], ecfg["dtype"])
-                            Fn.on_aux("tail", lambda gt=gt: tail(True, False, gt=gt), g, gt, wt, *sv)
-                            tail(False, True, gt=gt)
-                        else:
-                            Fn.on_aux("tail", tail, g, gt, wt, *sv)
-                            tail_aux = True
+                        Fn.on_aux("tail", tail, g, gt, wt, *sv)
+                        tail_aux = True
                     else:
                         tail()
                 else:
