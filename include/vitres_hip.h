@@ -96,21 +96,30 @@ typedef struct vr_gemm_args {
     int32_t rows_in;     /* rows per sample of the M index (0: single sample); wgrad: tokens per sample of the K index */
     int32_t n_period;    /* > 0: column n is kept iff (n % n_period) < keep_n[s] (per-head prefixes of the qkv layout) */
     int32_t k_period;    /* same for keep_k */
-    int32_t sched;       /* scheduling hints (bit mask, 0 = default): 1 = launched beside another kernel on a second stream (general
-                            kernel: 128x128 tile, one workgroup per tile instead of persistent workgroups); 2 = keep the hardware's
-                            round-robin workgroup -> XCD order (default: tiles remapped so that an XCD owns a contiguous run);
-                            4 = always use the general kernel (gemm.hip) -- measurement aid; 64 = split-K form of the 4-wave kernel
-                            (gemm_nt.hip: shares of a tile's K slices on several workgroups, fp32 slabs in ws, the last arriver runs the
-                            epilogue) wherever a cut exists; 128 (vr_gemm_group, first problem) = the group may fill the chip (default:
-                            capped at two resident workgroups per CU, VITRES_TN_GROUP_CAP); 0x100 = gemm_nt.hip's kernels instead of the
-                            lean-loop ones (gemm_ntk.hip); 0x600 / 0x1800 = slices in flight (1 - 3) / tile (1: 128 x 128, 2: 64 x 128,
-                            3: 64 x 64) of the lean-loop kernels instead of their grid-size rule (tests); 8, 16, 32: measurement aids of
-                            gemm_nt.hip (force its kernels, record stamps);
+    int32_t sched;       /* scheduling hints (bit mask, 0 = default).  None changes results beyond fp32 summation order.
+                            1 = launched beside another kernel on a second stream (general kernel: 128x128 tile, one workgroup per
+                                tile instead of persistent workgroups);
+                            2 = keep the hardware's round-robin workgroup -> XCD order (default: tiles remapped so that an XCD owns
+                                a contiguous run);
+                            4 = always use the general kernel (gemm.hip) -- measurement aid;
+                            8, 16, 32 = measurement aids of gemm_nt.hip (force its kernels, record stamps in ws);
+                            64 (vr_gemm_group, first problem) = tn_body's instruction stream for the weight-gradient group instead of
+                                the lean LDS-DMA one (tests); 0x10000 (same place) = the 8-wave, double-buffered group kernel -- one
+                                workgroup per CU, one token split for the whole group (faster alone, +0.05 ms inside the step: opt-in);
+                            128 (vr_gemm_group, first problem) = the group may fill the chip (default: at most two resident
+                                workgroups per CU);
+                            0x100 = gemm_nt.hip's kernels instead of the lean-loop ones (gemm_ntk.hip);
+                            0x600 / 0x1800 = slice buffers (1 - 3; see `ring`) / tile (1: 128 x 128, 2: 64 x 128, 3: 64 x 64) of the
+                                lean-loop kernels instead of their grid-size rule (tests);
                             0x40000 = the caller vouches that every reader of C / C2 is a kernel that tiles group by group (m_groups
-                            below) and skips the masked channels of a row's group: bf16 outputs without a residual then leave
-                            tiles that are masked (keep_n) for every row UNWRITTEN instead of storing zeros; 0x80000 = an operand
-                            of this launch was produced that way -- the launch runs on the group-by-group kernels or fails with
-                            VR_EUNSUPPORTED, it is never handed to a kernel that tiles across groups */
+                                below) and skips the masked channels of a row's group: bf16 outputs without a residual then leave
+                                tiles that are masked (keep_n) for every row UNWRITTEN instead of storing zeros;
+                            0x80000 = an operand of this launch was produced that way -- the launch runs on the group-by-group
+                                kernels or fails with VR_EUNSUPPORTED, it is never handed to a kernel that tiles across groups;
+                            0x200000 = the panel-resident kernel (gemm_panel.hip: K <= 320, bf16 result, K-contiguous weight; the A
+                                panel in LDS, weight strips in registers) wherever it covers the form, 0x800000 with it: its 80-row /
+                                4-wave form; 0x400000 / 0x1000000 / 0x2000000 with it: its measurement forms (no MFMA / no weight
+                                loads: results are NOT the GEMM's).  Opt-in: measured slower than the tiled kernels */
     vr_rowmap a_map;     /* remap of A's token rows (M index if a_trans==0, K index if a_trans==1) */
     vr_rowmap b_map;     /* remap of B's token rows (only meaningful when b_trans==1 && a_trans==1) */
     vr_rowmap c_map;     /* remap of output rows */
@@ -122,8 +131,8 @@ typedef struct vr_gemm_args {
                             / gemm_tn) also cut the grid per group -- no tile or token split holds rows of two groups (the last
                             tile of a group is short).  Results do not depend on it.  A keep value -(k + 2) marks a sample that is
                             masked on its own inside a group of width k (DropPath): every kernel reads it as 0.  0 / 1: one group */
-    void* ws;            /* optional workspace of the split-K form (sched 64, VITRES_NT_SPLIT): the workgroups that share a tile exchange
-                            fp32 partial accumulators through it.  >= vr_gemm_ws_bytes() bytes, 16-byte aligned, ZERO before its first
+    void* ws;            /* optional workspace of the K-split kernels (k_shares below): the workgroups that share a tile exchange fp32
+                            partial accumulators through it.  >= vr_gemm_ws_bytes() bytes, 16-byte aligned, ZERO before its first
                             use (the kernels leave its tickets at zero), never shared by launches that may run concurrently (one per
                             stream).  NULL: every tile is computed by one workgroup. */
     int64_t ws_bytes;
@@ -131,9 +140,11 @@ typedef struct vr_gemm_args {
                             ring - 1 are in flight).  0 = the library's rule: as deep as LDS allows without lowering the number of
                             workgroups the grid gives a CU */
     int32_t k_shares;    /* lean-loop bf16 kernels: workgroups that share a tile's K slices (needs ws; the partial fp32 tiles meet in ws by
-                            plain stores, the last arriver sums them in share order and runs the epilogue -- results do not depend on
-                            arrival order).  0 = the library's rule (under-filled grids with >= 16 slices), 1 = never, 2 - 4 = that many
-                            wherever the form has a split kernel */
+                            plain write-through stores, the last arriver sums them in share order and runs the epilogue -- results do
+                            not depend on arrival order, no fp32 atomics touch the output).  0 / 1 = one workgroup per tile (no rule
+                            turns the split on: every real split measured slower than the unsplit kernel on the step's shapes,
+                            DESIGN.md), 2 - 4 = that many shares wherever the form has a split kernel and ws holds tiles x shares
+                            slabs of the tile's fp32 size */
 } vr_gemm_args;
 
 /* bytes of vr_gemm_args.ws that enable tile sharing on the current device */
@@ -182,6 +193,18 @@ typedef struct vr_ln_epilogue {
 } vr_ln_epilogue;
 int vr_gemm_ln(const vr_gemm_args* args, const vr_ln_epilogue* ln, vr_stream_t stream);
 int vr_gemm_ln_supported(int32_t N);
+
+/*
+ * vr_gemm_ln_fold: mode 0 of vr_gemm_ln for widths where a row spans several tiles (N up to 2048; the Linear + LayerNorm pairs of
+ * stages 2 and 3: nets/supernet_blocks.py:214-253 followed by nets/masked_layer_norm.py:113-125) --
+ *   C = resid + scale[s] * mask_{keep_n}(A B^T + bias)   (fp32, exactly vr_gemm),   (y, mean, rstd) = MaskedLayerNorm(C; w, b, keep, eps)
+ * in ONE launch of the tiled lean-loop kernel: every 64 x 128 tile stores its part of C write-through and takes the ticket of its row
+ * block; the workgroup that holds a block's last ticket runs vr_ln_fwd's row routine on the block's rows (same arithmetic: results
+ * equal vr_gemm followed by vr_ln_fwd up to nothing -- the same fp32 operations in the same order per row).
+ * bf16 operands, fp32 C with bias and residual, ldc == N, N % 4 == 0, un-mapped output rows, args->ws >= 16 KB with zeroed tickets (the
+ * kernels leave them at zero; never shared by launches that may run concurrently).  VR_EUNSUPPORTED (nothing launched) otherwise.
+ */
+int vr_gemm_ln_fold(const vr_gemm_args* args, const vr_ln_epilogue* ln, vr_stream_t stream);
 
 /* fp32 -> bf16 (round to nearest even), n elements.  Replaces autocast's per-op weight casts (engine.py:112). */
 int vr_cast_f32_bf16(const float* src, void* dst, int64_t n, vr_stream_t stream);

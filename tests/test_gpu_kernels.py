@@ -236,6 +236,63 @@ def test_gemm_panel_resident_leaves_masked_strips_unwritten(form):
     assert relerr(torch.nan_to_num(out), ref) < 8e-3
 
 
+@pytest.mark.parametrize("M,N,K_,rows_in", [(8320, 512, 1536, 65), (2176, 1024, 768, 17), (2176, 1024, 3072, 17), (20 * 65, 512, 512, 65),
+                                            (6 * 257, 320, 640, 257), (4 * 17, 2048, 256, 17)])
+@pytest.mark.parametrize("masked,groups,with_scale", [(False, 1, True), (True, 2, True), (True, 1, False)])
+def test_gemm_ln_fold_matches_separate_kernels(M, N, K_, rows_in, masked, groups, with_scale, monkeypatch):
+    """vr_gemm_ln_fold (round 6, gemm_ntk.hip LNF): the Linear with bias + DropPath scale + residual on the tiled kernel and the
+    LayerNorm of its fp32 result in ONE launch -- every tile takes its row block's ticket, the last arriver normalises the block's
+    rows.  Against vr_gemm followed by vr_ln_fwd on the same inputs: the residual stream bit for bit (same kernel, write-through
+    stores), y / mean / rstd to the last bit or two (the same row routine); launch after launch beside a busy second stream (the
+    tickets return to zero, nobody waits for anybody), ragged last row blocks, prefix masks on K, N and the LayerNorm width, one
+    and two architecture groups."""
+    monkeypatch.setattr(K, "LN_FOLD", True)                  # (opt-in in the product: slower inside the step, DESIGN.md)
+    Bn = M // rows_in
+    g = torch.Generator().manual_seed(11)
+    a = rnd(M, K_, seed=1).to(torch.bfloat16)
+    keep_k = keep_n = ln_keep = None
+    if masked:
+        keep_k = torch.full((Bn,), K_, dtype=torch.int32)
+        keep_k[Bn // 2:] = (K_ * 5 // 8) // 64 * 64
+        a = a * (torch.arange(K_)[None, :] < keep_k.long().repeat_interleave(rows_in)[:, None])
+        keep_n = torch.full((Bn,), N, dtype=torch.int32)
+        keep_n[Bn // 2:] = (N * 3 // 4) // 8 * 8
+        ln_keep = keep_n.clone()
+    b = rnd(N, K_, seed=2, scale=K_ ** -0.5).to(torch.bfloat16)
+    resid = rnd(M, N, seed=4)
+    if masked:
+        resid = resid * (torch.arange(N)[None, :] < ln_keep.long().repeat_interleave(rows_in)[:, None])      # the stream's masked channels are zeros
+    kw = dict(M=M, N=N, K=K_, lda=K_, ldb=K_, ldc=N, rows_in=rows_in, keep_n=keep_n, keep_k=keep_k, bias=rnd(N, seed=3), resid=resid,
+              scale=(torch.rand(Bn, generator=g) + 0.5) if with_scale else None)
+    lw, lb = rnd(N, seed=6) + 1.0, rnd(N, seed=7)
+    to = lambda v: v.to(DEV) if isinstance(v, torch.Tensor) else v
+    kw_d = {k: to(v) for k, v in kw.items()}
+    ad, bd = a.to(DEV), b.to(DEV)
+    K.M_GROUPS[0] = groups
+    try:
+        x_sep = K.gemm(ad, bd, torch.full((M, N), float("nan"), device=DEV), sched=2 << 11, **kw_d)
+        y_sep, mu_sep, rs_sep = K.ln_fwd(x_sep, to(lw), to(lb), to(ln_keep), rows_in, 1e-6, torch.bfloat16)
+        side = torch.cuda.Stream()
+        busy = torch.randn(4096, 4096, device=DEV)
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                busy = torch.tanh(busy @ busy * 1e-2)
+        for rep in range(3):
+            x_f = torch.full((M, N), float("nan"), device=DEV)
+            got = K.gemm_ln_fold_fwd(ad, bd, x_f, to(lw), to(lb), to(ln_keep), 1e-6, **kw_d)
+            assert got is not None, "the form must be covered"
+            y_f, mu_f, rs_f = got
+            torch.cuda.synchronize()
+            assert torch.equal(x_f, x_sep), rep
+            assert relerr(mu_f, mu_sep) < 1e-6 and relerr(rs_f, rs_sep) < 1e-6
+            assert relerr(y_f, y_sep) < 8e-3, (rep, relerr(y_f, y_sep))
+            assert float((y_f.float() != y_sep.float()).float().mean()) < 1e-3
+        ws = K._workspace(torch.device(DEV))
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0          # tickets back at zero
+    finally:
+        K.M_GROUPS[0] = 1
+
+
 @pytest.mark.parametrize("tile,ring", [(1, 4), (2, 4), (2, 5), (2, 6), (3, 4), (3, 6)])
 @pytest.mark.parametrize("variant", ["fwd", "res", "dgrad", "dmul"])
 def test_gemm_lean_loop_deep_rings(tile, ring, variant):

@@ -901,7 +901,7 @@ def test_bf16_step_trains_like_the_fp32_step():
 
 
 OPT_IN_FORMS = ["VITRES_EMBED_WGRAD_SLICES=0", "VITRES_OVERLAP=0", "VITRES_DBG_K_SHARES=2", "VITRES_DBG_WGRAD_SCHED=0x10000",
-                "VITRES_DBG_WGRAD_SCHED=64", "VITRES_FUSE_LN=0"]
+                "VITRES_DBG_WGRAD_SCHED=64", "VITRES_FUSE_LN=0", "VITRES_LN_FOLD=1"]
 # (the conv stem's patch-direct path is the default that test_gpu_fullsize's bf16 gradient tests hold against the reference;
 # its kernels are pinned bit for bit to the unfold / fold forms in test_stem_glue_kernels)
 

@@ -817,6 +817,21 @@ extern "C" int vr_gemm(const vr_gemm_args* args, vr_stream_t stream) {
     return launch<float>(a, (hipStream_t)stream);
 }
 
+bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu, const vr_ln_epilogue* ln);   // gemm_ntk.hip
+
+// vr_gemm with the LayerNorm that consumes its fp32 result folded into the launch (see include/vitres_hip.h)
+extern "C" int vr_gemm_ln_fold(const vr_gemm_args* args, const vr_ln_epilogue* ln, vr_stream_t stream) {
+    if (!args || !ln) return VR_EINVAL;
+    vr_gemm_args a = *args;
+    const int vrc = gemm_validate(a);
+    if (vrc != VR_OK) return vrc;
+    if (a.in_dtype != VR_BF16 || a.a_trans || a.atomic || a.split_k > 1 || a.bias_grad || a.pos) return VR_EUNSUPPORTED;
+    if (((uintptr_t)ln->y & 15) || ((uintptr_t)ln->w & 15) || ((uintptr_t)ln->b & 15)) return VR_EALIGN;
+    if (!vr_gemm_ntk_launch(a, (hipStream_t)stream, cu_count(), ln)) return VR_EUNSUPPORTED;
+    VR_CHECK_LAUNCH();
+    return VR_OK;
+}
+
 extern "C" int vr_gemm_group(const vr_gemm_args* args, int count, vr_stream_t stream) {
     if (!args || count <= 0) return VR_EINVAL;
     if (count >= 2 && count <= 4) {

@@ -380,13 +380,13 @@ template <typename TO, int EPI> void launch1(const vr_gemm_args& a, hipStream_t 
 
 }  // namespace vr_gemm_nt
 
-bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);      // gemm_ntk.hip: the lean-loop kernels
+bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu, const vr_ln_epilogue* ln);      // gemm_ntk.hip: the lean-loop kernels
 
 // Called by vr_gemm after validation.  Returns false when the form is not covered here.
 bool vr_gemm_nt_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     using namespace vr_gemm_nt;
     if (a.in_dtype != VR_BF16 || a.a_trans || a.atomic || a.split_k > 1 || a.bias_grad) return false;
-    if (vr_gemm_ntk_launch(a, stream, n_cu)) return true;
+    if (vr_gemm_ntk_launch(a, stream, n_cu, nullptr)) return true;
     // sched bit 0x80000: the operand may hold unwritten (fully masked) tiles, readable only by the group-pure row tiling of
     // gemm_ntk.hip -- the kernels below tile across architecture groups: refused (vr_gemm then fails loudly)
     if ((a.sched & 0x80000) && a.keep_k && a.m_groups > 1) return false;

@@ -62,7 +62,8 @@ template <int ROWB> __device__ __forceinline__ bfv8 tr_frag(const char* p) {
 // next round's residual is requested as soon as this round's accumulators are parked (their registers are free then: no
 // higher peak), a round's worth of work ahead of its use; DEPTH = MI (the 8-wave kernel, two waves per SIMD): everything up front.
 // WAITV (gemm_panel.hip): one s_waitcnt vmcnt(0) in front of the tile's first store -- see there.
-template <typename TO, int EPI, bool FAST, int MI, int NJ, int FEAT, int DEPTH = 1, bool WAITV = false>
+// WT (gemm_ntk.hip LNF): the fp32 result is stored write-through (gemm_shared.h storew).
+template <typename TO, int EPI, bool FAST, int MI, int NJ, int FEAT, int DEPTH = 1, bool WAITV = false, bool WT = false>
 __device__ __forceinline__ void epilogue(const vr_gemm_args& p, f32x4 (&acc)[MI][NJ], float* park, const RowMeta* meta0, const int nw0,
                                          const int lane) {
     constexpr int WCOLS = 16 * NJ;
@@ -269,7 +270,7 @@ __device__ __forceinline__ void epilogue(const vr_gemm_args& p, f32x4 (&acc)[MI]
                         for (int e = 0; e < CW; ++e) v[e] += rv[q][e];
                     }
                 }
-                if (any) storew<TO, CW>(p.C, oidx[q], v, vec, mok, nvalid);
+                if (any) storew<TO, CW, WT && EPI == EPI_STORE>(p.C, oidx[q], v, vec, mok, nvalid);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -65,8 +65,98 @@ __device__ __forceinline__ void store_wt(float* p, const f32x4 v) {        // wr
 constexpr int SPLIT_TICKET_BYTES = 4096 * 4;      // ticket ints in front of the slabs
 constexpr int SPLIT_MAX_TILES = 4096;
 
-template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM, bool DEEP_EPI = false, bool SPLIT = false>
-__global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gemm_args p, const int ksplit) {
+// LNF (round 6: the LayerNorm that consumes the Linear's fp32 result -- norm2 of the block, norm1 of the next block, the norm in front
+// of a spatial reduction or the heads, reference nets/masked_layer_norm.py:113-125 -- folded into the producer at widths where a
+// row spans several tiles, C = 512 / 1024).  Every tile stores its part of the rows write-through, drains and takes the ticket of
+// its ROW BLOCK; the holder of the block's last ticket (all N tiles of these rows are in memory) acquires and runs the LayerNorm
+// forward's row routine (ln.hip: one wave per row, same arithmetic) on the block's rows -- 128 - 256 KB read back from L2, y / mean /
+// rstd written -- while the other workgroups have moved on.  No separate ln_fwd launch (25 per step at stages 2 - 3), no second trip
+// of the residual stream through HBM.
+// NVJ float4 per lane and row (C <= 256 NVJ); R = 8 / NVJ rows of a wave in flight at once -- the block's 64 rows are 4 - 8 batches of
+// loads for the workgroup instead of 16 row round trips per wave (one row at a time: +35 us per launch, 7.69 against 6.85 ms per step)
+template <int NVJ>
+__device__ __forceinline__ void lnf_rows(const vr_gemm_args& p, const vr_ln_epilogue& ln, int m0, int mend, int wave, int lane) {
+    constexpr int R = NVJ >= 8 ? 1 : 8 / NVJ, NWV = KTHR / 64;      // (8 float4 of rows per lane: the kernel keeps its 96 registers)
+    const int C = p.N;
+    const float* x = reinterpret_cast<const float*>(p.C);
+    bf16_t* y = reinterpret_cast<bf16_t*>(ln.y);
+    for (int mb = m0 + wave * R; mb < mend; mb += NWV * R) {
+        float4 v[R][NVJ];
+        int kcs[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int m = min(mb + u, mend - 1);                                    // (rows past the block: loaded again, never stored)
+            kcs[u] = ln.keep ? ln.keep[p.rows_in > 0 ? m / p.rows_in : 0] : C;
+            const float* xr = x + (long long)m * p.ldc;
+#pragma unroll
+            for (int j = 0; j < NVJ; ++j) {
+                const int c = (lane + 64 * j) * 4;
+                v[u][j] = *reinterpret_cast<const float4*>(xr + (c < C ? c : 0));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int m = mb + u;
+            if (m >= mend) break;
+            const int kc = kcs[u];
+            float s = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NVJ; ++j) {
+                const int c = (lane + 64 * j) * 4;
+                if (c >= C) v[u][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < C) {
+                    if (c + 0 >= kc) v[u][j].x = 0.f;
+                    if (c + 1 >= kc) v[u][j].y = 0.f;
+                    if (c + 2 >= kc) v[u][j].z = 0.f;
+                    if (c + 3 >= kc) v[u][j].w = 0.f;
+                    s += v[u][j].x + v[u][j].y + v[u][j].z + v[u][j].w;
+                    s2 += v[u][j].x * v[u][j].x + v[u][j].y * v[u][j].y + v[u][j].z * v[u][j].z + v[u][j].w * v[u][j].w;
+                }
+            }
+            s = wave_sum(s);
+            const float inv_n = kc > 0 ? 1.0f / (float)kc : 0.f;
+            const float mu = s * inv_n;
+            float var;
+            if (ln.keep) {                                   // masked path: var = E[x^2] / p - mu^2 (masked_layer_norm.py:38-40)
+                s2 = wave_sum(s2);
+                var = s2 * inv_n - mu * mu;
+            } else {                                         // plain F.layer_norm path (:118-122): two-pass variance
+                float d2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NVJ; ++j) {
+                    const int c = (lane + 64 * j) * 4;
+                    if (c < C) {
+                        const float a = v[u][j].x - mu, b1 = v[u][j].y - mu, c1 = v[u][j].z - mu, d1 = v[u][j].w - mu;
+                        d2 += a * a + b1 * b1 + c1 * c1 + d1 * d1;
+                    }
+                }
+                var = wave_sum(d2) * inv_n;
+            }
+            const float rs = 1.0f / sqrtf(var + ln.eps);
+            if (lane == 0) {
+                ln.mean[m] = mu;
+                ln.rstd[m] = rs;
+            }
+            bf16_t* yr = y + (long long)m * C;
+#pragma unroll
+            for (int j = 0; j < NVJ; ++j) {
+                const int c = (lane + 64 * j) * 4;
+                if (c < C) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(ln.w + c), b4 = *reinterpret_cast<const float4*>(ln.b + c);
+                    const float o0 = (c + 0 < kc) ? w4.x * ((v[u][j].x - mu) * rs) + b4.x : 0.f;
+                    const float o1 = (c + 1 < kc) ? w4.y * ((v[u][j].y - mu) * rs) + b4.y : 0.f;
+                    const float o2 = (c + 2 < kc) ? w4.z * ((v[u][j].z - mu) * rs) + b4.z : 0.f;
+                    const float o3 = (c + 3 < kc) ? w4.w * ((v[u][j].w - mu) * rs) + b4.w : 0.f;
+                    *reinterpret_cast<uint2*>(yr + c) = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
+                }
+            }
+        }
+    }
+}
+constexpr int LNF_TICKET_OFF = 2048;               // ints: the row blocks' tickets live in the upper half of the ticket area of ws
+
+template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM, bool DEEP_EPI = false, bool SPLIT = false, bool LNF = false>
+__global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gemm_args p, const int ksplit, const vr_ln_epilogue ln) {
     constexpr int BM = 32 * MI, WROWS = 16 * MI;
     constexpr int BN = 32 * NJ, WCOLS = 16 * NJ;
     constexpr int A_BYTES = BM * BK * 2, AP = MI;
@@ -75,7 +165,7 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
     constexpr int META_OFF = NBUF * STAGE_BYTES;
     static_assert(META_OFF >= 4 * 4096, "epilogue park area");
     // ONE shared array (slice ring | row metadata): a second __shared__ object makes hipcc drain the DMA queue before LDS reads
-    __shared__ __attribute__((aligned(1024))) char smem[META_OFF + BM * (int)sizeof(RowMeta) + (SPLIT ? 16 : 0)];
+    __shared__ __attribute__((aligned(1024))) char smem[META_OFF + BM * (int)sizeof(RowMeta) + ((SPLIT || LNF) ? 16 : 0)];
     RowMeta* rowmeta = reinterpret_cast<RowMeta*>(smem + META_OFF);
     // forms whose fully masked tiles hold nothing but zeros (bf16 result, no residual): see the write skipping below
     constexpr bool SKIP_FORM = sizeof(TO) == 2 && ((EPI == EPI_STORE && FEAT <= 1) || EPI == EPI_GELU || EPI == EPI_DMUL);
@@ -381,44 +471,72 @@ __global__ __launch_bounds__(KTHR, MI == 4 ? 4 : 5) void ntk_kernel(const vr_gem
     // side operands of the epilogue (fp32 residual rows, saved gelu'): with two 16-row rounds per wave all of them are requested up
     // front (DEPTH = MI: 32 / 16 registers) -- one exposed HBM latency per tile instead of one per round
     constexpr int EDEPTH = (MI == 2 && DEEP_EPI) ? 2 : 1;
-    epilogue<TO, EPI, true, MI, NJ, FEAT, EDEPTH>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wm * WROWS, n0 + wn * WCOLS,
-                                                 lane);
+    epilogue<TO, EPI, true, MI, NJ, FEAT, EDEPTH, false, LNF>(p, acc, reinterpret_cast<float*>(smem + wave * 4096), rowmeta + wm * WROWS,
+                                                             n0 + wn * WCOLS, lane);
+    if constexpr (LNF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this tile's part of the rows is in memory
+        __syncthreads();
+        int* tickets = reinterpret_cast<int*>(p.ws) + LNF_TICKET_OFF;
+        int* flag = reinterpret_cast<int*>(smem + META_OFF + BM * (int)sizeof(RowMeta));
+        const int rb = tile_lin / tiles_n;                           // row block (position in the row-tile order)
+        if (t == 0) *flag = __hip_atomic_fetch_add(tickets + rb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != tiles_n - 1) return;                            // another tile of these rows is still on its way
+        if (t == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(tickets + rb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (p.N <= 512) lnf_rows<2>(p, ln, m0, min(m0 + BM, mend), wave, lane);
+        else if (p.N <= 1024) lnf_rows<4>(p, ln, m0, min(m0 + BM, mend), wave, lane);
+        else lnf_rows<8>(p, ln, m0, min(m0 + BM, mend), wave, lane);
+    }
 }
 
-template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM> void klaunch(const vr_gemm_args& a, hipStream_t stream, int shares) {
+template <typename TO, int EPI, int MI, int NJ, int NBUF, int FEAT, bool BKM> void klaunch(const vr_gemm_args& a, hipStream_t stream, int shares,
+                                                                                             const vr_ln_epilogue* ln) {
+    const vr_ln_epilogue ln0 = ln ? *ln : vr_ln_epilogue{};
     const long long total = (long long)group_tiles(a.M, 32 * MI, a.m_groups) * ((a.N + 32 * NJ - 1) / (32 * NJ));
     constexpr bool SIDE = (EPI == EPI_STORE && FEAT >= 2) || EPI == EPI_DMUL;
     // the forms of the block Linears have a split kernel (FEAT 2: a block without DropPath -- the first one -- is never a long-K one)
     constexpr bool CAN_SPLIT = NBUF <= 3 && ((EPI == EPI_STORE && (FEAT == 0 || FEAT == 1 || FEAT == 3)) || EPI == EPI_GELU || EPI == EPI_DMUL);
-    if constexpr (CAN_SPLIT) {
-        if (shares > 1) {
-            const unsigned grid = (unsigned)(8 * ((total + 7) / 8) * shares);
-            hipLaunchKernelGGL((ntk_kernel<TO, EPI, MI, NJ, NBUF, FEAT, BKM, MI == 2 && SIDE, true>), dim3(grid), dim3(KTHR), 0, stream, a, shares);
+    if constexpr (sizeof(TO) == 4 && EPI == EPI_STORE && FEAT >= 2 && !BKM && NBUF <= 3 && MI == 2 && NJ == 4) {     // (64 x 128 tiles)
+        if (ln) {
+            hipLaunchKernelGGL((ntk_kernel<TO, EPI, MI, NJ, NBUF, FEAT, BKM, true, false, true>), dim3((unsigned)total), dim3(KTHR), 0, stream, a, 1,
+                               ln0);
             return;
         }
     }
-    hipLaunchKernelGGL((ntk_kernel<TO, EPI, MI, NJ, NBUF, FEAT, BKM, MI == 2 && SIDE>), dim3((unsigned)total), dim3(KTHR), 0, stream, a, 1);
+    if constexpr (CAN_SPLIT) {
+        if (shares > 1) {
+            const unsigned grid = (unsigned)(8 * ((total + 7) / 8) * shares);
+            hipLaunchKernelGGL((ntk_kernel<TO, EPI, MI, NJ, NBUF, FEAT, BKM, MI == 2 && SIDE, true>), dim3(grid), dim3(KTHR), 0, stream, a, shares, ln0);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((ntk_kernel<TO, EPI, MI, NJ, NBUF, FEAT, BKM, MI == 2 && SIDE>), dim3((unsigned)total), dim3(KTHR), 0, stream, a, 1, ln0);
 }
 
-template <typename TO, int EPI, int FEAT, bool BKM> void ktile(const vr_gemm_args& a, hipStream_t stream, int tile, int nbuf, int shares) {
+template <typename TO, int EPI, int FEAT, bool BKM> void ktile(const vr_gemm_args& a, hipStream_t stream, int tile, int nbuf, int shares,
+                                                                const vr_ln_epilogue* ln = nullptr) {
     if (tile == 1) {
-        if (nbuf == 1) klaunch<TO, EPI, 4, 4, 1, FEAT, BKM>(a, stream, shares);
-        else if (nbuf == 2) klaunch<TO, EPI, 4, 4, 2, FEAT, BKM>(a, stream, shares);
-        else if (nbuf == 3) klaunch<TO, EPI, 4, 4, 3, FEAT, BKM>(a, stream, shares);
-        else klaunch<TO, EPI, 4, 4, 4, FEAT, BKM>(a, stream, 1);
+        if (nbuf == 1) klaunch<TO, EPI, 4, 4, 1, FEAT, BKM>(a, stream, shares, ln);
+        else if (nbuf == 2) klaunch<TO, EPI, 4, 4, 2, FEAT, BKM>(a, stream, shares, ln);
+        else if (nbuf == 3) klaunch<TO, EPI, 4, 4, 3, FEAT, BKM>(a, stream, shares, ln);
+        else klaunch<TO, EPI, 4, 4, 4, FEAT, BKM>(a, stream, 1, ln);
     } else if (tile == 2) {
-        if (nbuf == 1) klaunch<TO, EPI, 2, 4, 1, FEAT, BKM>(a, stream, shares);
-        else if (nbuf == 2) klaunch<TO, EPI, 2, 4, 2, FEAT, BKM>(a, stream, shares);
-        else if (nbuf == 3) klaunch<TO, EPI, 2, 4, 3, FEAT, BKM>(a, stream, shares);
-        else if (nbuf == 4) klaunch<TO, EPI, 2, 4, 4, FEAT, BKM>(a, stream, 1);
-        else if (nbuf == 5) klaunch<TO, EPI, 2, 4, 5, FEAT, BKM>(a, stream, 1);
-        else klaunch<TO, EPI, 2, 4, 6, FEAT, BKM>(a, stream, 1);
+        if (nbuf == 1) klaunch<TO, EPI, 2, 4, 1, FEAT, BKM>(a, stream, shares, ln);
+        else if (nbuf == 2) klaunch<TO, EPI, 2, 4, 2, FEAT, BKM>(a, stream, shares, ln);
+        else if (nbuf == 3) klaunch<TO, EPI, 2, 4, 3, FEAT, BKM>(a, stream, shares, ln);
+        else if (nbuf == 4) klaunch<TO, EPI, 2, 4, 4, FEAT, BKM>(a, stream, 1, ln);
+        else if (nbuf == 5) klaunch<TO, EPI, 2, 4, 5, FEAT, BKM>(a, stream, 1, ln);
+        else klaunch<TO, EPI, 2, 4, 6, FEAT, BKM>(a, stream, 1, ln);
     } else {
-        if (nbuf == 1) klaunch<TO, EPI, 2, 2, 1, FEAT, BKM>(a, stream, shares);
-        else if (nbuf == 2) klaunch<TO, EPI, 2, 2, 2, FEAT, BKM>(a, stream, shares);
-        else if (nbuf == 3) klaunch<TO, EPI, 2, 2, 3, FEAT, BKM>(a, stream, shares);
-        else if (nbuf == 4) klaunch<TO, EPI, 2, 2, 4, FEAT, BKM>(a, stream, 1);
-        else klaunch<TO, EPI, 2, 2, 6, FEAT, BKM>(a, stream, 1);
+        if (nbuf == 1) klaunch<TO, EPI, 2, 2, 1, FEAT, BKM>(a, stream, shares, ln);
+        else if (nbuf == 2) klaunch<TO, EPI, 2, 2, 2, FEAT, BKM>(a, stream, shares, ln);
+        else if (nbuf == 3) klaunch<TO, EPI, 2, 2, 3, FEAT, BKM>(a, stream, shares, ln);
+        else if (nbuf == 4) klaunch<TO, EPI, 2, 2, 4, FEAT, BKM>(a, stream, 1, ln);
+        else klaunch<TO, EPI, 2, 2, 6, FEAT, BKM>(a, stream, 1, ln);
     }
 }
 
@@ -427,9 +545,16 @@ template <typename TO, int EPI, int FEAT, bool BKM> void ktile(const vr_gemm_arg
 bool vr_gemm_panel_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu);      // gemm_panel.hip: panel-resident stage-1 kernels
 
 // Called by vr_gemm_nt_launch in front of gemm_nt.hip's own kernels.  Returns false when the form is not covered here.
-bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
+// ln != nullptr (vr_gemm_ln_fold): the LNF kernels -- fp32 result with bias + residual on 64 x 128 tiles, whole rows [M][N = ldc],
+// tickets in a.ws; anything else returns false and nothing is launched.
+bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu, const vr_ln_epilogue* ln) {
     using namespace vr_gemm_nt;
-    if (!(a.sched & (8 | 16 | 32 | 0x100)) && vr_gemm_panel_launch(a, stream, n_cu)) return true;
+    if (ln) {
+        if (a.out_dtype != VR_F32 || !a.bias || !a.resid || a.b_trans || a.dact_u || a.act || a.c_map.rpi || a.ldc != a.N || a.N % 4 ||
+            a.N > 2048 || !a.ws || a.ws_bytes < SPLIT_TICKET_BYTES || group_tiles(a.M, 64, a.m_groups) > 2048 || ln->mode != 0 || !ln->w ||
+            !ln->b || !ln->y || !ln->mean || !ln->rstd || (a.sched & (8 | 16 | 32 | 0x100)))
+            return false;
+    } else if (!(a.sched & (8 | 16 | 32 | 0x100)) && vr_gemm_panel_launch(a, stream, n_cu)) return true;
     if (a.sched & (8 | 16 | 32 | 0x100)) return false;      // forms of gemm_nt.hip forced by the caller (tests, measurement aids)
     // an operand with unwritten masked tiles (0x80000) is readable only by the group-pure row tiling: refused where it cannot be had
     if ((a.sched & 0x80000) && a.keep_k && a.m_groups > 1 && !group_pure(a.M, a.m_groups)) return false;
@@ -458,7 +583,7 @@ bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     const long long t128 = (long long)((a.M + 127) / 128) * tn, t64 = (long long)((a.M + 63) / 64) * tn;
     // sched bits 0x1800: tile override (1: 128 x 128, 2: 64 x 128, 3: 64 x 64), 0x600: slice buffers 1 - 3 (tests); vr_gemm_args.ring /
     // k_shares: slice buffers 1 - 6 / shares
-    const int s_tile = (a.sched >> 11) & 3, s_buf = (a.sched >> 9) & 3;
+    const int s_tile = ln ? 2 : ((a.sched >> 11) & 3), s_buf = (a.sched >> 9) & 3;
     // (in-graph sweep of all nine tile x depth combinations, profiles/r05_ntk_policy_sweep.txt: 64 x 128 tiles for the forms with a
     // bf16 side operand or two outputs once the 128 x 128 grid is below four / six per CU -- they run beside the weight-gradient
     // group's resident workgroups, which leave room for three 25 KB workgroups but only two 34 KB ones --, and 64 x 64 only when
@@ -477,7 +602,7 @@ bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     const int ntiles = a.K / BK;
     int shares = 1;
     constexpr int rule_tile = 0, rule_ring = 0;
-    if (split_form && a.k_shares > 1) shares = std::min(std::min(a.k_shares, 4), std::max(1, ntiles / 2));
+    if (split_form && a.k_shares > 1 && !ln) shares = std::min(std::min(a.k_shares, 4), std::max(1, ntiles / 2));
     const int tile = s_tile ? s_tile : (rule_tile ? rule_tile : auto_tile);
     const long long wgs = (long long)group_tiles(a.M, tile == 1 ? 128 : 64, a.m_groups) * ((a.N + (tile == 3 ? 63 : 127)) / (tile == 3 ? 64 : 128));
     const int stage_kb = tile == 1 ? 32 : (tile == 2 ? 24 : 16);
@@ -502,6 +627,7 @@ bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
     if (nbuf > 3) shares = 1;                                   // (the deep rings have no split kernels)
     nbuf = std::min(nbuf, tile == 1 ? 4 : 6);
     if (tile == 3 && nbuf == 5) nbuf = 4;
+    if (ln && (a.b_trans || gelu || !of32)) return false;
     if (a.b_trans) {
         if (of32 || feat != 0 || gelu || a.b_map.rpi != 0 || a.ldb < (a.N + 7) / 8 * 8) return false;
         if (a.dact_u) {
@@ -519,12 +645,14 @@ bool vr_gemm_ntk_launch(const vr_gemm_args& a, hipStream_t stream, int n_cu) {
         return true;
     }
     if (of32) {
-        if (feat == 3) ktile<float, EPI_STORE, 3, false>(a, stream, tile, nbuf, shares);
-        else if (feat == 2) ktile<float, EPI_STORE, 2, false>(a, stream, tile, nbuf, shares);
-        else if (feat == 1) ktile<float, EPI_STORE, 1, false>(a, stream, tile, nbuf, shares);
+        if (ln) nbuf = std::min(nbuf, 3);
+        if (feat == 3) ktile<float, EPI_STORE, 3, false>(a, stream, tile, nbuf, shares, ln);
+        else if (feat == 2) ktile<float, EPI_STORE, 2, false>(a, stream, tile, nbuf, shares, ln);
+        else if (feat == 1 && !ln) ktile<float, EPI_STORE, 1, false>(a, stream, tile, nbuf, shares);
         else return false;
         return true;
     }
+    if (ln) return false;
     if (feat == 1) ktile<bf16_t, EPI_STORE, 1, false>(a, stream, tile, nbuf, shares);
     else if (feat == 0) ktile<bf16_t, EPI_STORE, 0, false>(a, stream, tile, nbuf, shares);
     else return false;

@@ -130,11 +130,19 @@ template <typename TI, int CW> __device__ __forceinline__ void loadw(const void*
         for (int e = 0; e < CW; ++e) v[e] = Elem<TI>::ld(p + (e < nvalid ? e : 0));
     }
 }
-template <typename TO, int CW> __device__ __forceinline__ void storew(void* base, long long idx, const float (&v)[CW], bool vec,
-                                                                      bool rowok, int nvalid) {
+// WT: fp32 stores go out write-through (sc1) -- a workgroup on another XCD reads them back inside the same launch (gemm_ntk.hip LNF)
+template <typename TO, int CW, bool WT = false> __device__ __forceinline__ void storew(void* base, long long idx, const float (&v)[CW], bool vec,
+                                                                                       bool rowok, int nvalid) {
     TO* p = reinterpret_cast<TO*>(base) + idx;
     if (vec) {
-        if constexpr (sizeof(TO) == 4) {
+        if constexpr (sizeof(TO) == 4 && WT) {
+#pragma unroll
+            for (int h = 0; h < CW / 4; ++h) {
+                const f32x4 x = {v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+                // (s_nop: the store reads its data registers for a few cycles after issue -- a hazard hipcc covers for its own stores only)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + 4 * h), "v"(x) : "memory");
+            }
+        } else if constexpr (sizeof(TO) == 4) {
 #pragma unroll
             for (int h = 0; h < CW / 4; ++h)
                 *reinterpret_cast<float4*>(p + 4 * h) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);

@@ -59,6 +59,7 @@ SYMBOLS = {
     "vr_gemm_group": [ctypes.POINTER(GemmArgs), ctypes.c_int32, c_void_p],
     "vr_gemm_ln": [ctypes.POINTER(GemmArgs), ctypes.POINTER(LnEpilogue), c_void_p],
     "vr_gemm_ln_supported": [c_int32],
+    "vr_gemm_ln_fold": [ctypes.POINTER(GemmArgs), ctypes.POINTER(LnEpilogue), c_void_p],
     "vr_gemm_ws_bytes": [],
     "vr_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "vr_adamw_flat": [c_void_p] * 6 + [c_float, c_void_p, c_void_p, c_int32, c_int64, c_void_p],

@@ -320,7 +320,12 @@ def attn_branch_fwd(x, p, cfg, embed_keep, attn_keep, out_keep, scale, save, pre
         post = K.gemm_ln_fwd(o, p["proj"].w_c, x1, next_ln[0], next_ln[1], next_ln[2], next_ln[3], M=M, N=C, K=HD, lda=HD,
                              ldb=p["proj"].ld, ldc=C, bias=p["proj"].b, scale=scale, keep_n=out_keep, resid=x, rows_in=N,
                              keep_k=attn_keep)
-    else:
+    elif next_ln is not None:
+        # wider rows (stages 2 - 3): the LayerNorm folded into the tiled kernel's launch (vr_gemm_ln_fold), or None
+        post = K.gemm_ln_fold_fwd(o, p["proj"].w_c, x1, next_ln[0], next_ln[1], next_ln[2], next_ln[3], M=M, N=C, K=HD, lda=HD,
+                                  ldb=p["proj"].ld, ldc=C, bias=p["proj"].b, scale=scale, keep_n=out_keep, resid=x, rows_in=N,
+                                  keep_k=attn_keep)
+    if post is None and not _ln_fusable(o, C, next_ln):
         K.gemm(o, p["proj"].w_c, x1, M=M, N=C, K=HD, lda=HD, ldb=p["proj"].ld, ldc=C, bias=p["proj"].b, scale=scale,
                keep_n=out_keep, resid=x, rows_in=N, keep_k=attn_keep)
     saved = (x, mean, rstd, y, qkv, o, lse) if save else None
@@ -405,7 +410,11 @@ def mlp_branch_fwd(x, p, cfg, embed_keep, mlp_keep, out_keep, scale, save, pre=N
         post = K.gemm_ln_fwd(h, p["fc2"].w_c, x2, next_ln[0], next_ln[1], next_ln[2], next_ln[3], M=M, N=C, K=F, lda=F,
                              ldb=p["fc2"].ld, ldc=C, bias=p["fc2"].b, scale=scale, keep_n=out_keep, resid=x, rows_in=N,
                              keep_k=mlp_keep, sched=K.reads_skipped())
-    else:
+    elif next_ln is not None:
+        post = K.gemm_ln_fold_fwd(h, p["fc2"].w_c, x2, next_ln[0], next_ln[1], next_ln[2], next_ln[3], M=M, N=C, K=F, lda=F,
+                                  ldb=p["fc2"].ld, ldc=C, bias=p["fc2"].b, scale=scale, keep_n=out_keep, resid=x, rows_in=N,
+                                  keep_k=mlp_keep, sched=K.reads_skipped())
+    if post is None and not _ln_fusable(h, C, next_ln):
         K.gemm(h, p["fc2"].w_c, x2, M=M, N=C, K=F, lda=F, ldb=p["fc2"].ld, ldc=C, bias=p["fc2"].b, scale=scale,
                keep_n=out_keep, resid=x, rows_in=N, keep_k=mlp_keep, sched=K.reads_skipped())
     saved = (x, mean, rstd, y, u, h) if save else None

@@ -198,6 +198,48 @@ def gemm_ln_fwd(a, b, out, ln_w, ln_b, ln_keep, eps, *, M, N, K, lda, ldb, ldc, 
     return y, mean, rstd
 
 
+# vr_gemm_ln_fold (rows of several 128-column tiles; narrower rows go to vr_gemm_ln) is OPT-IN: measured round 6 inside the sr_tiny step
+# 7.51 against 6.97 ms (52 - 73 us per folded launch against 22 - 35 + 5 - 8 for the two kernels, profiles/r06_ln_fold.txt): the tiles'
+# fp32 rows must be visible to a workgroup on ANOTHER XCD inside the launch, i.e. stored write-through (partial-line writes to
+# memory) and waited for, and the last arriver's row loop is a tail nothing runs beside.
+LN_FOLD = __import__("os").environ.get("VITRES_LN_FOLD", "0") != "0"
+
+
+def gemm_ln_fold_fwd(a, b, out, ln_w, ln_b, ln_keep, eps, *, M, N, K, lda, ldb, ldc, bias=None, scale=None, keep_n=None,
+                     resid=None, rows_in=0, keep_k=None, k_period=0, sched=0):
+    """gemm_ln_fwd for rows that span several tiles (vr_gemm_ln_fold): out = resid + scale * mask(a @ b^T + bias) (fp32) and
+    (y, mean, rstd) = masked LayerNorm(out), one launch of the tiled kernel -- or None (nothing launched) when the form is not
+    covered: the caller then issues the Linear and the LayerNorm separately."""
+    if not (LN_FOLD and a.is_cuda and a.dtype == torch.bfloat16 and out.dtype == torch.float32 and N == ldc and 256 < N <= 2048 and
+            bias is not None and resid is not None and K % 64 == 0):
+        return None
+    args = _gemm_args(a, b, out, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, bias=bias, scale=scale, keep_n=keep_n, resid=resid,
+                      rows_in=rows_in, keep_k=keep_k, k_period=k_period, sched=sched, k_shares=0,
+                      ws=_workspace(a.device))
+    if not args.ws:
+        return None
+    y = torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
+    mean = torch.empty(M, dtype=torch.float32, device=out.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=out.device)
+    ln = LnEpilogue()
+    ln.mode, ln.eps = 0, eps
+    ln.w, ln.b, ln.keep, ln.y, ln.mean, ln.rstd = _p(ln_w), _p(ln_b), _p(ln_keep), _p(y), _p(mean), _p(rstd)
+    if PROFILE is not None:
+        flops, alg_bytes = _gemm_work(a, out, M, N, K, False, rows_in, keep_k, keep_n, k_period, 0, resid=resid, bias=bias)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.lib().vr_gemm_ln_fold(ctypes.byref(args), ctypes.byref(ln), _stream())
+    if rc == -3:                                   # VR_EUNSUPPORTED: nothing was launched
+        return None
+    _lib.check(rc, "vr_gemm_ln_fold")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((("bf16", 0, 0, 0), flops, 2.0 * M * N * K, alg_bytes + M * N * 2, e0, e1))       # (+ the LayerNorm's output)
+        if PROFILE_DESC is not None:
+            PROFILE_DESC.append("nt+ln M%d N%d K%d bias res%s f32out" % (M, N, K, " scale" if scale is not None else ""))
+    return y, mean, rstd
+
+
 def gemm_ln_bwd(du, wt, x, ln_w, mean, rstd, ln_keep, dx_in, dw, db, next_cast=None, *, M, N, K, lda, ldb, rows_in=0,
                 keep_k=None, k_period=0, copies=1, sched=0):
     """LayerNorm backward of dy = du @ wt^T without writing dy -- vr_gemm_ln mode 1; returns dx or (dx, gt) like ln_bwd
