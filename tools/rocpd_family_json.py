@@ -11,7 +11,7 @@ scols = [r[1] for r in cur.execute("pragma table_info(%s)" % sym)]
 namecol = "display_name" if "display_name" in scols else "kernel_name"
 fam = {}
 for name, n, tot in cur.execute("select s.%s, count(*), sum(d.end - d.start) from %s d join %s s on d.kernel_id = s.id group by s.%s" % (namecol, dis, sym, namecol)):
-    k = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("vr_gemm_nt::ntk_kernel", "vr_gemm_nt::nt_kernel")   # (lean-loop kernels: same family)
+    k = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("vr_gemm_nt::ntk_kernel", "vr_gemm_nt::nt_kernel").replace("vr_gemm_tn::tn8_group_kernel", "vr_gemm_tn::tn_group_kernel")   # (lean-loop kernels: same family)
     for f in ("vr_gemm_nt::nt_kernel", "vr_gemm_tn::tn_group_kernel", "vr_gemm_tn::tn_kernel", "vr_gemm_ntln::ntln_kernel", "ln_bwd_kernel", "ln_fwd_kernel",
               "vr_attn_mfma::fwd_kernel", "vr_attn_mfma::bwd_dq_kernel", "vr_attn_mfma::bwd_dkv_kernel", "vr_attn_mfma::bwd_short_kernel", "adamw_kernel"):
         if k.startswith(f):

@@ -23,7 +23,7 @@ def per_kernel(path):
 
 
 def family(name):
-    name = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("vr_gemm_nt::ntk_kernel", "vr_gemm_nt::nt_kernel")   # (lean-loop kernels: same family)
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("vr_gemm_nt::ntk_kernel", "vr_gemm_nt::nt_kernel").replace("vr_gemm_tn::tn8_group_kernel", "vr_gemm_tn::tn_group_kernel")   # (lean-loop kernels: same family)
     for fam in ("vr_gemm_nt::nt_kernel", "vr_gemm_tn::tn_group_kernel", "vr_gemm_tn::tn_kernel", "gemm_kernel", "ln_bwd_kernel", "ln_fwd_kernel",
                 "vr_attn_mfma::fwd_kernel", "vr_attn_mfma::bwd_dq_kernel", "vr_attn_mfma::bwd_dkv_kernel"):
         if name.startswith(fam):
