@@ -350,8 +350,9 @@ def test_masked_tiles_left_unwritten_are_never_read(case, monkeypatch):
             assert rel(g1, g0) < max(4 * noise_g, 1e-4), (case, mode, rel(g1, g0), noise_g)
 
 
-def test_benched_configuration_vs_cpu_oracle():
-    """the BENCHED configuration itself -- sr_tiny supernet, B = 128, example_per_arch 64 (two
+@pytest.mark.parametrize("space,B,epa,dp", [("sr_tiny", 128, 64, 0.2), ("sr_small", 64, 32, 0.3)])
+def test_benched_configuration_vs_cpu_oracle(space, B, epa, dp):
+    """the BENCHED configurations themselves (bench.py WORKLOADS: C3 and C4) -- sr_tiny supernet, B = 128, example_per_arch 64 (two
     architecture groups of 64: the group-pure tiling, group_tile_rows, write skipping and token splits bench.py runs), epoch 31,
     drop_path 0.2 on injected draws -- against the CPU oracle (pinned to the reference by F1-F19) run on this box's host cores on
     the SAME weights, inputs, keeps and DropPath draws (reference engine.py:112-157, nets/channel_drop.py:93-111).
@@ -362,10 +363,10 @@ def test_benched_configuration_vs_cpu_oracle():
     from test_oracle_golden import oracle_noise
     from vitres import supernet_config
     from vitres.nets import vit_sr_supernet as V
-    B, epa, dp = 128, 64, 0.2
-    prod = make(recipe.SR_TINY_DEF, "sr_tiny", dp, epa=epa)
-    orc = O.OracleViTSR(recipe.SR_TINY_DEF, num_classes=1000, drop_path_rate=dp, supernet=True, patch_output=True,
-                        num_channels_to_keep=supernet_config.sr_tiny.num_channels_to_keep, example_per_arch=epa, num_warmup_epochs=30)
+    nd = recipe.SR_TINY_DEF if space == "sr_tiny" else recipe.SR_SMALL_DEF
+    prod = make(nd, space, dp, epa=epa)
+    orc = O.OracleViTSR(nd, num_classes=1000, drop_path_rate=dp, supernet=True, patch_output=True,
+                        num_channels_to_keep=getattr(supernet_config, space).num_channels_to_keep, example_per_arch=epa, num_warmup_epochs=30)
     shapes = [(k, tuple(v.shape)) for k, v in orc.state_dict().items()]
     assert shapes == [(k, tuple(v.shape)) for k, v in prod.state_dict().items()]
     sd = recipe.fill_state_dict(shapes, 4343)
@@ -408,13 +409,24 @@ def test_benched_configuration_vs_cpu_oracle():
     assert any(not torch.equal(k[0::G_], k[1::G_]) for k in keeps), "the two architecture groups drew different widths"
     # fp32 parity mode
     e_cls, e_pat = rel(cls, ocls), rel(pat, opat)
-    worst = max(rel(grads[n], ograds[n]) for n in ograds)
-    print("B=128/epa=64 fp32 vs CPU oracle: logits %.2e / %.2e, loss %.2e, worst gradient %.2e" % (
-        e_cls, e_pat, abs(loss - oloss) / abs(oloss), worst))
+    # (a parameter whose gradient is mathematically zero -- the bias of a convolution in front of a train-mode BatchNorm -- holds
+    # rounding noise on both sides: compared on the scale of the largest gradient element of the network instead of its own)
+    gmax = max(float(g_.abs().max()) for g_ in ograds.values())
+
+    def grel(n):
+        a_, b_ = grads[n].double(), ograds[n].double()
+        return float((a_ - b_).abs().max() / max(float(b_.abs().max()), 1e-4 * gmax))
+    # convolution weights in front of a train-mode BatchNorm: the gradient through the batch statistics is a small difference of
+    # large sums over B x 112 x 112 positions -- fp32 summation order (CPU oracle against GPU) shows at ~3e-3 there; band 1e-2
+    stem = [n for n in ograds if n.startswith("patch_embed.conv")]
+    assert all(grel(n) < 1e-2 for n in stem), max((grel(n), n) for n in stem)
+    wname = max((n for n in ograds if n not in stem), key=grel)
+    worst = grel(wname)
+    print("%s B=%d/epa=%d fp32 vs CPU oracle: logits %.2e / %.2e, loss %.2e, worst gradient %.2e (%s, |g|max %.2e of %.2e)" % (
+        space, B, epa, e_cls, e_pat, abs(loss - oloss) / abs(oloss), worst, wname, float(ograds[wname].abs().max()), gmax))
     assert e_cls < 1e-3 and e_pat < 1e-3, (e_cls, e_pat)
     assert abs(loss - oloss) < 1e-4 * abs(oloss)
-    for n in ograds:
-        assert rel(grads[n], ograds[n]) < 5e-4, (n, rel(grads[n], ograds[n]))
+    assert worst < 5e-4, (wname, worst)
     # bf16 fast path, masked tiles left unwritten (the benched kernels), against the same oracle outputs
     assert V._SKIP_WRITES
     plan_b, cls_b, pat_b, loss_b, grads_b = hip(torch.bfloat16)
@@ -423,8 +435,47 @@ def test_benched_configuration_vs_cpu_oracle():
     drift = {n: abs(float(grads_b[n].double().norm()) - float(ograds[n].double().norm())) / max(float(ograds[n].double().norm()), 1e-12)
              for n in ograds}
     wn = max(drift, key=drift.get)
-    print("B=128/epa=64 bf16 (write skipping) vs CPU oracle: logits %.2e / %.2e, loss %.2e, worst gradient-norm drift %.2e (%s)" % (
-        rel(cls_b, ocls), rel(pat_b, opat), abs(loss_b - oloss) / abs(oloss), drift[wn], wn))
+    print("%s B=%d/epa=%d bf16 (write skipping) vs CPU oracle: logits %.2e / %.2e, loss %.2e, worst gradient-norm drift %.2e (%s)" % (
+        space, B, epa, rel(cls_b, ocls), rel(pat_b, opat), abs(loss_b - oloss) / abs(oloss), drift[wn], wn))
     assert rel(cls_b, ocls) < 3e-2 and rel(pat_b, opat) < 3e-2
     assert abs(loss_b - oloss) < 1e-2 * abs(oloss)
-    assert drift[wn] < 5e-2, (wn, drift[wn])
+    assert drift[wn] < (5e-2 if space == "sr_tiny" else 1.5e-1), (wn, drift[wn])          # (conv stem + train-mode BatchNorm in bf16: see
+                                                                                           #  test_full_size_bf16_gradients_vs_reference)
+
+
+def test_full_size_ln_fold_equals_separate_kernels(monkeypatch):
+    """Round 6: vr_gemm_ln_fold inside the model (opt-in, VITRES_LN_FOLD): the sr_tiny supernet at B = 16 with the LayerNorm of stages
+    2 - 3 folded into its producer gives the forward of the default path bit for bit (same GEMM kernel, same row routine) and the
+    same gradients up to the order of the fp32 atomics."""
+    from vitres import kernels as K
+    B = 16
+    prod = make(recipe.SR_TINY_DEF, "sr_tiny", 0.2, epa=8)
+    sd = recipe.fill_state_dict([(k, tuple(v.shape)) for k, v in prod.state_dict().items()], 4343)
+    prod.load_state_dict(sd)
+    prod = prod.to(DEV).set_compute_dtype(torch.bfloat16)
+    prod.train()
+    prod.set_epoch(31)
+    prod.load_state_dict(sd)
+    x, t, pt, _ = (v.to(DEV) for v in recipe.inputs(29, B, 224, 1000, 16))
+    res = {}
+    calls = []
+    real = K.gemm_ln_fold_fwd
+    for fold in (False, True):
+        monkeypatch.setattr(K, "LN_FOLD", fold)
+        def spy(*a, **k):
+            r = real(*a, **k)
+            calls.append(r is not None)
+            return r
+        monkeypatch.setattr(K, "gemm_ln_fold_fwd", spy)
+        prod.zero_grad(set_to_none=True)
+        prod.drop_path_generator(seed=3)
+        torch.manual_seed(5)
+        cls, pat = prod(x, patch_output_type="seq")
+        loss = O.soft_target_ce(cls, t) + O.soft_target_ce(pat, pt)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[fold] = (cls.detach().float().cpu(), pat.detach().float().cpu(),
+                     torch.cat([p.grad.reshape(-1).float() for p in prod.parameters()]).cpu())
+    assert any(calls), "the folded path ran"
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert rel(res[True][2], res[False][2]) < 1e-4

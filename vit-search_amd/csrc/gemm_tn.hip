@@ -555,9 +555,13 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
     g.count = count;
     int next = 0;
     const long long slices = (args[0].K + BT - 1) / BT;
+    // the lean kernels address a token split through 32-bit offsets of a buffer descriptor: every operand below 2 GB
+    bool lean_ok = true;
+    for (int i = 0; i < count; ++i)
+        lean_ok = lean_ok && (long long)args[i].K * args[i].lda * 2 < 0x7ff00000LL && (long long)args[i].K * args[i].ldb * 2 < 0x7ff00000LL;
     bool same_k = true;
     for (int i = 1; i < count; ++i) same_k = same_k && args[i].K == args[0].K && args[i].m_groups == args[0].m_groups;
-    if (!any_store && same_k && (args[0].sched & 0x10000)) {
+    if (!any_store && same_k && lean_ok && (args[0].sched & 0x10000)) {
         // ---- atomic form, OPT-IN (sched 0x10000 on the first problem): tn8_group_kernel<8>, one 8-wave workgroup per CU ----
         // One token split for the whole group.  Cost of s splits in slice-times of one workgroup: rounds of the chip x (slices of an
         // item + its epilogue: 64 KB of fp32 atomics per item, ~40 slice-times while every CU adds at once -- ~1.1 TB/s of payload
@@ -614,7 +618,7 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
         grid = next < lim ? next : lim;
     }
     if (TWv == 64) hipLaunchKernelGGL((tn_group_kernel<false, 64>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
-    else if (any_store || knob_dbg || (args[0].sched & 64)) hipLaunchKernelGGL((tn_group_kernel<false, 128>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
+    else if (any_store || knob_dbg || !lean_ok || (args[0].sched & 64)) hipLaunchKernelGGL((tn_group_kernel<false, 128>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
     else hipLaunchKernelGGL(tn8_group_kernel<4>, dim3((unsigned)grid), dim3(NTHR), 0, stream, g);     // (sched 64: tn_body's instruction stream, tests)
     return true;
 }
