@@ -44,7 +44,6 @@ FUSE_LN_FWD_MAXK = int(_os.environ.get('VITRES_FUSE_LN_FWD_MAXK', '4096'))
 LN_COPIES = int(_os.environ.get('VITRES_LN_COPIES', '64'))
 _DBG_SKIP_WGRAD = _os.environ.get('VITRES_DBG_SKIP_WGRAD', '0') != '0'
 _DBG_WGRAD_SCHED = int(_os.environ.get('VITRES_DBG_WGRAD_SCHED', '0'), 0)      # dev aid: OR-ed into the weight gradients' sched (64: 4-wave group kernel)
-_DBG_WGRAD8_MAXT = int(_os.environ.get('VITRES_DBG_WGRAD8_MAXT', '0'))         # dev aid: 8-wave group kernel for blocks with at most this many tokens
 _ln_pending = []
 
 
@@ -344,7 +343,7 @@ def attn_branch_bwd(g, saved, p, grads, cfg, embed_keep, attn_keep, out_keep, sc
     dt = cfg["dtype"]
     ov = _overlap(g)
     sch = 1 if ov else 0
-    wsch = sch | _DBG_WGRAD_SCHED | (0x10000 if M <= _DBG_WGRAD8_MAXT else 0)
+    wsch = sch | _DBG_WGRAD_SCHED
     if gt is None:
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)                   # d(branch output), compute dtype
 
@@ -430,7 +429,7 @@ def mlp_branch_bwd(g, saved, p, grads, cfg, embed_keep, mlp_keep, out_keep, scal
     dt = cfg["dtype"]
     ov = _overlap(g)
     sch = 1 if ov else 0
-    wsch = sch | _DBG_WGRAD_SCHED | (0x10000 if M <= _DBG_WGRAD8_MAXT else 0)
+    wsch = sch | _DBG_WGRAD_SCHED
     if gt is None:
         gt = K.scale_mask_cast(g, scale, out_keep, N, dt)
 
