@@ -253,6 +253,7 @@ def run_evo_eval(args, rank, world, device):
                         traffic_note = "HBM-side bytes per launch (read + write) from profiles/%s: %s" % (tj_name, tj["source"])
             roof = {"bound": "hbm", "kernel": "vr_gemm_nt::nt_kernel (forward)", "achieved": round(gbps, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": traffic, "traffic_note": traffic_note,
+                    "traffic_over_algorithmic": (round(traffic / (by / n), 3) if traffic else None),
                     "launches_per_step": n // args.profile_steps, "avg_launch_us": round(sec / n * 1e6, 2),
                     "flops_per_launch": fl / n, "algorithmic_bytes_per_launch": by / n,
                     "mfma_check": {"achieved_TFLOPs_kept": round(ach, 2), "peak_TFLOPs": MFMA_PEAK["bf16"],
