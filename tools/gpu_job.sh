@@ -2,8 +2,6 @@
 # scratch: the command list of the last gpurun call of the round
 cd $GRAFT_REPO_ROOT
 export PYTHONUNBUFFERED=1
-for i in 1 2 3 4 5 6; do
-  timeout 3000 python -X faulthandler -m pytest tests/ -x -v -m gpu > gpurun_out/r20_tests_$i.txt 2>&1
-  echo "run $i rc=$?"; grep -n " passed\| failed" gpurun_out/r20_tests_$i.txt | tail -1 | cut -c1-200
-  grep -n "Memory access\|fault\|Fatal\|Abort" gpurun_out/r20_tests_$i.txt | head -5
-done
+P=$GRAFT_REPO_ROOT/gpurun_prev
+( AB_STEPS=60 AB_WARMUP=20 tools/ab.sh "X=0" "VITRES_LIB=$P/cap15.so" "VITRES_LIB=$P/cap25.so" "VITRES_LIB=$P/cap30.so" "X=0" "VITRES_LIB=$P/cap15.so" "VITRES_LIB=$P/cap25.so" "VITRES_LIB=$P/cap30.so" 2>&1 ) > gpurun_out/r21_ab.txt
+cat gpurun_out/r21_ab.txt

@@ -36,6 +36,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) s4 lds_s4;
 typedef __attribute__((address_space(1))) const void glb_void;
 
+#ifndef TN_CAP10
+#define TN_CAP10 20
+#endif
 constexpr int BT = 64, NTHR = 256;                       // BT: tokens per slice
 
 __device__ const uint4 zero_chunk[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -614,7 +617,7 @@ bool vr_gemm_tn_group_launch(const vr_gemm_args* args, int count, hipStream_t st
     for (int i = count; i <= MAXG; ++i) g.first[i] = next;
     int grid = next;
     if (!(args[0].sched & 128)) {            // (sched bit 128: nothing runs beside this group -- the step's last)
-        const int lim = (2 * n_cu + 7) / 8 * 8;
+        const int lim = (TN_CAP10 * n_cu / 10 + 7) / 8 * 8;
         grid = next < lim ? next : lim;
     }
     if (TWv == 64) hipLaunchKernelGGL((tn_group_kernel<false, 64>), dim3((unsigned)grid), dim3(NTHR), 0, stream, g);
